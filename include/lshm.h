@@ -1,0 +1,191 @@
+/* liblshm_hip — C ABI of the MI355X (gfx950) implementation of the LSHM
+ * cascaded-autoencoder + k-harmonic-means training step.
+ *
+ * The reference (SarodYatawatta/LSHM @ v2) has no native/FFI boundary: its hot
+ * path is Python calling PyTorch ATen ops.  Each entry point below therefore
+ * names the reference *call site* whose ATen op(s) it replaces (paths relative
+ * to the upstream repo root).  INTEGRATION.md shows the ctypes binding a
+ * maintainer would add on the reference side.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative LSHM_ERR_* code for a bad
+ *    argument / unsupported size / short workspace, or a positive hipError_t;
+ *    lshm_last_error_string() describes the last failure of the calling thread;
+ *  - all tensor pointers are DEVICE pointers to caller-owned, contiguous fp32
+ *    storage (row-major / NCHW unless a leading dimension is given); the library
+ *    allocates nothing: scratch is passed in, sized by the *_workspace_floats
+ *    queries; scalars returned on the device are double precision;
+ *  - `stream` is a hipStream_t (pass the caller's current stream); calls only
+ *    enqueue work (no synchronisation) and are HIP-graph capturable;
+ *  - no global mutable state; distinct streams may be driven from distinct
+ *    threads.
+ */
+#ifndef LSHM_H
+#define LSHM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSHM_OK 0
+#define LSHM_ERR_ARG (-1)
+#define LSHM_ERR_WORKSPACE (-2)
+#define LSHM_ERR_UNSUPPORTED (-3)
+
+/* convolution flavours of the autoencoders */
+#define LSHM_CONV2D_K4S2P1 0  /* nn.Conv2d(..,4,stride=2,padding=1)          src/lofar_models.py:31-41 */
+#define LSHM_TCONV2D_K4S2P1 1 /* nn.ConvTranspose2d(..,4,stride=2,padding=1) src/lofar_models.py:52-57 */
+#define LSHM_CONV1D_K4S4P1 2  /* nn.Conv1d(..,4,stride=4,padding=1)          src/lofar_models.py:115-125 */
+#define LSHM_TCONV1D_K4S4P0 3 /* nn.ConvTranspose1d(..,4,stride=4,padding=0) src/lofar_models.py:137-142 */
+
+typedef void* lshm_stream_t; /* hipStream_t */
+
+int lshm_version(void);
+const char* lshm_last_error_string(void);
+
+/* ---- harmonic features: kron(scales, uv) -> cat(sin, cos)   src/lofar_models.py:60-62,145-147
+ * uv (B,2), scales (H) -> out (B,4H) */
+int lshm_uv_harmonics(const float* uv, const float* scales, int H, int B, float* out,
+                      lshm_stream_t stream);
+
+/* ---- convolution layers, forward + fused bias + optional ELU     src/lofar_models.py:73-78,93-98,158-163,178-183
+ * x (B,Cin,Hin,Win) [1D: Hin=1, Win=L]; weight in torch layout (Conv: (Cout,Cin,k..), ConvTranspose:
+ * (Cin,Cout,k..)); in_bs / out_bs are batch strides in elements (0 = dense). act: 0 none, 1 ELU. */
+int lshm_conv_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B,
+                  int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, int act,
+                  lshm_stream_t stream);
+/* data gradient: dx = op^T(dz, w); if y_in_saved != NULL the result is multiplied by ELU'(y_in_saved)
+ * (the saved *output* of the previous layer), i.e. it is already the pre-activation gradient. */
+int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved,
+                    int B, int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs,
+                    lshm_stream_t stream);
+size_t lshm_conv_wgrad_workspace_floats(int kind, int B, int Cin, int Cout, int Hin, int Win);
+/* weight + bias gradient (deterministic split-K); dw/db overwritten unless accumulate != 0 */
+int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float* db, int B, int Cin,
+                    int Cout, int Hin, int Win, long in_bs, long out_bs, float* workspace,
+                    size_t workspace_floats, int accumulate, lshm_stream_t stream);
+/* dz = gy * ELU'(y) from the saved output y                      (autograd of F.elu) */
+int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t stream);
+
+/* ---- dense layers (F.linear + optional ELU)                    src/lofar_models.py:80-83,89-91,67-68 */
+int lshm_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                    int B, int K, int N, int act, lshm_stream_t stream);
+int lshm_linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
+                      const float* x_saved, long ldxs, int B, int K, int N, lshm_stream_t stream);
+int lshm_linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db,
+                      int B, int K, int N, lshm_stream_t stream);
+
+/* ---- K-harmonic means                                           src/lofar_models.py:199-212
+ * X (N,D) with leading dimension ldx, M (K,D).  loss_sum[0] = sum_i K/(e_i+eps) (caller divides by
+ * N_total*K*D); dX/dM are gradients of gscale * loss_sum * inv_count (inv_count = 1/(N_total*K*D)). */
+size_t lshm_khm_workspace_floats(int N, int D, int K);
+int lshm_khm_fwd_bwd(const float* X, long ldx, const float* M, int N, int D, int K, float p,
+                     float eps, double inv_count, float gscale, double* loss_sum, float* dX,
+                     long lddx, float* dM, int accumulate_dx, float* workspace,
+                     size_t workspace_floats, lshm_stream_t stream);
+/* Zhang's generalised-KHM recursion partial sums (intent of Kmeans.offline_update,
+ * src/lofar_models.py:231-261): num (K,D), den (K); M_new = num/den after a sum over ranks. */
+int lshm_khm_offline_partials(const float* X, long ldx, const float* M, int N, int D, int K, float p,
+                              float eps, float* num, float* den, float* workspace,
+                              size_t workspace_floats, lshm_stream_t stream);
+/* dist[k] = mean_n ||X_n - M_k||^p                              src/evaluate_clustering.py:111-115 */
+int lshm_khm_mean_distances(const float* X, long ldx, const float* M, int N, int D, int K, float p,
+                            float* dist, float* workspace, size_t workspace_floats,
+                            lshm_stream_t stream);
+
+/* ---- Kmeans.cluster_similarity                                  src/lofar_models.py:214-229 */
+int lshm_cluster_sim_fwd_bwd(const float* M, int K, int D, float eps, float gscale, double* loss,
+                             float* dM, int accumulate, lshm_stream_t stream);
+/* ---- augmented_loss(mu, bpb, batch_size)                        src/kharmonic_lofar.py:97-110
+ * loss must have room for 1 + ceil(rows/bpb) doubles (loss[0] = result). */
+int lshm_aug_loss_fwd_bwd(const float* Z, long ldz, int rows, int D, int bpb, int batch_size,
+                          float gscale, double* loss, float* dZ, long lddz, int accumulate,
+                          lshm_stream_t stream);
+/* ---- RICA penalty scale*sum(log cosh z), dz (+)= scale*tanh z   src/kharmonic_lofar.py:169-171 */
+int lshm_logcosh_fwd_bwd(const float* z, long ldz, int rows, int cols, float scale, double* loss,
+                         float* dz, long lddz, int accumulate, lshm_stream_t stream);
+
+/* ---- glue of the closure                                        src/kharmonic_lofar.py:137-158 */
+/* out_row = (x-x1)/2, out_col = per-plane transpose of it (planes = B*C planes of P x P) */
+int lshm_residual_split(const float* x, const float* x1, float* out_row, float* out_col, int planes,
+                        int P, lshm_stream_t stream);
+int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_stream_t stream);
+size_t lshm_recon_workspace_floats(int planes, int P);
+/* sums7 = [sum e^2, y1.r1, sum r1^2, y2.r2, sum r2^2, y3.r3, sum r3^2]; gradients scaled by 1/n;
+ * x3c / gx3c are in the column-vectorised (per-plane transposed) layout of the third AE. */
+int lshm_recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
+                              const float* y1, const float* y2, const float* y3, float rho,
+                              int planes, int P, double* sums7, float* gx1_partial, float* gx2,
+                              float* gx3c, float* workspace, lshm_stream_t stream);
+int lshm_combine_dx1(const float* gx1_partial, const float* gT, const float* gFc, float* gx1,
+                     int planes, int P, lshm_stream_t stream);
+/* y_k += rho * r_k                                                src/kharmonic_lofar.py:200-202 */
+int lshm_multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c,
+                           float* y1, float* y2, float* y3, float rho, int planes, int P,
+                           lshm_stream_t stream);
+
+/* ---- optimiser algebra on flat arenas                           src/kharmonic_lofar.py:92, src/lbfgsnew.py:84-112 */
+int lshm_adam_step_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1,
+                        float beta2, float eps, const int* step_dev, int step_host, float grad_scale,
+                        lshm_stream_t stream);
+int lshm_axpy_flat(float* y, const float* x, float alpha, long n, lshm_stream_t stream);
+int lshm_scale_flat(float* x, float alpha, long n, lshm_stream_t stream);
+/* out[0] = a.b (double); workspace >= 512 floats */
+int lshm_dot_flat(const float* a, const float* b, long n, double* out, float* workspace,
+                  lshm_stream_t stream);
+
+/* ---- FFT feature step: fftn(dims 2,3, ortho) -> fftshift -> cat(Re,Im) -> clamp
+ *      Demo.ipynb:169-175, src/lofar_tools.py:24-30.  x (B,C,128,128) -> out (B,2C,128,128) */
+int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clamp,
+                                    lshm_stream_t stream);
+
+/* ---- fused training-step engine (one ADMM iteration)            src/kharmonic_lofar.py:131-202 */
+typedef struct lshm_engine lshm_engine;
+typedef struct lshm_step_config {
+  int B, C, P;          /* batch, channels (4), patch size (128) */
+  int L, Lt, K;         /* latent dims of AE1 / 1D AEs, number of centroids */
+  float p;              /* K-harmonic order */
+  float alpha, beta, gamma, rho, rica_lambda;
+  int rica;             /* 0/1 */
+  int bpb, batch_size;  /* patches per baseline, baselines used by augmented_loss */
+  int H;                /* number of harmonic scales (4) */
+  float scales[8];
+  int world;            /* data-parallel world size (gradients are averaged over it) */
+} lshm_step_config;
+
+int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);
+void lshm_engine_destroy(lshm_engine* e);
+/* number of floats in the flat parameter arena and the offset of a named tensor
+ * ("net.conv0.weight", "netT.fc1.bias", "mod.M", ...); names follow the reference's state_dict keys */
+long lshm_engine_param_count(const lshm_engine* e);
+int lshm_engine_param_lookup(const lshm_engine* e, const char* name, long* offset, long* numel);
+int lshm_engine_param_name(const lshm_engine* e, int index, char* buf, int buflen, long* offset,
+                           long* numel, int* ndim, long* shape /* >= 4 */);
+size_t lshm_engine_workspace_floats(const lshm_engine* e);
+/* closure forward + backward: fills grads (same layout as params) and terms[16] (double, device):
+ * [0..7] = loss0, loss1, loss2, loss3, kdist, aug, sim, rica (already weighted, as logged upstream),
+ * [8] = total.  With world > 1 the loss terms / gradients are this rank's share (sum over ranks = global). */
+int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* grads, const float* x,
+                                 const float* uv, const float* y1, const float* y2, const float* y3,
+                                 double* terms, float* workspace, size_t workspace_floats,
+                                 lshm_stream_t stream);
+/* closure forward only (line-search evaluations of LBFGS): terms as above */
+int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x, const float* uv,
+                             const float* y1, const float* y2, const float* y3, double* terms,
+                             float* workspace, size_t workspace_floats, lshm_stream_t stream);
+/* no-grad forward of the three AEs and y_k += rho r_k              src/kharmonic_lofar.py:187-202 */
+int lshm_engine_multiplier_update(lshm_engine* e, const float* params, const float* x,
+                                  const float* uv, float* y1, float* y2, float* y3,
+                                  float* workspace, size_t workspace_floats, lshm_stream_t stream);
+/* forward of the three AEs only: latents Mu (B, L+2Lt) and reconstructions (optional outputs) */
+int lshm_engine_encode(lshm_engine* e, const float* params, const float* x, const float* uv,
+                       float* Mu, float* x1, float* x2, float* x3, float* workspace,
+                       size_t workspace_floats, lshm_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSHM_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of liblshm_hip.so (C ABI declared in include/lshm.h).
+
+The shared library is built in-tree by ``make`` / ``__graft_entry__.build()``.
+There is NO fallback: if the library is missing or no HIP device is present the
+product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblshm_hip.so")
+
+_lib = None
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+c_long = C.c_long
+c_int = C.c_int
+c_size_t = C.c_size_t
+c_float = C.c_float
+c_double = C.c_double
+c_void_p = C.c_void_p
+
+
+class StepConfig(C.Structure):
+    """Mirror of lshm_step_config (include/lshm.h)."""
+    _fields_ = [("B", c_int), ("C", c_int), ("P", c_int), ("L", c_int), ("Lt", c_int), ("K", c_int),
+                ("p", c_float), ("alpha", c_float), ("beta", c_float), ("gamma", c_float),
+                ("rho", c_float), ("rica_lambda", c_float), ("rica", c_int), ("bpb", c_int),
+                ("batch_size", c_int), ("H", c_int), ("scales", c_float * 8), ("world", c_int)]
+
+
+_SIGNATURES = {
+    "lshm_version": (c_int, []),
+    "lshm_last_error_string": (C.c_char_p, []),
+    "lshm_uv_harmonics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "lshm_conv_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                              c_int, c_long, c_long, c_int, c_void_p]),
+    "lshm_conv_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_long, c_long, c_void_p]),
+    "lshm_conv_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "lshm_conv_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                c_int, c_long, c_long, c_void_p, c_size_t, c_int, c_void_p]),
+    "lshm_elu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "lshm_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
+                                c_int, c_void_p]),
+    "lshm_linear_dgrad": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int,
+                                  c_int, c_int, c_void_p]),
+    "lshm_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int,
+                                  c_int, c_void_p]),
+    "lshm_khm_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "lshm_khm_fwd_bwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                                 c_double, c_float, c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p,
+                                 c_size_t, c_void_p]),
+    "lshm_khm_offline_partials": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_float, c_float,
+                                          c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lshm_khm_mean_distances": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                        c_void_p, c_size_t, c_void_p]),
+    "lshm_cluster_sim_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_int,
+                                         c_void_p]),
+    "lshm_aug_loss_fwd_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                      c_void_p, c_long, c_int, c_void_p]),
+    "lshm_logcosh_fwd_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_long,
+                                     c_int, c_void_p]),
+    "lshm_residual_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lshm_plane_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lshm_recon_workspace_floats": (c_size_t, [c_int, c_int]),
+    "lshm_recon_losses_fwd_bwd": (c_int, [c_void_p] * 7 + [c_float, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "lshm_combine_dx1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lshm_multiplier_update": (c_int, [c_void_p] * 7 + [c_float, c_int, c_int, c_void_p]),
+    "lshm_adam_step_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,
+                                    c_float, c_void_p, c_int, c_float, c_void_p]),
+    "lshm_axpy_flat": (c_int, [c_void_p, c_void_p, c_float, c_long, c_void_p]),
+    "lshm_scale_flat": (c_int, [c_void_p, c_float, c_long, c_void_p]),
+    "lshm_dot_flat": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "lshm_fft2_ortho_shift_cat_clamp": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "lshm_engine_create": (c_int, [C.POINTER(StepConfig), C.POINTER(c_void_p)]),
+    "lshm_engine_destroy": (None, [c_void_p]),
+    "lshm_engine_param_count": (c_long, [c_void_p]),
+    "lshm_engine_param_lookup": (c_int, [c_void_p, C.c_char_p, C.POINTER(c_long), C.POINTER(c_long)]),
+    "lshm_engine_param_name": (c_int, [c_void_p, c_int, C.c_char_p, c_int, C.POINTER(c_long),
+                                       C.POINTER(c_long), C.POINTER(c_int), C.POINTER(c_long)]),
+    "lshm_engine_workspace_floats": (c_size_t, [c_void_p]),
+    "lshm_engine_forward_backward": (c_int, [c_void_p] * 9 + [c_void_p, c_size_t, c_void_p]),
+    "lshm_engine_forward_loss": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
+    "lshm_engine_multiplier_update": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "lshm_engine_encode": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load():
+    """dlopen the library and attach prototypes (no device needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"lshm_amd: HIP library not built ({LIB_PATH} missing). Run `make` or "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` - there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError -> a declared symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().lshm_last_error_string().decode("utf-8", "replace")
+        raise RuntimeError(f"lshm_amd: {what or 'kernel call'} failed (code {rc}): {msg}")
+
+
+def require_device(*tensors: torch.Tensor):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("lshm_amd: tensors must live on a HIP device (cuda:N); there is no CPU path")
+        if t.dtype != torch.float32:
+            raise RuntimeError(f"lshm_amd: expected float32 tensors, got {t.dtype}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

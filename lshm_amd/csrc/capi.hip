@@ -1,0 +1,201 @@
+// extern "C" surface of liblshm_hip (declared in include/lshm.h): argument
+// checking + translation to the internal launchers.  No torch types, no
+// allocation, no synchronisation.
+#include "../../include/lshm.h"
+#include "kernels.h"
+
+#include <string.h>
+
+namespace lshm {
+static thread_local char g_err[256] = "";
+void set_last_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) return LSHM_OK;
+  snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+  return (int)e;
+}
+}  // namespace lshm
+
+using namespace lshm;
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define REQUIRE(cond, msg)        \
+  do {                            \
+    if (!(cond)) {                \
+      set_last_error(msg);        \
+      return LSHM_ERR_ARG;        \
+    }                             \
+  } while (0)
+
+static int make_layer(int kind, int B, int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs,
+                      ConvLayer* L) {
+  REQUIRE(kind >= 0 && kind <= 3, "conv: unknown kind");
+  REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv: non-positive dimension");
+  if (kind == 0) REQUIRE(Hin % 4 == 0 && Win % 4 == 0, "conv2d k4s2p1: H and W must be multiples of 4");
+  if (kind == 1) REQUIRE(Hin >= 1 && Win >= 1, "tconv2d: bad size");
+  if (kind >= 2) REQUIRE(Hin == 1, "1D conv: Hin must be 1");
+  if (kind == 2) REQUIRE(Win % 16 == 0, "conv1d k4s4p1: L must be a multiple of 16");
+  L->kind = kind; L->B = B; L->Cin = Cin; L->Cout = Cout; L->Hin = Hin; L->Win = Win;
+  int Ho, Wo;
+  conv_out_dims(*L, Ho, Wo);
+  L->in_bs = in_bs ? in_bs : (long)Cin * Hin * Win;
+  L->out_bs = out_bs ? out_bs : (long)Cout * Ho * Wo;
+  REQUIRE(L->in_bs % 4 == 0 && L->out_bs % 4 == 0, "conv: batch strides must be multiples of 4");
+  return LSHM_OK;
+}
+
+extern "C" {
+
+int lshm_version(void) { return 100; }
+const char* lshm_last_error_string(void) { return g_err; }
+
+int lshm_uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, lshm_stream_t s) {
+  REQUIRE(uv && scales && out && H > 0 && B >= 0, "uv_harmonics: bad argument");
+  if (B == 0) return LSHM_OK;
+  return uv_harmonics(uv, scales, H, B, out, ST(s));
+}
+
+int lshm_conv_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B, int Cin,
+                  int Cout, int Hin, int Win, long in_bs, long out_bs, int act, lshm_stream_t s) {
+  REQUIRE(x && w && y, "conv_fwd: null pointer");
+  ConvLayer L;
+  int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
+  if (rc) return rc;
+  return conv_layer_fwd(L, x, w, bias, y, act, ST(s));
+}
+int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved, int B,
+                    int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, lshm_stream_t s) {
+  REQUIRE(dz && w && dx, "conv_dgrad: null pointer");
+  ConvLayer L;
+  int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
+  if (rc) return rc;
+  return conv_layer_dgrad(L, dz, w, dx, y_in_saved, ST(s));
+}
+size_t lshm_conv_wgrad_workspace_floats(int kind, int B, int Cin, int Cout, int Hin, int Win) {
+  ConvLayer L;
+  if (make_layer(kind, B, Cin, Cout, Hin, Win, 0, 0, &L)) return 0;
+  return conv_wgrad_workspace_floats(L);
+}
+int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float* db, int B, int Cin,
+                    int Cout, int Hin, int Win, long in_bs, long out_bs, float* ws, size_t wsf,
+                    int accumulate, lshm_stream_t s) {
+  REQUIRE(x && dz && dw && ws, "conv_wgrad: null pointer");
+  ConvLayer L;
+  int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
+  if (rc) return rc;
+  return conv_layer_wgrad(L, x, dz, dw, db, ws, wsf, accumulate, ST(s));
+}
+int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t s) {
+  REQUIRE(gy && y && dz && n >= 0, "elu_bwd: bad argument");
+  if (n == 0) return LSHM_OK;
+  return elu_bwd(gy, y, dz, n, ST(s));
+}
+
+int lshm_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                    int B, int K, int N, int act, lshm_stream_t s) {
+  REQUIRE(x && w && y && B > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N, "linear_fwd: bad argument");
+  return linear_fwd(x, ldx, w, bias, y, ldy, B, K, N, act, ST(s));
+}
+int lshm_linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
+                      const float* x_saved, long ldxs, int B, int K, int N, lshm_stream_t s) {
+  REQUIRE(dz && w && dx && B > 0 && K > 0 && N > 0 && lddz >= N && lddx >= K, "linear_dgrad: bad argument");
+  return linear_dgrad(dz, lddz, w, dx, lddx, x_saved, ldxs, B, K, N, ST(s));
+}
+int lshm_linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
+                      int K, int N, lshm_stream_t s) {
+  REQUIRE(x && dz && dw && B > 0 && K > 0 && N > 0, "linear_wgrad: bad argument");
+  return linear_wgrad(x, ldx, dz, lddz, dw, db, B, K, N, 0, ST(s));
+}
+
+size_t lshm_khm_workspace_floats(int N, int D, int K) { return khm_workspace_floats(N, D, K); }
+int lshm_khm_fwd_bwd(const float* X, long ldx, const float* M, int N, int D, int K, float p, float eps,
+                     double inv_count, float gscale, double* loss_sum, float* dX, long lddx, float* dM,
+                     int accumulate_dx, float* ws, size_t wsf, lshm_stream_t s) {
+  REQUIRE(loss_sum && dM, "khm_fwd_bwd: null output");
+  return khm_fwd_bwd(X, ldx, M, N, D, K, p, eps, inv_count, gscale, loss_sum, dX, lddx, dM,
+                     accumulate_dx, ws, wsf, ST(s));
+}
+int lshm_khm_offline_partials(const float* X, long ldx, const float* M, int N, int D, int K, float p,
+                              float eps, float* num, float* den, float* ws, size_t wsf, lshm_stream_t s) {
+  REQUIRE(num && den, "khm_offline_partials: null output");
+  return khm_offline_partials(X, ldx, M, N, D, K, p, eps, num, den, ws, wsf, ST(s));
+}
+int lshm_khm_mean_distances(const float* X, long ldx, const float* M, int N, int D, int K, float p,
+                            float* dist, float* ws, size_t wsf, lshm_stream_t s) {
+  REQUIRE(dist, "khm_mean_distances: null output");
+  return khm_mean_distances(X, ldx, M, N, D, K, p, dist, ws, wsf, ST(s));
+}
+int lshm_cluster_sim_fwd_bwd(const float* M, int K, int D, float eps, float gscale, double* loss,
+                             float* dM, int accumulate, lshm_stream_t s) {
+  return cluster_sim_fwd_bwd(M, K, D, eps, gscale, loss, dM, accumulate, ST(s));
+}
+int lshm_aug_loss_fwd_bwd(const float* Z, long ldz, int rows, int D, int bpb, int batch_size, float gscale,
+                          double* loss, float* dZ, long lddz, int accumulate, lshm_stream_t s) {
+  return aug_loss_fwd_bwd(Z, ldz, rows, D, bpb, batch_size, gscale, loss, dZ, lddz, accumulate, ST(s));
+}
+int lshm_logcosh_fwd_bwd(const float* z, long ldz, int rows, int cols, float scale, double* loss,
+                         float* dz, long lddz, int accumulate, lshm_stream_t s) {
+  REQUIRE(z && rows >= 0 && cols >= 0, "logcosh: bad argument");
+  return logcosh_mean_fwd_bwd(z, ldz, rows, cols, scale, loss, dz, lddz, accumulate, ST(s));
+}
+
+int lshm_residual_split(const float* x, const float* x1, float* out_row, float* out_col, int planes, int P,
+                        lshm_stream_t s) {
+  REQUIRE(x && x1 && out_col && planes > 0, "residual_split: bad argument");
+  return residual_split(x, x1, out_row, out_col, planes, P, ST(s));
+}
+int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_stream_t s) {
+  REQUIRE(in && out && planes > 0, "plane_transpose: bad argument");
+  return plane_transpose(in, out, planes, P, ST(s));
+}
+size_t lshm_recon_workspace_floats(int planes, int P) { return recon_partials_floats(planes, P); }
+int lshm_recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
+                              const float* y1, const float* y2, const float* y3, float rho, int planes,
+                              int P, double* sums7, float* gx1p, float* gx2, float* gx3c, float* ws,
+                              lshm_stream_t s) {
+  REQUIRE(x && x1 && x2 && x3c && y1 && y2 && y3 && sums7 && gx1p && gx2 && gx3c && ws && planes > 0,
+          "recon_losses: null pointer");
+  return recon_losses_fwd_bwd(x, x1, x2, x3c, y1, y2, y3, rho, planes, P, sums7, gx1p, gx2, gx3c, ws, ST(s));
+}
+int lshm_combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes, int P,
+                     lshm_stream_t s) {
+  REQUIRE(gx1p && gT && gFc && gx1 && planes > 0 && P % 32 == 0, "combine_dx1: bad argument");
+  return combine_dx1(gx1p, gT, gFc, gx1, planes, P, ST(s));
+}
+int lshm_multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c, float* y1,
+                           float* y2, float* y3, float rho, int planes, int P, lshm_stream_t s) {
+  REQUIRE(x && x1 && x2 && x3c && y1 && y2 && y3 && planes > 0, "multiplier_update: bad argument");
+  return multiplier_update(x, x1, x2, x3c, y1, y2, y3, rho, planes, P, ST(s));
+}
+
+int lshm_adam_step_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                        float eps, const int* step_dev, int step_host, float gscale, lshm_stream_t s) {
+  REQUIRE(p && g && m && v && n >= 0, "adam: bad argument");
+  if (n == 0) return LSHM_OK;
+  return adam_step_flat(p, g, m, v, n, lr, b1, b2, eps, step_dev, step_host, gscale, ST(s));
+}
+int lshm_axpy_flat(float* y, const float* x, float alpha, long n, lshm_stream_t s) {
+  REQUIRE(y && x && n >= 0, "axpy: bad argument");
+  if (n == 0) return LSHM_OK;
+  return axpy_flat(y, x, alpha, n, ST(s));
+}
+int lshm_scale_flat(float* x, float alpha, long n, lshm_stream_t s) {
+  REQUIRE(x && n >= 0, "scale: bad argument");
+  if (n == 0) return LSHM_OK;
+  return scale_flat(x, alpha, n, ST(s));
+}
+int lshm_dot_flat(const float* a, const float* b, long n, double* out, float* ws, lshm_stream_t s) {
+  REQUIRE(a && b && out && ws && n >= 0, "dot: bad argument");
+  return dot_flat(a, b, n, out, ws, ST(s));
+}
+
+int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv, lshm_stream_t s) {
+  REQUIRE(x && out && B > 0 && C > 0, "fft2: bad argument");
+  return fft2_ortho_shift_cat_clamp(x, out, B, C, clampv, ST(s));
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Shared device/host helpers for the LSHM gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define LSHM_OK 0
+#define LSHM_ERR_ARG (-1)        // bad argument (null pointer, unsupported size)
+#define LSHM_ERR_WORKSPACE (-2)  // workspace too small
+#define LSHM_ERR_UNSUPPORTED (-3)
+
+namespace lshm {
+
+void set_last_error(const char* msg);
+int check_launch(const char* what);  // hipGetLastError -> code + message
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float elu(float v) { return v > 0.f ? v : expm1f(v); }
+// derivative of ELU(alpha=1) from the saved *output*: 1 if y>0 else y+1
+__device__ __forceinline__ float elu_grad_from_out(float y) { return y > 0.f ? 1.f : y + 1.f; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* smem /* >= 16 */) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (lane == 0) smem[w] = v;
+  __syncthreads();
+  T r = 0;
+  if (threadIdx.x == 0) {
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) r += smem[i];
+  }
+  __syncthreads();
+  return r;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace lshm

@@ -1,0 +1,410 @@
+// Memory-bound glue of the training step: harmonic features, residual/transposes,
+// the fused reconstruction losses + their gradients, multiplier update, Adam and
+// flat-vector algebra.  Reference call sites: src/lofar_models.py:60-62 and
+// src/kharmonic_lofar.py:137-158,187-202,92.  All kernels are coalesced, float4
+// where the layout allows, transposes go through padded LDS tiles, and every
+// reduction is deterministic (fixed-order partials, no float atomics).
+#include "kernels.h"
+
+namespace lshm {
+
+// --------------------------------------------------------------------------
+// uv harmonics: out[b, 2h+c] = sin(scales[h]*uv[b,c]); out[b, 2H+2h+c] = cos(..)
+// --------------------------------------------------------------------------
+__global__ void uv_harmonics_kernel(const float* __restrict__ uv, const float* __restrict__ sc,
+                                    int H, int B, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = 2 * H;
+  if (i >= B * w) return;
+  const int b = i / w, j = i - b * w;
+  const float a = sc[j >> 1] * uv[2 * b + (j & 1)];
+  out[(long)b * 2 * w + j] = sinf(a);
+  out[(long)b * 2 * w + w + j] = cosf(a);
+}
+int uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, hipStream_t st) {
+  const int n = B * 2 * H;
+  hipLaunchKernelGGL(uv_harmonics_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, uv, scales, H, B, out);
+  return check_launch("uv_harmonics");
+}
+
+// same, with the (<= 8) scales passed by value: no device copy of the scales is needed, which
+// keeps the engine's launch sequence free of host->device copies (graph capture friendly)
+struct ScalesArg { float s[8]; };
+__global__ void uv_harmonics_val_kernel(const float* __restrict__ uv, ScalesArg sc, int H, int B,
+                                        float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int w = 2 * H;
+  if (i >= B * w) return;
+  const int b = i / w, j = i - b * w;
+  const float a = sc.s[j >> 1] * uv[2 * b + (j & 1)];
+  out[(long)b * 2 * w + j] = sinf(a);
+  out[(long)b * 2 * w + w + j] = cosf(a);
+}
+int uv_harmonics_host_scales(const float* uv, const float* scales_host, int H, int B, float* out,
+                             hipStream_t st) {
+  if (H > 8) { set_last_error("uv_harmonics: at most 8 scales"); return LSHM_ERR_UNSUPPORTED; }
+  ScalesArg sc;
+  for (int i = 0; i < 8; ++i) sc.s[i] = i < H ? scales_host[i] : 0.f;
+  const int n = B * 2 * H;
+  hipLaunchKernelGGL(uv_harmonics_val_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, uv, sc, H, B, out);
+  return check_launch("uv_harmonics");
+}
+
+__global__ void elu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
+                               float* __restrict__ dz, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dz[i] = gy[i] * elu_grad_from_out(y[i]);
+}
+int elu_bwd(const float* gy, const float* y, float* dz, long n, hipStream_t st) {
+  hipLaunchKernelGGL(elu_bwd_kernel, dim3(min(cdiv(n, 256), 4096)), dim3(256), 0, st, gy, y, dz, n);
+  return check_launch("elu_bwd");
+}
+
+// --------------------------------------------------------------------------
+// 32x32 tile helpers: block (32,8); thread handles rows ty, ty+8, ty+16, ty+24
+// --------------------------------------------------------------------------
+#define TILE 32
+struct TileIdx {
+  long row_off[4];  // offsets of (h0+ty+8i, w0+tx) in the row-major plane
+  long col_off[4];  // offsets of (w0+ty+8i, h0+tx) in the transposed plane
+};
+__device__ __forceinline__ TileIdx tile_idx(int P) {
+  TileIdx t;
+  const long plane = (long)blockIdx.z * P * P;
+  const int h0 = blockIdx.y * TILE, w0 = blockIdx.x * TILE;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    t.row_off[i] = plane + (long)(h0 + threadIdx.y + 8 * i) * P + w0 + threadIdx.x;
+    t.col_off[i] = plane + (long)(w0 + threadIdx.y + 8 * i) * P + h0 + threadIdx.x;
+  }
+  return t;
+}
+
+__global__ __launch_bounds__(256) void residual_split_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ x1,
+                                                             float* __restrict__ out_row,
+                                                             float* __restrict__ out_col, int P) {
+  __shared__ float tile[TILE][TILE + 1];
+  const TileIdx t = tile_idx(P);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float v = (x[t.row_off[i]] - x1[t.row_off[i]]) * 0.5f;
+    if (out_row) out_row[t.row_off[i]] = v;
+    tile[threadIdx.y + 8 * i][threadIdx.x] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out_col[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
+}
+int residual_split(const float* x, const float* x1, float* out_row, float* out_col, int planes,
+                   int P, hipStream_t st) {
+  if (P % TILE) { set_last_error("residual_split: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
+  hipLaunchKernelGGL(residual_split_kernel, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
+                     x, x1, out_row, out_col, P);
+  return check_launch("residual_split");
+}
+
+__global__ __launch_bounds__(256) void plane_transpose_kernel(const float* __restrict__ in,
+                                                              float* __restrict__ out, int P) {
+  __shared__ float tile[TILE][TILE + 1];
+  const TileIdx t = tile_idx(P);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = in[t.row_off[i]];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
+}
+int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t st) {
+  if (P % TILE) { set_last_error("plane_transpose: size must be a multiple of 32"); return LSHM_ERR_ARG; }
+  hipLaunchKernelGGL(plane_transpose_kernel, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
+                     in, out, P);
+  return check_launch("plane_transpose");
+}
+
+// --------------------------------------------------------------------------
+// reduce_partials / channel sums
+// --------------------------------------------------------------------------
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                       long n, int S, int accumulate) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  for (int s = 0; s < S; ++s) acc += partial[(long)s * n + i];
+  out[i] = accumulate ? out[i] + acc : acc;
+}
+int reduce_partials(const float* partial, float* out, long n, int S, int accumulate,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, partial, out, n,
+                     S, accumulate);
+  return check_launch("reduce_partials");
+}
+
+// partial[s*C + c] = sum over images b in slice s, all HW positions, of dz[b*bs + c*HW + r]
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dz, long bs, int B,
+                                                          int C, long HW, float* __restrict__ partial,
+                                                          int S) {
+  __shared__ float red[16];
+  const int c = blockIdx.x, s = blockIdx.y;
+  const int b0 = (int)((long)B * s / S), b1 = (int)((long)B * (s + 1) / S);
+  float acc = 0.f;
+  for (int b = b0; b < b1; ++b) {
+    const float* src = dz + (long)b * bs + (long)c * HW;
+    for (long r = threadIdx.x; r < HW; r += blockDim.x) acc += src[r];
+  }
+  const float tot = block_sum<float>(acc, red);
+  if (threadIdx.x == 0) partial[(long)s * C + c] = tot;
+}
+int channel_sum_partials(const float* dz, long bs, int B, int C, long HW, float* partial, int S,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(HW >= 256 ? 256 : 64), 0, st, dz, bs, B,
+                     C, HW, partial, S);
+  return check_launch("channel_sum");
+}
+
+// --------------------------------------------------------------------------
+// reconstruction losses (src/kharmonic_lofar.py:150-158) and their gradients.
+//   r1 = x-x1, h = r1/2, r2 = h-x2, r3 = h-x3, e = x1+x2+x3-x       (x3 = x3c^T per plane)
+//   sums = [sum e^2, y1.r1, sum r1^2, y2.r2, sum r2^2, y3.r3, sum r3^2]
+//   gx2  = (2e - y2 - rho r2)/n           gx3c = ((2e - y3 - rho r3)/n)^T
+//   gx1p = (2e - y1 - rho r1)/n - (y2 + rho r2 + y3 + rho r3)/(2n)
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void recon_kernel(
+    const float* __restrict__ x, const float* __restrict__ x1, const float* __restrict__ x2,
+    const float* __restrict__ x3c, const float* __restrict__ y1, const float* __restrict__ y2,
+    const float* __restrict__ y3, float rho, float inv_n, int P, double* __restrict__ partials,
+    float* __restrict__ gx1p, float* __restrict__ gx2, float* __restrict__ gx3c) {
+  __shared__ float tile[TILE][TILE + 1];
+  __shared__ double red[16];
+  const TileIdx t = tile_idx(P);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = x3c[t.col_off[i]];
+  __syncthreads();
+  float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float g3[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long o = t.row_off[i];
+    const float xv = x[o], a1 = x1[o], a2 = x2[o];
+    const float a3 = tile[threadIdx.x][threadIdx.y + 8 * i];
+    const float r1 = xv - a1, h = 0.5f * r1, r2 = h - a2, r3 = h - a3;
+    const float e = a1 + a2 + a3 - xv;
+    const float m1 = y1[o], m2 = y2[o], m3 = y3[o];
+    s[0] += e * e;
+    s[1] += m1 * r1; s[2] += r1 * r1;
+    s[3] += m2 * r2; s[4] += r2 * r2;
+    s[5] += m3 * r3; s[6] += r3 * r3;
+    const float t2 = m2 + rho * r2, t3 = m3 + rho * r3;
+    gx2[o] = (2.f * e - t2) * inv_n;
+    g3[i] = (2.f * e - t3) * inv_n;
+    gx1p[o] = (2.f * e - m1 - rho * r1) * inv_n - 0.5f * (t2 + t3) * inv_n;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = g3[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gx3c[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
+  const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  // flatten thread index for block_sum
+  const int tid = threadIdx.y * TILE + threadIdx.x;
+  const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int q = 0; q < 7; ++q) {
+    double v = wave_sum_d((double)s[q]);
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    if (tid == 0) partials[blk * 7 + q] = red[0] + red[1] + red[2] + red[3];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void sum7_kernel(const double* __restrict__ partials, long nblk,
+                                                   double* __restrict__ sums7) {
+  __shared__ double red[16];
+  for (int q = 0; q < 7; ++q) {
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < nblk; i += blockDim.x) acc += partials[i * 7 + q];
+    const double tot = block_sum<double>(acc, red);
+    if (threadIdx.x == 0) sums7[q] = tot;
+  }
+}
+size_t recon_partials_floats(int planes, int P) {
+  return (size_t)planes * (P / TILE) * (P / TILE) * 7 * 2;
+}
+int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
+                         const float* y1, const float* y2, const float* y3, float rho, int planes,
+                         int P, double* sums7, float* gx1p, float* gx2, float* gx3c,
+                         float* block_partials, hipStream_t st) {
+  if (P % TILE) { set_last_error("recon_losses: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
+  const double n = (double)planes * P * P;
+  double* part = reinterpret_cast<double*>(block_partials);
+  dim3 grid(P / TILE, P / TILE, planes);
+  hipLaunchKernelGGL(recon_kernel, grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
+                     (float)(1.0 / n), P, part, gx1p, gx2, gx3c);
+  int rc = check_launch("recon_losses");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum7_kernel, dim3(1), dim3(256), 0, st, part,
+                     (long)grid.x * grid.y * grid.z, sums7);
+  return check_launch("recon_sum7");
+}
+
+// gx1 = gx1p - 0.5*(gT + gFc^T)
+__global__ __launch_bounds__(256) void combine_dx1_kernel(const float* __restrict__ gx1p,
+                                                          const float* __restrict__ gT,
+                                                          const float* __restrict__ gFc,
+                                                          float* __restrict__ gx1, int P) {
+  __shared__ float tile[TILE][TILE + 1];
+  const TileIdx t = tile_idx(P);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = gFc[t.col_off[i]];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long o = t.row_off[i];
+    gx1[o] = gx1p[o] - 0.5f * (gT[o] + tile[threadIdx.x][threadIdx.y + 8 * i]);
+  }
+}
+int combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes, int P,
+                hipStream_t st) {
+  hipLaunchKernelGGL(combine_dx1_kernel, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
+                     gx1p, gT, gFc, gx1, P);
+  return check_launch("combine_dx1");
+}
+
+// y1 += rho (x-x1); y2 += rho (h-x2); y3 += rho (h-x3)   (src/kharmonic_lofar.py:200-202)
+__global__ __launch_bounds__(256) void multiplier_update_kernel(
+    const float* __restrict__ x, const float* __restrict__ x1, const float* __restrict__ x2,
+    const float* __restrict__ x3c, float* __restrict__ y1, float* __restrict__ y2,
+    float* __restrict__ y3, float rho, int P) {
+  __shared__ float tile[TILE][TILE + 1];
+  const TileIdx t = tile_idx(P);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = x3c[t.col_off[i]];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long o = t.row_off[i];
+    const float r1 = x[o] - x1[o], h = 0.5f * r1;
+    y1[o] += rho * r1;
+    y2[o] += rho * (h - x2[o]);
+    y3[o] += rho * (h - tile[threadIdx.x][threadIdx.y + 8 * i]);
+  }
+}
+int multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c, float* y1,
+                      float* y2, float* y3, float rho, int planes, int P, hipStream_t st) {
+  if (P % TILE) { set_last_error("multiplier_update: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
+  hipLaunchKernelGGL(multiplier_update_kernel, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0,
+                     st, x, x1, x2, x3c, y1, y2, y3, rho, P);
+  return check_launch("multiplier_update");
+}
+
+// --------------------------------------------------------------------------
+// Adam over one flat arena (torch.optim.Adam defaults; src/kharmonic_lofar.py:92)
+// --------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                            const int* __restrict__ step_dev, int step_host, float gscale) {
+  const int tstep = step_dev ? *step_dev : step_host;
+  const double c1 = 1.0 - pow((double)b1, (double)tstep);
+  const double c2 = 1.0 - pow((double)b2, (double)tstep);
+  const float step_size = (float)((double)lr / c1);
+  const float inv_sqrt_c2 = (float)(1.0 / sqrt(c2));
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step_size * mi / (sqrtf(vi) * inv_sqrt_c2 + eps);
+  }
+}
+int adam_step_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1,
+                   float b2, float eps, const int* step_dev, int step_host, float gscale,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(adam_kernel, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, st, p, g, m, v, n, lr,
+                     b1, b2, eps, step_dev, step_host, gscale);
+  return check_launch("adam");
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) y[i] += a * x[i];
+}
+int axpy_flat(float* y, const float* x, float alpha, long n, hipStream_t st) {
+  hipLaunchKernelGGL(axpy_kernel, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, st, y, x, alpha, n);
+  return check_launch("axpy");
+}
+__global__ void scale_kernel(float* __restrict__ x, float a, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) x[i] *= a;
+}
+int scale_flat(float* x, float alpha, long n, hipStream_t st) {
+  hipLaunchKernelGGL(scale_kernel, dim3(min(cdiv(n, 256), 2048)), dim3(256), 0, st, x, alpha, n);
+  return check_launch("scale");
+}
+
+// two-stage deterministic dot product; ws >= 2*DOT_BLOCKS floats (holds doubles)
+#define DOT_BLOCKS 256
+__global__ __launch_bounds__(256) void dot_stage1(const float* __restrict__ a, const float* __restrict__ b,
+                                                  long n, double* __restrict__ part) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    acc += (double)a[i] * (double)b[i];
+  const double tot = block_sum<double>(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void dot_stage2(const double* __restrict__ part, int nb,
+                                                  double* __restrict__ out) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += part[i];
+  const double tot = block_sum<double>(acc, red);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+int dot_flat(const float* a, const float* b, long n, double* out, float* ws, hipStream_t st) {
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(dot_stage1, dim3(DOT_BLOCKS), dim3(256), 0, st, a, b, n, part);
+  int rc = check_launch("dot1");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dot_stage2, dim3(1), dim3(256), 0, st, part, DOT_BLOCKS, out);
+  return check_launch("dot2");
+}
+
+// --------------------------------------------------------------------------
+// RICA penalty: loss = scale * sum log cosh(z);  dz (+)= scale * tanh(z)
+// (src/kharmonic_lofar.py:169-171).  One workgroup: the latents are tiny.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void logcosh_kernel(const float* __restrict__ z, long ldz, int rows,
+                                                       int cols, float scale, double* __restrict__ loss,
+                                                       float* __restrict__ dz, long lddz, int accumulate) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  const long n = (long)rows * cols;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    const float v = z[(long)r * ldz + c];
+    const float a = fabsf(v);
+    // log cosh v = |v| + log1p(exp(-2|v|)) - log 2   (no overflow)
+    acc += (double)(a + log1pf(expf(-2.f * a)) - 0.69314718056f);
+    if (dz) {
+      const float gz = scale * tanhf(v);
+      float* d = dz + (long)r * lddz + c;
+      *d = accumulate ? *d + gz : gz;
+    }
+  }
+  const double tot = block_sum<double>(acc, red);
+  if (threadIdx.x == 0 && loss) loss[0] = tot * (double)scale;
+}
+int logcosh_mean_fwd_bwd(const float* z, long ldz, int rows, int cols, float scale, double* loss,
+                         float* dz, long lddz, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(logcosh_kernel, dim3(1), dim3(1024), 0, st, z, ldz, rows, cols, scale, loss, dz,
+                     lddz, accumulate);
+  return check_launch("logcosh");
+}
+
+}  // namespace lshm

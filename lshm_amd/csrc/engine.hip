@@ -1,0 +1,516 @@
+// Native step engine: one ADMM iteration of src/kharmonic_lofar.py:131-202
+// (closure forward, backward, and the no-grad forward + multiplier update) as a
+// fixed sequence of kernel launches on one HIP stream, over a flat parameter /
+// gradient arena and a caller-provided activation workspace.  The engine owns no
+// device memory and never synchronises, so a whole iteration can be captured in
+// a HIP graph by the host.
+//
+// Data layout in HBM (all fp32):
+//   params / grads : one arena; tensors in the reference's state_dict order for
+//                    net, netT, netF (torch layouts) followed by mod.M; offsets
+//                    are multiples of 4 floats.
+//   workspace      : per autoencoder the saved activations
+//                    (conv0..4 outputs, cat1 = [conv5 out | elu(fcuv1)], z1, cat3 =
+//                    [elu(fc2out) | elu(fcuv3)], fc3 out, tconv0..4 outputs, output),
+//                    shared: uv harmonics, Mu = [mu | muT | muF] (B, L+2Lt), the row- and
+//                    column-vectorised residuals, gradient ping-pong buffers, split-K partials.
+#include "../../include/lshm.h"
+#include "kernels.h"
+
+#include <string.h>
+#include <string>
+#include <vector>
+
+namespace lshm {
+
+static const int CHL[7] = {4, 8, 12, 24, 48, 96, 192};  // src/lofar_models.py:31-41 (index 0 = input channels)
+
+struct ParamInfo {
+  std::string name;
+  long offset, numel;
+  int ndim;
+  long shape[4];
+};
+
+struct AEPlan {
+  int ndim;  // 2 or 1
+  int L;     // latent dim
+  int mu_col;  // column offset of this AE's latent inside Mu
+  ConvLayer enc[6], dec[6];
+  // parameter offsets
+  long cw[6], cb[6], tw[6], tb[6];
+  long fcuv1w, fcuv1b, fcuv3w, fcuv3b, fc1w, fc1b, fc2inw, fc2inb, fc2outw, fc2outb, fc3w, fc3b;
+  // workspace offsets (floats)
+  size_t act[5];   // conv0..conv4 outputs
+  size_t cat1, z1, cat3, d0;
+  size_t dact[5];  // tconv0..tconv4 outputs
+  size_t out;      // (B, C, P*P)
+};
+
+}  // namespace lshm
+
+using namespace lshm;
+
+struct lshm_engine {
+  lshm_step_config cfg;
+  int D;        // L + 2 Lt
+  int hdim;     // 4 H
+  std::vector<ParamInfo> params;
+  long nparams;
+  long Moff;
+  AEPlan ae[3];
+  // shared workspace offsets
+  size_t o_scales, o_uvh, o_Mu, o_gMu, o_row, o_col, o_gx1p, o_gx2, o_gx3c, o_gT, o_gFc, o_gx1,
+      o_gA, o_gB, o_dcat1, o_dz1, o_dzmu, o_dcat3, o_dd0, o_part, o_scal, o_dMscratch;
+  size_t part_floats;
+  size_t ws_floats;
+};
+
+namespace lshm {
+
+static long add_param(lshm_engine* e, const std::string& name, std::initializer_list<long> shape) {
+  ParamInfo p;
+  p.name = name;
+  p.ndim = (int)shape.size();
+  p.numel = 1;
+  int i = 0;
+  for (long s : shape) { p.shape[i++] = s; p.numel *= s; }
+  for (; i < 4; ++i) p.shape[i] = 1;
+  p.offset = e->nparams;
+  e->nparams += (p.numel + 3) / 4 * 4;
+  e->params.push_back(p);
+  return p.offset;
+}
+
+static size_t take(size_t& cur, size_t n) {
+  const size_t o = cur;
+  cur += (n + 3) / 4 * 4;
+  return o;
+}
+
+static void plan_ae(lshm_engine* e, int idx, const char* prefix, int ndim, int L, int mu_col,
+                    size_t& cur) {
+  const lshm_step_config& c = e->cfg;
+  AEPlan& a = e->ae[idx];
+  a.ndim = ndim;
+  a.L = L;
+  a.mu_col = mu_col;
+  const int B = c.B, P = c.P, hd = e->hdim;
+  int ch[7];
+  for (int i = 0; i < 7; ++i) ch[i] = CHL[i];
+  ch[0] = c.C;
+  const std::string pre(prefix);
+  for (int i = 0; i < 6; ++i) {
+    const std::string n = pre + ".conv" + std::to_string(i);
+    if (ndim == 2) a.cw[i] = add_param(e, n + ".weight", {ch[i + 1], ch[i], 4, 4});
+    else a.cw[i] = add_param(e, n + ".weight", {ch[i + 1], ch[i], 4});
+    a.cb[i] = add_param(e, n + ".bias", {ch[i + 1]});
+  }
+  a.fcuv1w = add_param(e, pre + ".fcuv1.weight", {hd, hd});
+  a.fcuv1b = add_param(e, pre + ".fcuv1.bias", {hd});
+  a.fcuv3w = add_param(e, pre + ".fcuv3.weight", {hd, hd});
+  a.fcuv3b = add_param(e, pre + ".fcuv3.bias", {hd});
+  a.fc1w = add_param(e, pre + ".fc1.weight", {L, 768 + hd});
+  a.fc1b = add_param(e, pre + ".fc1.bias", {L});
+  if (c.rica) {
+    a.fc2inw = add_param(e, pre + ".fc2in.weight", {L, L});
+    a.fc2inb = add_param(e, pre + ".fc2in.bias", {L});
+    a.fc2outw = add_param(e, pre + ".fc2out.weight", {L, L});
+    a.fc2outb = add_param(e, pre + ".fc2out.bias", {L});
+  }
+  a.fc3w = add_param(e, pre + ".fc3.weight", {768, L + hd});
+  a.fc3b = add_param(e, pre + ".fc3.bias", {768});
+  for (int i = 0; i < 6; ++i) {
+    const std::string n = pre + ".tconv" + std::to_string(i);
+    if (ndim == 2) a.tw[i] = add_param(e, n + ".weight", {ch[6 - i], ch[5 - i], 4, 4});
+    else a.tw[i] = add_param(e, n + ".weight", {ch[6 - i], ch[5 - i], 4});
+    a.tb[i] = add_param(e, n + ".bias", {ch[5 - i]});
+  }
+  // layers + activation workspace
+  const long PP = (long)P * P;
+  for (int i = 0; i < 6; ++i) {
+    ConvLayer& Le = a.enc[i];
+    Le.kind = ndim == 2 ? 0 : 2;
+    Le.B = B; Le.Cin = ch[i]; Le.Cout = ch[i + 1];
+    if (ndim == 2) { Le.Hin = P >> i; Le.Win = P >> i; }
+    else { Le.Hin = 1; Le.Win = (int)(PP >> (2 * i)); }
+    int Ho, Wo;
+    conv_out_dims(Le, Ho, Wo);
+    Le.in_bs = (long)Le.Cin * Le.Hin * Le.Win;
+    Le.out_bs = (i == 5) ? (768 + hd) : (long)Le.Cout * Ho * Wo;
+    if (i < 5) a.act[i] = take(cur, (size_t)B * Le.out_bs);
+    ConvLayer& Ld = a.dec[i];
+    Ld.kind = ndim == 2 ? 1 : 3;
+    Ld.B = B; Ld.Cin = ch[6 - i]; Ld.Cout = ch[5 - i];
+    if (ndim == 2) { Ld.Hin = 2 << i; Ld.Win = 2 << i; }
+    else { Ld.Hin = 1; Ld.Win = 4 << (2 * i); }
+    conv_out_dims(Ld, Ho, Wo);
+    Ld.in_bs = (long)Ld.Cin * Ld.Hin * Ld.Win;
+    Ld.out_bs = (long)Ld.Cout * Ho * Wo;
+    if (i < 5) a.dact[i] = take(cur, (size_t)B * Ld.out_bs);
+  }
+  a.cat1 = take(cur, (size_t)B * (768 + hd));
+  a.z1 = take(cur, (size_t)B * L);
+  a.cat3 = take(cur, (size_t)B * (L + hd));
+  a.d0 = take(cur, (size_t)B * 768);
+  a.out = take(cur, (size_t)B * c.C * PP);
+}
+
+static int ae_forward(const lshm_engine* e, int idx, const float* prm, const float* input,
+                      float* ws, hipStream_t st) {
+  const AEPlan& a = e->ae[idx];
+  const lshm_step_config& c = e->cfg;
+  const int B = c.B, hd = e->hdim, L = a.L, D = e->D;
+  const float* uvh = ws + e->o_uvh;
+  float* cat1 = ws + a.cat1;
+  float* Mu = ws + e->o_Mu + a.mu_col;
+  float* cat3 = ws + a.cat3;
+  int rc;
+  const float* in = input;
+  for (int i = 0; i < 6; ++i) {
+    float* out = (i < 5) ? ws + a.act[i] : cat1;
+    if ((rc = conv_layer_fwd(a.enc[i], in, prm + a.cw[i], prm + a.cb[i], out, 1, st))) return rc;
+    in = out;
+  }
+  if ((rc = linear_fwd(uvh, hd, prm + a.fcuv1w, prm + a.fcuv1b, cat1 + 768, 768 + hd, B, hd, hd, 1, st))) return rc;
+  if (c.rica) {
+    if ((rc = linear_fwd(cat1, 768 + hd, prm + a.fc1w, prm + a.fc1b, ws + a.z1, L, B, 768 + hd, L, 1, st))) return rc;
+    if ((rc = linear_fwd(ws + a.z1, L, prm + a.fc2inw, prm + a.fc2inb, Mu, D, B, L, L, 1, st))) return rc;
+    if ((rc = linear_fwd(Mu, D, prm + a.fc2outw, prm + a.fc2outb, cat3, L + hd, B, L, L, 1, st))) return rc;
+  } else {
+    if ((rc = linear_fwd(cat1, 768 + hd, prm + a.fc1w, prm + a.fc1b, Mu, D, B, 768 + hd, L, 1, st))) return rc;
+    if ((rc = copy2d(Mu, D, cat3, L + hd, B, L, st))) return rc;
+  }
+  if ((rc = linear_fwd(uvh, hd, prm + a.fcuv3w, prm + a.fcuv3b, cat3 + L, L + hd, B, hd, hd, 1, st))) return rc;
+  if ((rc = linear_fwd(cat3, L + hd, prm + a.fc3w, prm + a.fc3b, ws + a.d0, 768, B, L + hd, 768, 0, st))) return rc;
+  in = ws + a.d0;
+  for (int i = 0; i < 6; ++i) {
+    float* out = (i < 5) ? ws + a.dact[i] : ws + a.out;
+    if ((rc = conv_layer_fwd(a.dec[i], in, prm + a.tw[i], prm + a.tb[i], out, i < 5, st))) return rc;
+    in = out;
+  }
+  return LSHM_OK;
+}
+
+// dz_out: gradient w.r.t. the AE output (B,C,P*P); gMu (B,D) holds the gradient w.r.t. the latents.
+// dinput: gradient w.r.t. the AE input, or null.
+static int ae_backward(const lshm_engine* e, int idx, const float* prm, float* grd,
+                       const float* input, const float* dz_out, float* dinput, float* ws,
+                       hipStream_t st) {
+  const AEPlan& a = e->ae[idx];
+  const lshm_step_config& c = e->cfg;
+  const int B = c.B, hd = e->hdim, L = a.L, D = e->D;
+  const float* uvh = ws + e->o_uvh;
+  float* gA = ws + e->o_gA;
+  float* gB = ws + e->o_gB;
+  float* part = ws + e->o_part;
+  const size_t pf = e->part_floats;
+  float* dd0 = ws + e->o_dd0;
+  float* dcat3 = ws + e->o_dcat3;
+  float* dzmu = ws + e->o_dzmu;
+  float* dz1 = ws + e->o_dz1;
+  float* dcat1 = ws + e->o_dcat1;
+  const float* Mu = ws + e->o_Mu + a.mu_col;
+  const float* gMu = ws + e->o_gMu + a.mu_col;
+  const float* cat1 = ws + a.cat1;
+  const float* cat3 = ws + a.cat3;
+  int rc;
+  // ---- decoder, last layer first
+  const float* dz = dz_out;
+  for (int i = 5; i >= 0; --i) {
+    const float* xin = (i == 0) ? ws + a.d0 : ws + a.dact[i - 1];
+    if ((rc = conv_layer_wgrad(a.dec[i], xin, dz, grd + a.tw[i], grd + a.tb[i], part, pf, 0, st))) return rc;
+    float* dx = (i == 0) ? dd0 : ((i & 1) ? gA : gB);
+    // previous activation is an ELU output (except fc3's output feeding tconv0)
+    if ((rc = conv_layer_dgrad(a.dec[i], dz, prm + a.tw[i], dx, i == 0 ? nullptr : xin, st))) return rc;
+    dz = dx;
+  }
+  // ---- fc3 (no activation on its output): dd0 is its pre-activation gradient
+  if ((rc = linear_wgrad(cat3, L + hd, dd0, 768, grd + a.fc3w, grd + a.fc3b, B, L + hd, 768, 0, st))) return rc;
+  if (c.rica) {
+    if ((rc = linear_dgrad(dd0, 768, prm + a.fc3w, dcat3, L + hd, cat3, L + hd, B, L + hd, 768, st))) return rc;
+  } else {
+    // latent == decoder input: add the latent-loss gradient before the ELU' multiply
+    if ((rc = linear_dgrad(dd0, 768, prm + a.fc3w, dcat3, L + hd, cat3, L + hd, B, L + hd, 768, st, gMu, D, L))) return rc;
+  }
+  if ((rc = linear_wgrad(uvh, hd, dcat3 + L, L + hd, grd + a.fcuv3w, grd + a.fcuv3b, B, hd, hd, 0, st))) return rc;
+  const float* dzfc1;  // pre-activation gradient of fc1's output
+  long ld_dzfc1;
+  if (c.rica) {
+    if ((rc = linear_wgrad(Mu, D, dcat3, L + hd, grd + a.fc2outw, grd + a.fc2outb, B, L, L, 0, st))) return rc;
+    if ((rc = linear_dgrad(dcat3, L + hd, prm + a.fc2outw, dzmu, L, Mu, D, B, L, L, st, gMu, D, L))) return rc;
+    if ((rc = linear_wgrad(ws + a.z1, L, dzmu, L, grd + a.fc2inw, grd + a.fc2inb, B, L, L, 0, st))) return rc;
+    if ((rc = linear_dgrad(dzmu, L, prm + a.fc2inw, dz1, L, ws + a.z1, L, B, L, L, st))) return rc;
+    dzfc1 = dz1;
+    ld_dzfc1 = L;
+  } else {
+    dzfc1 = dcat3;
+    ld_dzfc1 = L + hd;
+  }
+  if ((rc = linear_wgrad(cat1, 768 + hd, dzfc1, ld_dzfc1, grd + a.fc1w, grd + a.fc1b, B, 768 + hd, L, 0, st))) return rc;
+  if ((rc = linear_dgrad(dzfc1, ld_dzfc1, prm + a.fc1w, dcat1, 768 + hd, cat1, 768 + hd, B, 768 + hd, L, st))) return rc;
+  if ((rc = linear_wgrad(uvh, hd, dcat1 + 768, 768 + hd, grd + a.fcuv1w, grd + a.fcuv1b, B, hd, hd, 0, st))) return rc;
+  // ---- encoder
+  dz = dcat1;
+  for (int i = 5; i >= 0; --i) {
+    const float* xin = (i == 0) ? input : ws + a.act[i - 1];
+    if ((rc = conv_layer_wgrad(a.enc[i], xin, dz, grd + a.cw[i], grd + a.cb[i], part, pf, 0, st))) return rc;
+    if (i == 0 && !dinput) break;
+    float* dx = (i == 0) ? dinput : ((i & 1) ? gA : gB);
+    if ((rc = conv_layer_dgrad(a.enc[i], dz, prm + a.cw[i], dx, i == 0 ? nullptr : xin, st))) return rc;
+    dz = dx;
+  }
+  return LSHM_OK;
+}
+
+// scal layout (doubles): [0..6] sums7, [7] khm sum, [8] sim, [9..11] rica x3, [12] aug, [13..] aug partials
+__global__ void finalize_terms_kernel(const double* __restrict__ scal, double* __restrict__ terms,
+                                      double n_global, double rho, double khm_scale, int rica) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double l0 = scal[0] / n_global;
+  const double l1 = (scal[1] + 0.5 * rho * scal[2]) / n_global;
+  const double l2 = (scal[3] + 0.5 * rho * scal[4]) / n_global;
+  const double l3 = (scal[5] + 0.5 * rho * scal[6]) / n_global;
+  const double kd = scal[7] * khm_scale;
+  const double sim = scal[8];
+  const double rc = rica ? scal[9] + scal[10] + scal[11] : 0.0;
+  const double aug = scal[12];
+  terms[0] = l0; terms[1] = l1; terms[2] = l2; terms[3] = l3;
+  terms[4] = kd; terms[5] = aug; terms[6] = sim; terms[7] = rc;
+  terms[8] = l0 + l1 + l2 + l3 + kd + aug + sim + rc;
+}
+
+static int three_forward(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws,
+                         hipStream_t st) {
+  const lshm_step_config& c = e->cfg;
+  int rc;
+  if ((rc = uv_harmonics_host_scales(uv, c.scales, c.H, c.B, ws + e->o_uvh, st))) return rc;
+  if ((rc = ae_forward(e, 0, prm, x, ws, st))) return rc;
+  if ((rc = residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st))) return rc;
+  if ((rc = ae_forward(e, 1, prm, ws + e->o_row, ws, st))) return rc;
+  if ((rc = ae_forward(e, 2, prm, ws + e->o_col, ws, st))) return rc;
+  return LSHM_OK;
+}
+
+// losses (and, when grd != null, every gradient) after three_forward
+static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, const float* x,
+                               const float* y1, const float* y2, const float* y3, double* terms,
+                               float* ws, hipStream_t st) {
+  const lshm_step_config& c = e->cfg;
+  const int B = c.B, D = e->D, planes = c.B * c.C;
+  const double world = c.world > 0 ? c.world : 1;
+  const double n_global = world * (double)B * c.C * c.P * c.P;
+  double* scal = reinterpret_cast<double*>(ws + e->o_scal);
+  float* gMu = ws + e->o_gMu;
+  float* Mu = ws + e->o_Mu;
+  float* dM = grd ? grd + e->Moff : ws + e->o_dMscratch;
+  const float* M = prm + e->Moff;
+  int rc;
+  // reconstruction terms; the kernel's 1/n uses the local element count, rescale for world > 1 below
+  if ((rc = recon_losses_fwd_bwd(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3,
+                                 c.rho, planes, c.P, scal, ws + e->o_gx1p, ws + e->o_gx2,
+                                 ws + e->o_gx3c, ws + e->o_part, st))) return rc;
+  if (world > 1 && grd) {
+    const long n = (long)planes * c.P * c.P;
+    const float s = (float)(1.0 / world);
+    if ((rc = scale_flat(ws + e->o_gx1p, s, n, st))) return rc;
+    if ((rc = scale_flat(ws + e->o_gx2, s, n, st))) return rc;
+    if ((rc = scale_flat(ws + e->o_gx3c, s, n, st))) return rc;
+  }
+  // latent-space terms: gMu = d/dMu (alpha*khm + gamma*aug + lambda*rica), dM = alpha*khm' + beta*sim'
+  const double inv_count = 1.0 / (world * (double)B * c.K * D);
+  if ((rc = khm_fwd_bwd(Mu, D, M, B, D, c.K, c.p, 1e-9f, inv_count, c.alpha, scal + 7, gMu, D, dM, 0,
+                        ws + e->o_part, e->part_floats, st))) return rc;
+  if ((rc = cluster_sim_fwd_bwd(M, c.K, D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 1, st))) return rc;
+  const int bs_global = (int)(c.batch_size * world);
+  // augmented loss: local groups, global normalisation
+  {
+    const int used = c.batch_size * c.bpb < B ? c.batch_size * c.bpb : B;
+    const float coef_scale = c.gamma;
+    // aug_loss_fwd_bwd normalises by batch_size*bpb*bpb of the value passed: pass the global batch size,
+    // but only the local rows take part
+    if ((rc = aug_loss_fwd_bwd(Mu, D, used, D, c.bpb, bs_global, coef_scale, scal + 12, gMu, D, 1, st))) return rc;
+  }
+  if (c.rica) {
+    const AEPlan* a = e->ae;
+    for (int i = 0; i < 3; ++i) {
+      const float s = (float)(c.rica_lambda / (world * (double)B * a[i].L));
+      if ((rc = logcosh_mean_fwd_bwd(Mu + a[i].mu_col, D, B, a[i].L, s, scal + 9 + i, gMu + a[i].mu_col, D, 1, st))) return rc;
+    }
+  }
+  hipLaunchKernelGGL(finalize_terms_kernel, dim3(1), dim3(64), 0, st, scal, terms, n_global, (double)c.rho,
+                     (double)c.alpha * inv_count, c.rica);
+  if ((rc = check_launch("finalize_terms"))) return rc;
+  if (!grd) return LSHM_OK;
+  // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
+  if ((rc = ae_backward(e, 1, prm, grd, ws + e->o_row, ws + e->o_gx2, ws + e->o_gT, ws, st))) return rc;
+  if ((rc = ae_backward(e, 2, prm, grd, ws + e->o_col, ws + e->o_gx3c, ws + e->o_gFc, ws, st))) return rc;
+  if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st))) return rc;
+  if ((rc = ae_backward(e, 0, prm, grd, x, ws + e->o_gx1, nullptr, ws, st))) return rc;
+  return LSHM_OK;
+}
+
+}  // namespace lshm
+
+extern "C" {
+
+int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
+  if (!cfg || !out) { set_last_error("engine_create: null argument"); return LSHM_ERR_ARG; }
+  if (cfg->P != 128) { set_last_error("engine: patch size must be 128 (fc1 is 768+16 wide, src/lofar_models.py:45-46)"); return LSHM_ERR_UNSUPPORTED; }
+  if (cfg->B < 1 || cfg->C < 1 || cfg->L < 1 || cfg->Lt < 1 || cfg->K < 1 || cfg->H < 1 || cfg->H > 8 ||
+      cfg->bpb < 1 || cfg->batch_size < 1) {
+    set_last_error("engine_create: bad configuration");
+    return LSHM_ERR_ARG;
+  }
+  if (cfg->K > 64 || cfg->L + 2 * cfg->Lt > 512 || cfg->bpb > 32) {
+    set_last_error("engine: supports K <= 64, L+2Lt <= 512, bpb <= 32");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  lshm_engine* e = new lshm_engine();
+  e->cfg = *cfg;
+  if (e->cfg.world < 1) e->cfg.world = 1;
+  e->D = cfg->L + 2 * cfg->Lt;
+  e->hdim = 4 * cfg->H;
+  e->nparams = 0;
+  size_t cur = 0;
+  const int B = cfg->B;
+  const long img = (long)cfg->C * cfg->P * cfg->P;
+  plan_ae(e, 0, "net", 2, cfg->L, 0, cur);
+  plan_ae(e, 1, "netT", 1, cfg->Lt, cfg->L, cur);
+  plan_ae(e, 2, "netF", 1, cfg->Lt, cfg->L + cfg->Lt, cur);
+  e->Moff = add_param(e, "mod.M", {cfg->K, e->D});
+  e->o_scales = take(cur, 8);
+  e->o_uvh = take(cur, (size_t)B * e->hdim);
+  e->o_Mu = take(cur, (size_t)B * e->D);
+  e->o_gMu = take(cur, (size_t)B * e->D);
+  e->o_row = take(cur, (size_t)B * img);
+  e->o_col = take(cur, (size_t)B * img);
+  e->o_gx1p = take(cur, (size_t)B * img);
+  e->o_gx2 = take(cur, (size_t)B * img);
+  e->o_gx3c = take(cur, (size_t)B * img);
+  e->o_gT = take(cur, (size_t)B * img);
+  e->o_gFc = take(cur, (size_t)B * img);
+  e->o_gx1 = take(cur, (size_t)B * img);
+  const size_t gmax = (size_t)B * 8 * (cfg->P / 2) * (cfg->P / 2);
+  e->o_gA = take(cur, gmax);
+  e->o_gB = take(cur, gmax);
+  const int Lmax = cfg->L > cfg->Lt ? cfg->L : cfg->Lt;
+  e->o_dcat1 = take(cur, (size_t)B * (768 + e->hdim));
+  e->o_dz1 = take(cur, (size_t)B * Lmax);
+  e->o_dzmu = take(cur, (size_t)B * Lmax);
+  e->o_dcat3 = take(cur, (size_t)B * (Lmax + e->hdim));
+  e->o_dd0 = take(cur, (size_t)B * 768);
+  e->o_dMscratch = take(cur, (size_t)cfg->K * e->D);
+  // split-K / reduction scratch: the largest consumer among wgrads, KHM and the recon partials
+  size_t pf = khm_workspace_floats(B, e->D, cfg->K);
+  const size_t rp = recon_partials_floats(B * cfg->C, cfg->P);
+  if (rp > pf) pf = rp;
+  for (int a = 0; a < 3; ++a)
+    for (int i = 0; i < 6; ++i) {
+      size_t w = conv_wgrad_workspace_floats(e->ae[a].enc[i]);
+      if (w > pf) pf = w;
+      w = conv_wgrad_workspace_floats(e->ae[a].dec[i]);
+      if (w > pf) pf = w;
+    }
+  e->part_floats = pf;
+  e->o_part = take(cur, pf);
+  const size_t ngroups = (size_t)(B + cfg->bpb - 1) / cfg->bpb;
+  e->o_scal = take(cur, 2 * (16 + ngroups));
+  e->ws_floats = cur;
+  *out = e;
+  return LSHM_OK;
+}
+
+void lshm_engine_destroy(lshm_engine* e) { delete e; }
+
+long lshm_engine_param_count(const lshm_engine* e) { return e ? e->nparams : 0; }
+
+int lshm_engine_param_lookup(const lshm_engine* e, const char* name, long* offset, long* numel) {
+  if (!e || !name) { set_last_error("param_lookup: null argument"); return LSHM_ERR_ARG; }
+  for (const ParamInfo& p : e->params)
+    if (p.name == name) {
+      if (offset) *offset = p.offset;
+      if (numel) *numel = p.numel;
+      return LSHM_OK;
+    }
+  set_last_error("param_lookup: unknown parameter name");
+  return LSHM_ERR_ARG;
+}
+
+int lshm_engine_param_name(const lshm_engine* e, int index, char* buf, int buflen, long* offset,
+                           long* numel, int* ndim, long* shape) {
+  if (!e || index < 0 || index >= (int)e->params.size()) return LSHM_ERR_ARG;
+  const ParamInfo& p = e->params[index];
+  if (buf && buflen > 0) {
+    strncpy(buf, p.name.c_str(), buflen - 1);
+    buf[buflen - 1] = 0;
+  }
+  if (offset) *offset = p.offset;
+  if (numel) *numel = p.numel;
+  if (ndim) *ndim = p.ndim;
+  if (shape) for (int i = 0; i < 4; ++i) shape[i] = p.shape[i];
+  return LSHM_OK;
+}
+
+size_t lshm_engine_workspace_floats(const lshm_engine* e) { return e ? e->ws_floats : 0; }
+
+#define ENGINE_CHECK(cond, msg)     \
+  do {                              \
+    if (!(cond)) {                  \
+      set_last_error(msg);          \
+      return LSHM_ERR_ARG;          \
+    }                               \
+  } while (0)
+
+int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* grads, const float* x,
+                                 const float* uv, const float* y1, const float* y2, const float* y3,
+                                 double* terms, float* ws, size_t wsf, lshm_stream_t s) {
+  ENGINE_CHECK(e && params && grads && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_backward: null pointer");
+  if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  int rc = three_forward(e, params, x, uv, ws, st);
+  if (rc) return rc;
+  return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st);
+}
+
+int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x, const float* uv,
+                             const float* y1, const float* y2, const float* y3, double* terms,
+                             float* ws, size_t wsf, lshm_stream_t s) {
+  ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_loss: null pointer");
+  if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  int rc = three_forward(e, params, x, uv, ws, st);
+  if (rc) return rc;
+  return losses_and_backward(e, params, nullptr, x, y1, y2, y3, terms, ws, st);
+}
+
+int lshm_engine_multiplier_update(lshm_engine* e, const float* params, const float* x, const float* uv,
+                                  float* y1, float* y2, float* y3, float* ws, size_t wsf,
+                                  lshm_stream_t s) {
+  ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update: null pointer");
+  if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  int rc = three_forward(e, params, x, uv, ws, st);
+  if (rc) return rc;
+  const lshm_step_config& c = e->cfg;
+  return multiplier_update(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3, c.rho,
+                           c.B * c.C, c.P, st);
+}
+
+int lshm_engine_encode(lshm_engine* e, const float* params, const float* x, const float* uv, float* Mu,
+                       float* x1, float* x2, float* x3, float* ws, size_t wsf, lshm_stream_t s) {
+  ENGINE_CHECK(e && params && x && uv && ws, "engine_encode: null pointer");
+  if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  int rc = three_forward(e, params, x, uv, ws, st);
+  if (rc) return rc;
+  const lshm_step_config& c = e->cfg;
+  const size_t img = (size_t)c.B * c.C * c.P * c.P;
+  if (Mu && (rc = hipMemcpyAsync(Mu, ws + e->o_Mu, sizeof(float) * c.B * e->D, hipMemcpyDeviceToDevice, st))) return rc;
+  if (x1 && (rc = hipMemcpyAsync(x1, ws + e->ae[0].out, sizeof(float) * img, hipMemcpyDeviceToDevice, st))) return rc;
+  if (x2 && (rc = hipMemcpyAsync(x2, ws + e->ae[1].out, sizeof(float) * img, hipMemcpyDeviceToDevice, st))) return rc;
+  if (x3 && (rc = plane_transpose(ws + e->ae[2].out, x3, c.B * c.C, c.P, st))) return rc;
+  return LSHM_OK;
+}
+
+}  // extern "C"

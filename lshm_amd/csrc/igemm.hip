@@ -1,0 +1,477 @@
+// Implicit-GEMM family on the exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// One kernel template serves every GEMM-shaped op of the autoencoders
+// (reference: src/lofar_models.py:31-57,73-98 for the 2D AE, :115-142,158-183
+// for the 1D AEs): k4s2p1 conv2d forward / data-gradient / weight-gradient (the
+// transposed conv is the data-gradient kernel with the roles of the tensors
+// swapped), k4s4 conv1d forward / data-gradient / weight-gradient, and the
+// small dense layers.  Operand gathers, tile->tensor index maps and fused
+// epilogues (bias, ELU, multiply by ELU' of a saved activation) are policy
+// classes; the mainloop stages A and B tiles through LDS in bank-conflict-free
+// layouts and feeds 16x16x4 f32 MFMAs, which are bit-for-bit an fmaf chain, so
+// results match the fp32 CPU reference to rounding.
+//
+// 64-wide wavefronts: a 256-thread workgroup is 4 waves stacked along M; each
+// wave owns (BM/64) x (BN/16) accumulator tiles.
+#include "kernels.h"
+
+namespace lshm {
+
+// --------------------------------------------------------------------------
+// mainloop
+// --------------------------------------------------------------------------
+template <class P, int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) {
+  constexpr int NT = 256;
+  constexpr int TM = BM / 64, TN = BN / 16;
+  // LDS leading dimensions: [k][m]/[k][n] images need ld == 16 (mod 32), [m][k]/[n][k]
+  // images ld == BK+2, so that the 2x32-lane groups of ds_read_b32 hit 32 distinct banks.
+  constexpr int LDA = P::A_M_FAST ? (BM + 16) : (BK + 2);
+  constexpr int LDB = P::B_N_FAST ? ((BN % 32 == 16) ? BN : BN + 16) : (BK + 2);
+  constexpr int A_ELEMS = P::A_M_FAST ? BK * LDA : BM * LDA;
+  constexpr int B_ELEMS = P::B_N_FAST ? BK * LDB : BN * LDB;
+  __shared__ float smem[A_ELEMS + B_ELEMS];
+  float* As = smem;
+  float* Bs = smem + A_ELEMS;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int lm = lane & 15, lk = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
+  int kbeg, kend;
+  P::k_range(p, z, kbeg, kend);
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-thread fixed "fast" coordinates of the gathers
+  typename P::FastA fa;
+  typename P::FastB fb;
+  if (P::A_M_FAST) fa = P::a_fast(p, m0 + (t % BM), z);
+  if (P::B_N_FAST) fb = P::b_fast(p, n0 + (t % BN), z);
+
+  const int wm0 = wave * (BM / 4);
+
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // ---- stage A
+    if (P::A_M_FAST) {
+      const int ml = t % BM;
+#pragma unroll 4
+      for (int kl = t / BM; kl < BK; kl += NT / BM) {
+        const int k = k0 + kl;
+        As[kl * LDA + ml] = (k < kend) ? P::a_load(p, fa, m0 + ml, k, z) : 0.f;
+      }
+    } else {
+      const int kl = t % BK;
+      const int k = k0 + kl;
+      if (k < kend) fa = P::a_fast(p, k, z);
+#pragma unroll 4
+      for (int ml = t / BK; ml < BM; ml += NT / BK)
+        As[ml * LDA + kl] = (k < kend) ? P::a_load(p, fa, m0 + ml, k, z) : 0.f;
+    }
+    // ---- stage B
+    if (P::B_N_FAST) {
+      const int nl = t % BN;
+      for (int kl = t / BN; kl < BK; kl += NT / BN) {
+        const int k = k0 + kl;
+        Bs[kl * LDB + nl] = (k < kend) ? P::b_load(p, fb, k, n0 + nl, z) : 0.f;
+      }
+    } else {
+      const int kl = t % BK;
+      const int k = k0 + kl;
+      if (k < kend) fb = P::b_fast(p, k, z);
+      for (int nl = t / BK; nl < BN; nl += NT / BK)
+        Bs[nl * LDB + kl] = (k < kend) ? P::b_load(p, fb, k, n0 + nl, z) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ++ks) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = P::A_M_FAST ? As[(4 * ks + lk) * LDA + wm0 + 16 * i + lm]
+                           : As[(wm0 + 16 * i + lm) * LDA + 4 * ks + lk];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = P::B_N_FAST ? Bs[(4 * ks + lk) * LDB + 16 * j + lm]
+                           : Bs[(16 * j + lm) * LDB + 4 * ks + lk];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // ---- epilogue: lane holds rows 4*lk..4*lk+3 of column lm in each 16x16 tile
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      P::store(p, m0 + wm0 + 16 * i + 4 * lk, n0 + 16 * j + lm, acc[i][j], z);
+}
+
+__device__ __forceinline__ float epi(float v, float bias, int act) {
+  v += bias;
+  return act ? elu(v) : v;
+}
+
+// --------------------------------------------------------------------------
+// conv2d k4 s2 p1 forward:  y[b,co,oy,ox] = sum_{ci,ky,kx} w[co,ci,ky,kx] x[b,ci,2oy-1+ky,2ox-1+kx]
+// (also the data-gradient of the transposed conv)
+// --------------------------------------------------------------------------
+struct Conv2dFwd {
+  static constexpr bool A_M_FAST = true, B_N_FAST = false;
+  using Params = Conv2dFwdParams;
+  struct FastA { const float* base; int iy0, ix0; };
+  struct FastB { int k; };
+  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
+  __device__ static FastA a_fast(const Params& p, int m, int) {
+    FastA f;
+    if (m >= p.M) { f.base = nullptr; f.iy0 = f.ix0 = 0; return f; }
+    const int hw = p.Ho * p.Wo;
+    const int b = m / hw, r = m - b * hw;
+    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    f.base = p.x + (long)b * p.x_bs;
+    f.iy0 = 2 * oy - 1;
+    f.ix0 = 2 * ox - 1;
+    return f;
+  }
+  __device__ static float a_load(const Params& p, const FastA& f, int, int k, int) {
+    if (!f.base) return 0.f;
+    const int ci = k >> 4, iy = f.iy0 + ((k >> 2) & 3), ix = f.ix0 + (k & 3);
+    if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) return 0.f;
+    return f.base[((long)ci * p.H + iy) * p.W + ix];
+  }
+  __device__ static FastB b_fast(const Params&, int k, int) { return FastB{k}; }
+  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
+    return n < p.N ? p.w[(long)n * p.K + k] : 0.f;
+  }
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
+    if (m >= p.M || n >= p.N) return;
+    const int hw = p.Ho * p.Wo;
+    const int b = m / hw, r = m - b * hw;
+    const long idx = (long)b * p.y_bs + (long)n * hw + r;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = epi(v[i], bias, p.act);
+    if (p.dact) {
+      const f32x4 s = *reinterpret_cast<const f32x4*>(p.dact + idx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] *= elu_grad_from_out(s[i]);
+    }
+    *reinterpret_cast<f32x4*>(p.y + idx) = o;
+  }
+};
+
+// --------------------------------------------------------------------------
+// conv2d k4 s2 p1 data-gradient == transposed-conv forward, one output parity
+// (py,px) = (z>>1, z&1) per grid.z slice:
+//   big[b,cb,2m+py,2n+px] = sum_{cs,t,u} small[b,cs,m+py-t,n+px-u] w[cs,cb,2t+1-py,2u+1-px]
+// --------------------------------------------------------------------------
+struct Conv2dDgrad {
+  static constexpr bool A_M_FAST = true, B_N_FAST = true;
+  using Params = Conv2dDgradParams;
+  struct FastA { const float* base; int mm, nn; };
+  struct FastB { int n; };
+  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
+  __device__ static FastA a_fast(const Params& p, int m, int) {
+    FastA f;
+    if (m >= p.M) { f.base = nullptr; f.mm = f.nn = 0; return f; }
+    const int hw = p.Hs * p.Ws;
+    const int b = m / hw, r = m - b * hw;
+    f.mm = r / p.Ws;
+    f.nn = r - f.mm * p.Ws;
+    f.base = p.s + (long)b * p.s_bs;
+    return f;
+  }
+  __device__ static float a_load(const Params& p, const FastA& f, int, int k, int z) {
+    if (!f.base) return 0.f;
+    const int cs = k >> 2, tt = (k >> 1) & 1, u = k & 1;
+    const int iy = f.mm + (z >> 1) - tt, ix = f.nn + (z & 1) - u;
+    if ((unsigned)iy >= (unsigned)p.Hs || (unsigned)ix >= (unsigned)p.Ws) return 0.f;
+    return f.base[((long)cs * p.Hs + iy) * p.Ws + ix];
+  }
+  __device__ static FastB b_fast(const Params&, int n, int) { return FastB{n}; }
+  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int z) {
+    if (n >= p.N) return 0.f;
+    const int cs = k >> 2, tt = (k >> 1) & 1, u = k & 1;
+    const int ky = 2 * tt + 1 - (z >> 1), kx = 2 * u + 1 - (z & 1);
+    return p.w[(((long)cs * p.Cb + n) * 4 + ky) * 4 + kx];
+  }
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int z) {
+    if (n >= p.N) return;
+    const int hw = p.Hs * p.Ws;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    const int Hb = 2 * p.Hs, Wb = 2 * p.Ws;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int mr = m + i;
+      if (mr >= p.M) break;
+      const int b = mr / hw, r = mr - b * hw;
+      const int mm = r / p.Ws, nn = r - mm * p.Ws;
+      const long idx = (long)b * p.big_bs + ((long)n * Hb + 2 * mm + (z >> 1)) * Wb + 2 * nn + (z & 1);
+      float o = epi(v[i], bias, p.act);
+      if (p.dact) o *= elu_grad_from_out(p.dact[idx]);
+      p.big[idx] = o;
+    }
+  }
+};
+
+// --------------------------------------------------------------------------
+// conv2d k4 s2 p1 weight-gradient (split-K over grid.z, deterministic partials):
+//   dW[cs,cb,ky,kx] = sum_{b,oy,ox} small[b,cs,oy,ox] big[b,cb,2oy-1+ky,2ox-1+kx]
+// --------------------------------------------------------------------------
+struct Conv2dWgrad {
+  static constexpr bool A_M_FAST = false, B_N_FAST = false;
+  using Params = Conv2dWgradParams;
+  struct FastA { const float* base; };
+  struct FastB { const float* base; int iy0, ix0; };
+  __device__ static void k_range(const Params& p, int z, int& kb, int& ke) {
+    kb = z * p.ksplit;
+    ke = min(p.K, kb + p.ksplit);
+  }
+  __device__ static FastA a_fast(const Params& p, int k, int) {
+    const int hw = p.Hs * p.Ws;
+    const int b = k / hw, r = k - b * hw;
+    return FastA{p.s + (long)b * p.s_bs + r};
+  }
+  __device__ static float a_load(const Params& p, const FastA& f, int m, int, int) {
+    return m < p.M ? f.base[(long)m * p.Hs * p.Ws] : 0.f;
+  }
+  __device__ static FastB b_fast(const Params& p, int k, int) {
+    const int hw = p.Hs * p.Ws;
+    const int b = k / hw, r = k - b * hw;
+    const int oy = r / p.Ws, ox = r - oy * p.Ws;
+    return FastB{p.big + (long)b * p.big_bs, 2 * oy - 1, 2 * ox - 1};
+  }
+  __device__ static float b_load(const Params& p, const FastB& f, int, int n, int) {
+    if (n >= p.N) return 0.f;
+    const int cb = n >> 4, iy = f.iy0 + ((n >> 2) & 3), ix = f.ix0 + (n & 3);
+    const int Hb = 2 * p.Hs, Wb = 2 * p.Ws;
+    if ((unsigned)iy >= (unsigned)Hb || (unsigned)ix >= (unsigned)Wb) return 0.f;
+    return f.base[((long)cb * Hb + iy) * Wb + ix];
+  }
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int z) {
+    if (n >= p.N) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (m + i < p.M) p.partial[((long)z * p.M + m + i) * p.N + n] = v[i];
+  }
+};
+
+// --------------------------------------------------------------------------
+// conv1d k4 s4 forward with left padding `pad`:
+//   y[b,co,j] = sum_{ci,t} w[co,ci,t] x[b,ci,4j-pad+t]
+// (pad=1: the encoder conv; pad=0: data-gradient of the k4 s4 p0 transposed conv)
+// --------------------------------------------------------------------------
+struct Conv1dFwd {
+  static constexpr bool A_M_FAST = true, B_N_FAST = false;
+  using Params = Conv1dFwdParams;
+  struct FastA { const float* base; int j0; };
+  struct FastB { int k; };
+  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
+  __device__ static FastA a_fast(const Params& p, int m, int) {
+    if (m >= p.M) return FastA{nullptr, 0};
+    const int b = m / p.Lo, j = m - b * p.Lo;
+    return FastA{p.x + (long)b * p.x_bs, 4 * j - p.pad};
+  }
+  __device__ static float a_load(const Params& p, const FastA& f, int, int k, int) {
+    if (!f.base) return 0.f;
+    const int ci = k >> 2, pos = f.j0 + (k & 3);
+    if ((unsigned)pos >= (unsigned)p.L) return 0.f;
+    return f.base[(long)ci * p.L + pos];
+  }
+  __device__ static FastB b_fast(const Params&, int k, int) { return FastB{k}; }
+  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
+    return n < p.N ? p.w[(long)n * p.K + k] : 0.f;
+  }
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
+    if (m >= p.M || n >= p.N) return;
+    const int b = m / p.Lo, j = m - b * p.Lo;
+    const long idx = (long)b * p.y_bs + (long)n * p.Lo + j;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+    f32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = epi(v[i], bias, p.act);
+    if (p.dact) {
+      const f32x4 s = *reinterpret_cast<const f32x4*>(p.dact + idx);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] *= elu_grad_from_out(s[i]);
+    }
+    *reinterpret_cast<f32x4*>(p.y + idx) = o;
+  }
+};
+
+// --------------------------------------------------------------------------
+// k4 s4 transposed conv1d forward / conv1d data-gradient:
+//   big[b,cb,4i+t-pad] = sum_cs small[b,cs,i] w[cs,cb,t]      (N = Cb*4, K = Cs)
+// positions of `big` no window reaches (the last `pad` ones) are written as zero.
+// --------------------------------------------------------------------------
+struct Conv1dDgrad {
+  static constexpr bool A_M_FAST = true, B_N_FAST = true;
+  using Params = Conv1dDgradParams;
+  struct FastA { const float* base; };
+  struct FastB { int n; };
+  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
+  __device__ static FastA a_fast(const Params& p, int m, int) {
+    if (m >= p.M) return FastA{nullptr};
+    const int b = m / p.Ls, i = m - b * p.Ls;
+    return FastA{p.s + (long)b * p.s_bs + i};
+  }
+  __device__ static float a_load(const Params& p, const FastA& f, int, int k, int) {
+    return f.base ? f.base[(long)k * p.Ls] : 0.f;
+  }
+  __device__ static FastB b_fast(const Params&, int n, int) { return FastB{n}; }
+  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
+    return n < p.N ? p.w[(long)k * p.N + n] : 0.f;
+  }
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
+    if (n >= p.N) return;
+    const int cb = n >> 2, tt = n & 3;
+    const float bias = p.bias ? p.bias[cb] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mr = m + r;
+      if (mr >= p.M) break;
+      const int b = mr / p.Ls, i = mr - b * p.Ls;
+      const long row = (long)b * p.big_bs + (long)cb * p.Lb;
+      const int pos = 4 * i + tt - p.pad;
+      if ((unsigned)pos < (unsigned)p.Lb) {
+        float o = epi(v[r], bias, p.act);
+        if (p.dact) o *= elu_grad_from_out(p.dact[row + pos]);
+        p.big[row + pos] = o;
+      }
+      if (i == p.Ls - 1)
+        for (int q = 4 * p.Ls - p.pad + tt; q < p.Lb; q += 4) p.big[row + q] = 0.f;
+    }
+  }
+};
+
+// --------------------------------------------------------------------------
+// k4 s4 conv1d weight-gradient (split-K):
+//   dW[cs,cb,t] = sum_{b,i} small[b,cs,i] big[b,cb,4i+t-pad]
+// --------------------------------------------------------------------------
+struct Conv1dWgrad {
+  static constexpr bool A_M_FAST = false, B_N_FAST = false;
+  using Params = Conv1dWgradParams;
+  struct FastA { const float* base; };
+  struct FastB { const float* base; int pos0; };
+  __device__ static void k_range(const Params& p, int z, int& kb, int& ke) {
+    kb = z * p.ksplit;
+    ke = min(p.K, kb + p.ksplit);
+  }
+  __device__ static FastA a_fast(const Params& p, int k, int) {
+    const int b = k / p.Ls, i = k - b * p.Ls;
+    return FastA{p.s + (long)b * p.s_bs + i};
+  }
+  __device__ static float a_load(const Params& p, const FastA& f, int m, int, int) {
+    return m < p.M ? f.base[(long)m * p.Ls] : 0.f;
+  }
+  __device__ static FastB b_fast(const Params& p, int k, int) {
+    const int b = k / p.Ls, i = k - b * p.Ls;
+    return FastB{p.big + (long)b * p.big_bs, 4 * i - p.pad};
+  }
+  __device__ static float b_load(const Params& p, const FastB& f, int, int n, int) {
+    if (n >= p.N) return 0.f;
+    const int cb = n >> 2, pos = f.pos0 + (n & 3);
+    if ((unsigned)pos >= (unsigned)p.Lb) return 0.f;
+    return f.base[(long)cb * p.Lb + pos];
+  }
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int z) {
+    if (n >= p.N) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (m + i < p.M) p.partial[((long)z * p.M + m + i) * p.N + n] = v[i];
+  }
+};
+
+// --------------------------------------------------------------------------
+// generic strided GEMM (dense layers):  C[m,n] = act(sum_k A[m,k] B[k,n] + bias[n]) * dact'
+// --------------------------------------------------------------------------
+template <bool AMF, bool BNF>
+struct Strided {
+  static constexpr bool A_M_FAST = AMF, B_N_FAST = BNF;
+  using Params = StridedGemmParams;
+  struct FastA { int i; };
+  struct FastB { int i; };
+  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
+  __device__ static FastA a_fast(const Params&, int i, int) { return FastA{i}; }
+  __device__ static FastB b_fast(const Params&, int i, int) { return FastB{i}; }
+  __device__ static float a_load(const Params& p, const FastA&, int m, int k, int) {
+    return m < p.M ? p.a[(long)m * p.sam + (long)k * p.sak] : 0.f;
+  }
+  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
+    return n < p.N ? p.b[(long)k * p.sbk + (long)n * p.sbn] : 0.f;
+  }
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
+    if (n >= p.N) return;
+    const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (m + i >= p.M) break;
+      const long idx = (long)(m + i) * p.scm + (long)n * p.scn;
+      float o = epi(v[i], bias, p.act);
+      if (p.add && n < p.add_n) o += p.add[(long)(m + i) * p.sxm + n];
+      if (p.dact) o *= elu_grad_from_out(p.dact[(long)(m + i) * p.sdm + (long)n * p.sdn]);
+      p.c[idx] = o;
+    }
+  }
+};
+
+// --------------------------------------------------------------------------
+// launch helpers
+// --------------------------------------------------------------------------
+template <class P, int BM, int BN, int BK>
+static int launch_cfg(const typename P::Params& p, int M, int N, int Z, hipStream_t st) {
+  dim3 grid(cdiv(M, BM), cdiv(N, BN), Z);
+  hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK>), grid, dim3(256), 0, st, p);
+  return check_launch("igemm");
+}
+
+// choose the N tile from the real N so padding waste stays small
+template <class P, int BM>
+static int launch_by_n(const typename P::Params& p, int M, int N, int Z, hipStream_t st) {
+  if (N <= 16) return launch_cfg<P, BM, 16, 16>(p, M, N, Z, st);
+  if (N <= 32) return launch_cfg<P, BM, 32, 16>(p, M, N, Z, st);
+  if (N <= 48 || (N % 48 == 0 && N % 64 != 0)) return launch_cfg<P, BM, 48, 16>(p, M, N, Z, st);
+  return launch_cfg<P, BM, 64, 16>(p, M, N, Z, st);
+}
+
+template <class P>
+static int launch_auto(const typename P::Params& p, int M, int N, int Z, hipStream_t st) {
+  // small-M problems (deep layers, weight gradients): 64-row tiles give more workgroups
+  if (M <= 64 || (long)cdiv(M, 128) * cdiv(N, 64) * Z < 256) return launch_by_n<P, 64>(p, M, N, Z, st);
+  return launch_by_n<P, 128>(p, M, N, Z, st);
+}
+
+int conv2d_fwd(const Conv2dFwdParams& p, hipStream_t st) {
+  return launch_auto<Conv2dFwd>(p, p.M, p.N, 1, st);
+}
+int conv2d_dgrad(const Conv2dDgradParams& p, hipStream_t st) {
+  return launch_auto<Conv2dDgrad>(p, p.M, p.N, 4, st);
+}
+int conv2d_wgrad(const Conv2dWgradParams& p, int nsplit, hipStream_t st) {
+  return launch_auto<Conv2dWgrad>(p, p.M, p.N, nsplit, st);
+}
+int conv1d_fwd(const Conv1dFwdParams& p, hipStream_t st) {
+  return launch_auto<Conv1dFwd>(p, p.M, p.N, 1, st);
+}
+int conv1d_dgrad(const Conv1dDgradParams& p, hipStream_t st) {
+  return launch_auto<Conv1dDgrad>(p, p.M, p.N, 1, st);
+}
+int conv1d_wgrad(const Conv1dWgradParams& p, int nsplit, hipStream_t st) {
+  return launch_auto<Conv1dWgrad>(p, p.M, p.N, nsplit, st);
+}
+int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, hipStream_t st) {
+  if (a_m_fast && b_n_fast) return launch_auto<Strided<true, true>>(p, p.M, p.N, 1, st);
+  if (a_m_fast) return launch_auto<Strided<true, false>>(p, p.M, p.N, 1, st);
+  if (b_n_fast) return launch_auto<Strided<false, true>>(p, p.M, p.N, 1, st);
+  return launch_auto<Strided<false, false>>(p, p.M, p.N, 1, st);
+}
+
+}  // namespace lshm

@@ -1,0 +1,157 @@
+// Internal launcher interface shared by the C-ABI layer (capi.hip) and the step
+// engine (engine.hip).  All pointers are device pointers; every launcher only
+// enqueues work on `st` (no allocation, no synchronisation: graph-capturable).
+#pragma once
+#include "common.h"
+
+namespace lshm {
+
+// ---- implicit-GEMM problem descriptors (igemm.hip) -------------------------
+struct Conv2dFwdParams {   // y = act(conv2d_k4s2p1(x, w) + bias) [* elu'(dact)]
+  const float* x; const float* w; const float* bias; float* y; const float* dact;
+  int B, Cin, H, W, Cout, Ho, Wo;
+  long x_bs, y_bs;  // batch strides (elements)
+  int act;
+  int M, N, K;
+};
+struct Conv2dDgradParams {  // big = act(tconv2d_k4s2p1(small, w) + bias) [* elu'(dact)]
+  const float* s; const float* w; const float* bias; float* big; const float* dact;
+  int B, Cs, Hs, Ws, Cb;
+  long s_bs, big_bs;
+  int act;
+  int M, N, K;
+};
+struct Conv2dWgradParams {  // partial[z] = small^T (x) im2col(big) over a K slice
+  const float* s; const float* big; float* partial;
+  int B, Cs, Hs, Ws, Cb;
+  long s_bs, big_bs;
+  int M, N, K, ksplit;
+};
+struct Conv1dFwdParams {
+  const float* x; const float* w; const float* bias; float* y; const float* dact;
+  int B, Cin, L, Cout, Lo, pad;
+  long x_bs, y_bs;
+  int act;
+  int M, N, K;
+};
+struct Conv1dDgradParams {
+  const float* s; const float* w; const float* bias; float* big; const float* dact;
+  int B, Cs, Ls, Cb, Lb, pad;
+  long s_bs, big_bs;
+  int act;
+  int M, N, K;
+};
+struct Conv1dWgradParams {
+  const float* s; const float* big; float* partial;
+  int B, Cs, Ls, Cb, Lb, pad;
+  long s_bs, big_bs;
+  int M, N, K, ksplit;
+};
+struct StridedGemmParams {
+  const float* a; const float* b; const float* bias; float* c; const float* dact;
+  long sam, sak, sbk, sbn, scm, scn, sdm, sdn;
+  int act;
+  int M, N, K;
+  // optional addend applied before the ELU' multiply: c = (acc + add[m,n]) * elu'(dact), n < add_n
+  const float* add; long sxm; int add_n;
+};
+
+int conv2d_fwd(const Conv2dFwdParams& p, hipStream_t st);
+int conv2d_dgrad(const Conv2dDgradParams& p, hipStream_t st);
+int conv2d_wgrad(const Conv2dWgradParams& p, int nsplit, hipStream_t st);
+int conv1d_fwd(const Conv1dFwdParams& p, hipStream_t st);
+int conv1d_dgrad(const Conv1dDgradParams& p, hipStream_t st);
+int conv1d_wgrad(const Conv1dWgradParams& p, int nsplit, hipStream_t st);
+int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, hipStream_t st);
+
+// ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
+// kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
+struct ConvLayer {
+  int kind;
+  int B, Cin, Cout;
+  int Hin, Win;       // 1D: Hin = 1, Win = L
+  long in_bs, out_bs; // batch strides of input / output tensors (elements)
+};
+void conv_out_dims(const ConvLayer& L, int& Hout, int& Wout);
+size_t conv_wgrad_workspace_floats(const ConvLayer& L);
+// y = act(op(x,w)+b)
+int conv_layer_fwd(const ConvLayer& L, const float* x, const float* w, const float* b, float* y,
+                   int act, hipStream_t st);
+// dx = op^T(dz, w) [* elu'(x_saved) if dact_in]; dx may be null (first layer)
+int conv_layer_dgrad(const ConvLayer& L, const float* dz, const float* w, float* dx,
+                     const float* dact_in, hipStream_t st);
+// dw, db overwritten (accumulate=0) or accumulated (accumulate=1); ws >= conv_wgrad_workspace_floats
+int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float* dw, float* db,
+                     float* ws, size_t ws_floats, int accumulate, hipStream_t st);
+
+// y[B,N] (ld ldy) = act(x[B,K] (ld ldx) @ w[N,K]^T + b)
+int linear_fwd(const float* x, long ldx, const float* w, const float* b, float* y, long ldy, int B,
+               int K, int N, int act, hipStream_t st);
+// dx[B,K] (ld lddx) = dz[B,N] (ld lddz) @ w[N,K]  [* elu'(xsaved (ld ldxs))]
+int linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
+                 const float* xsaved, long ldxs, int B, int K, int N, hipStream_t st,
+                 const float* add = nullptr, long ldadd = 0, int add_n = 0);
+int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t st);
+// dw[N,K] = dz^T x ; db[N] = colsum(dz)
+int linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
+                 int K, int N, int accumulate, hipStream_t st);
+
+// ---- elementwise / reductions (elementwise.hip) -----------------------------
+int uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, hipStream_t st);
+int uv_harmonics_host_scales(const float* uv, const float* scales_host, int H, int B, float* out,
+                             hipStream_t st);
+int elu_bwd(const float* gy, const float* y, float* dz, long n, hipStream_t st);
+// out_row = (x-x1)/2 ; out_col = per-plane transpose of out_row (planes of P x P)
+int residual_split(const float* x, const float* x1, float* out_row, float* out_col, int planes,
+                   int P, hipStream_t st);
+int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t st);
+// reduce_partials: out[i] (=|+=) sum_{s<S} partial[s*n + i]
+int reduce_partials(const float* partial, float* out, long n, int S, int accumulate,
+                    hipStream_t st);
+int channel_sum_partials(const float* dz, long bs, int B, int C, long HW, float* partial, int S,
+                         hipStream_t st);
+// the seven reductions + gradients of src/kharmonic_lofar.py:150-158 (see elementwise.hip)
+int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
+                         const float* y1, const float* y2, const float* y3, float rho, int planes,
+                         int P, double* sums7, float* gx1p, float* gx2, float* gx3c,
+                         float* block_partials, hipStream_t st);
+size_t recon_partials_floats(int planes, int P);
+int combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes,
+                int P, hipStream_t st);
+int multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c,
+                      float* y1, float* y2, float* y3, float rho, int planes, int P,
+                      hipStream_t st);
+int adam_step_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1,
+                   float b2, float eps, const int* step_dev, int step_host, float gscale,
+                   hipStream_t st);
+int axpy_flat(float* y, const float* x, float alpha, long n, hipStream_t st);
+int dot_flat(const float* a, const float* b, long n, double* out, float* ws, hipStream_t st);
+int scale_flat(float* x, float alpha, long n, hipStream_t st);
+int logcosh_mean_fwd_bwd(const float* z, long ldz, int rows, int cols, float scale, double* loss,
+                         float* dz, long lddz, int accumulate, hipStream_t st);
+
+// ---- k-harmonic means (khm.hip) ---------------------------------------------
+size_t khm_workspace_floats(int N, int D, int K);
+// loss_sum[0] = sum_i K/(e_i+eps) (NOT yet divided by N*K*D);
+// dX = gscale * d(loss_mean)/dX, dM likewise, with loss_mean = loss_sum/(Ntot*K*D)
+int khm_fwd_bwd(const float* X, long ldx, const float* M, int N, int D, int K, float p, float eps,
+                double inv_count, float gscale, double* loss_sum, float* dX, long lddx, float* dM,
+                int accumulate_dx, float* ws, size_t ws_floats, hipStream_t st);
+int khm_offline_partials(const float* X, long ldx, const float* M, int N, int D, int K, float p,
+                         float eps, float* num, float* den, float* ws, size_t ws_floats,
+                         hipStream_t st);
+int khm_mean_distances(const float* X, long ldx, const float* M, int N, int D, int K, float p,
+                       float* dist, float* ws, size_t ws_floats, hipStream_t st);
+
+// ---- small latent-space losses (latent.hip) ---------------------------------
+int cluster_sim_fwd_bwd(const float* M, int K, int D, float eps, float gscale, double* loss,
+                        float* dM, int accumulate, hipStream_t st);
+int aug_loss_fwd_bwd(const float* Z, long ldz, int rows, int D, int bpb, int batch_size,
+                     float gscale, double* loss, float* dZ, long lddz, int accumulate,
+                     hipStream_t st);
+
+// ---- batched 2D FFT feature op (fft.hip) ------------------------------------
+int fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv,
+                               hipStream_t st);
+
+}  // namespace lshm

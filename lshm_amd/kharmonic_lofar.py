@@ -1,0 +1,279 @@
+"""Training-step driver: the ADMM loop body of the reference's
+``src/kharmonic_lofar.py:128-202`` on the native step engine.
+
+One :meth:`KHarmonicTrainer.step` is one iteration of ``for admm in range(Nadmm)``:
+closure forward + backward over the three cascaded autoencoders and the
+K-harmonic / similarity / augmentation / RICA terms, one Adam update of every
+selected parameter group, then the no-grad forward and the multiplier update
+``y_k += rho * r_k``.  All device work is enqueued by three C calls
+(``lshm_engine_forward_backward``, ``lshm_adam_step_flat``,
+``lshm_engine_multiplier_update``) on torch's current stream, so the whole
+iteration can be captured in a HIP graph (``use_graph=True``).
+
+Data parallelism: one process per GPU; patches (whole baselines) are sharded
+over ranks, parameters and Adam state are replicated, and the flat gradient
+arena plus the 9 loss terms are summed with one RCCL all-reduce each per
+closure (``torch.distributed``, backend ``nccl`` == RCCL on ROCm).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Dict, Iterable, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+
+GROUPS = ("net", "netT", "netF", "mod")
+TERM_NAMES = ("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica", "total")
+
+
+@dataclass
+class TrainConfig:
+    """Script constants of src/kharmonic_lofar.py:25-57,92 (defaults identical)."""
+    L: int = 224
+    Lt: int = 16
+    Kc: int = 10
+    Khp: float = 4
+    alpha: float = 0.01
+    beta: float = 0.01
+    gamma: float = 0.01
+    rho: float = 1.0
+    use_rica: bool = True
+    rica_lambda: float = 0.01
+    patch_size: int = 128
+    num_in_channels: int = 4
+    harmonic_scales: Tuple[float, ...] = (1e-4, 1e-3, 1e-2, 1e-1)
+    lr: float = 1e-4
+    betas: Tuple[float, float] = (0.9, 0.999)
+    adam_eps: float = 1e-8
+    # which parameter groups the optimiser updates; upstream ships {"net"} (:86-90) and asks the
+    # user to alternate by hand (README.md:27-30); the benchmark trains all four
+    train_groups: Tuple[str, ...] = GROUPS
+
+
+class KHarmonicTrainer:
+    def __init__(self, cfg: TrainConfig, batch: int, batch_per_bline: int, default_batch: Optional[int] = None,
+                 device: Optional[torch.device] = None, process_group=None):
+        self.cfg = cfg
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise RuntimeError("KHarmonicTrainer needs a HIP device; there is no CPU path")
+        self.lib = L.load()
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+        self.B = int(batch)
+        self.bpb = int(batch_per_bline)
+        self.default_batch = int(default_batch if default_batch is not None else max(1, batch // batch_per_bline))
+        sc = L.StepConfig()
+        sc.B, sc.C, sc.P = self.B, cfg.num_in_channels, cfg.patch_size
+        sc.L, sc.Lt, sc.K = cfg.L, cfg.Lt, cfg.Kc
+        sc.p = float(cfg.Khp)
+        sc.alpha, sc.beta, sc.gamma, sc.rho = cfg.alpha, cfg.beta, cfg.gamma, cfg.rho
+        sc.rica_lambda, sc.rica = cfg.rica_lambda, int(cfg.use_rica)
+        sc.bpb, sc.batch_size = self.bpb, self.default_batch
+        sc.H = len(cfg.harmonic_scales)
+        for i, s in enumerate(cfg.harmonic_scales):
+            sc.scales[i] = s
+        sc.world = self.world
+        self._sc = sc
+        h = C.c_void_p()
+        L.check(self.lib.lshm_engine_create(C.byref(sc), C.byref(h)), "engine_create")
+        self._h = h
+        n = self.lib.lshm_engine_param_count(h)
+        self.nparams = n
+        dev = self.device
+        self.params = torch.zeros(n, device=dev)
+        self.grads = torch.zeros(n, device=dev)
+        self.exp_avg = torch.zeros(n, device=dev)
+        self.exp_avg_sq = torch.zeros(n, device=dev)
+        self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.ws_floats = self.lib.lshm_engine_workspace_floats(h)
+        self.ws = torch.empty(self.ws_floats, device=dev)
+        self.terms = torch.zeros(16, device=dev, dtype=torch.float64)
+        # name -> (offset, shape)
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        buf = C.create_string_buffer(128)
+        off, num, nd = C.c_long(), C.c_long(), C.c_int()
+        shp = (C.c_long * 4)()
+        i = 0
+        while self.lib.lshm_engine_param_name(h, i, buf, 128, C.byref(off), C.byref(num), C.byref(nd), shp) == 0:
+            self.layout[buf.value.decode()] = (off.value, tuple(shp[j] for j in range(nd.value)))
+            i += 1
+        # gradient mask for frozen groups (1 = trained)
+        self.set_train_groups(cfg.train_groups)
+        img = (self.B, cfg.num_in_channels, cfg.patch_size, cfg.patch_size)
+        self.x = torch.zeros(img, device=dev)
+        self.uv = torch.zeros((self.B, 2), device=dev)
+        self.y = [torch.zeros(self.x.numel(), device=dev) for _ in range(3)]
+        self._graph = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self.lib.lshm_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def view(self, name: str, flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        off, shape = self.layout[name]
+        n = 1
+        for s in shape:
+            n *= s
+        return (self.params if flat is None else flat)[off:off + n].view(shape)
+
+    def set_train_groups(self, groups: Iterable[str]):
+        groups = tuple(groups)
+        for g in groups:
+            if g not in GROUPS:
+                raise ValueError(f"unknown parameter group {g!r}")
+        self.train_groups = groups
+        if set(groups) == set(GROUPS):
+            self._mask = None
+            return
+        m = torch.zeros(self.nparams, device=self.device)
+        for name in self.layout:
+            if name.split(".", 1)[0] in groups:
+                self.view(name, m).fill_(1.0)
+        self._mask = m
+
+    def load_state_dicts(self, net=None, netT=None, netF=None, mod=None):
+        """Accepts the reference's four state_dicts (keys 'conv0.weight' ... / 'M')."""
+        with torch.no_grad():
+            for prefix, sd in (("net", net), ("netT", netT), ("netF", netF), ("mod", mod)):
+                if sd is None:
+                    continue
+                for k, v in sd.items():
+                    name = f"{prefix}.{k}"
+                    if name not in self.layout:
+                        raise KeyError(f"unexpected key {k!r} for {prefix}")
+                    dst = self.view(name)
+                    if tuple(v.shape) != tuple(dst.shape):
+                        raise RuntimeError(f"size mismatch for {name}: {tuple(v.shape)} vs {tuple(dst.shape)}")
+                    dst.copy_(v.to(self.device, torch.float32))
+
+    def state_dicts(self) -> Dict[str, Dict[str, torch.Tensor]]:
+        out = {g: {} for g in GROUPS}
+        for name in self.layout:
+            g, k = name.split(".", 1)
+            out[g][k] = self.view(name).detach().clone()
+        return out
+
+    def init_parameters(self, seed: Optional[int] = None):
+        """Reference default initialisation (torch layer defaults, drawn in the reference's
+        construction order net, netT, netF, mod: src/kharmonic_lofar.py:60-65)."""
+        from .lofar_models import AutoEncoder1DCNN, AutoEncoderCNN2, Kmeans
+        if seed is not None:
+            torch.manual_seed(seed)
+        c = self.cfg
+        hs = torch.tensor(c.harmonic_scales)
+        net = AutoEncoderCNN2(c.L, c.num_in_channels, hs, c.use_rica)
+        netT = AutoEncoder1DCNN(c.Lt, c.num_in_channels, hs, c.use_rica)
+        netF = AutoEncoder1DCNN(c.Lt, c.num_in_channels, hs, c.use_rica)
+        mod = Kmeans(c.L + 2 * c.Lt, c.Kc, c.Khp)
+        self.load_state_dicts(net.state_dict(), netT.state_dict(), netF.state_dict(), mod.state_dict())
+
+    def save_checkpoints(self, prefix: str = "."):
+        """Same four files / dict format as src/kharmonic_lofar.py:210-222."""
+        import os
+        sds = self.state_dicts()
+        for fname, g in (("net.model", "net"), ("khm.model", "mod"), ("netT.model", "netT"), ("netF.model", "netF")):
+            torch.save({"model_state_dict": {k: v.cpu() for k, v in sds[g].items()}}, os.path.join(prefix, fname))
+
+    # ------------------------------------------------------------------ data
+    def new_minibatch(self, x: torch.Tensor, uv: torch.Tensor):
+        """Start a new minibatch: multipliers reset to zero (src/kharmonic_lofar.py:128-130)."""
+        if tuple(x.shape) != tuple(self.x.shape) or tuple(uv.shape) != tuple(self.uv.shape):
+            raise RuntimeError(f"expected x {tuple(self.x.shape)} and uv {tuple(self.uv.shape)}")
+        self.x.copy_(x)
+        self.uv.copy_(uv)
+        for t in self.y:
+            t.zero_()
+
+    # ------------------------------------------------------------------ one iteration
+    def _closure_fwd_bwd(self):
+        P = L.ptr
+        L.check(self.lib.lshm_engine_forward_backward(
+            self._h, P(self.params), P(self.grads), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]),
+            P(self.y[2]), P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_forward_backward")
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.grads, group=self.pg)
+            dist.all_reduce(self.terms, group=self.pg)
+        if self._mask is not None:
+            self.grads.mul_(self._mask)
+
+    def _adam(self):
+        c = self.cfg
+        self.step_count.add_(1)
+        P = L.ptr
+        L.check(self.lib.lshm_adam_step_flat(P(self.params), P(self.grads), P(self.exp_avg), P(self.exp_avg_sq),
+                                             self.nparams, c.lr, c.betas[0], c.betas[1], c.adam_eps,
+                                             P(self.step_count), 0, 1.0, L.stream()), "adam")
+
+    def _multipliers(self):
+        P = L.ptr
+        L.check(self.lib.lshm_engine_multiplier_update(
+            self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+            P(self.ws), self.ws_floats, L.stream()), "engine_multiplier_update")
+
+    def _step_impl(self):
+        self._closure_fwd_bwd()
+        self._adam()
+        self._multipliers()
+
+    def capture_graph(self, warmup: int = 2):
+        """Capture one iteration in a HIP graph (state is restored afterwards)."""
+        snap = [t.clone() for t in (self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y)]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._step_impl()
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_impl()
+        for t, v in zip((self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y), snap):
+            t.copy_(v)
+        self._graph = g
+
+    def step(self):
+        """One ADMM iteration.  Loss terms of the closure stay on the device (``read_terms``)."""
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._step_impl()
+
+    def closure_only(self):
+        """Closure forward + backward without the update (gradients in ``self.grads``)."""
+        self._closure_fwd_bwd()
+
+    def read_terms(self) -> Dict[str, float]:
+        """The reference's log line (src/kharmonic_lofar.py:176-181) as a dict: one
+        device->host copy of nine doubles."""
+        t = self.terms[:9].cpu().tolist()
+        return dict(zip(TERM_NAMES, t))
+
+    def format_log(self, epoch: int, i: int, admm: int) -> str:
+        t = self.read_terms()
+        cols = [t[k] for k in TERM_NAMES[:7]] + ([t["rica"]] if self.cfg.use_rica else [])
+        return ("%d %d %d " % (epoch, i, admm)) + " ".join("%f" % v for v in cols)
+
+    # ------------------------------------------------------------------ inference helper
+    def encode(self, want_recon: bool = False):
+        """Latents Mu = [mu | muT | muF] (B, L+2Lt) for the current x, uv (no grad)."""
+        c = self.cfg
+        Mu = torch.empty((self.B, c.L + 2 * c.Lt), device=self.device)
+        outs = [torch.empty_like(self.x) for _ in range(3)] if want_recon else [None] * 3
+        P = L.ptr
+        L.check(self.lib.lshm_engine_encode(self._h, P(self.params), P(self.x), P(self.uv), P(Mu), P(outs[0]),
+                                            P(outs[1]), P(outs[2]), P(self.ws), self.ws_floats, L.stream()),
+                "engine_encode")
+        return (Mu, *outs) if want_recon else Mu

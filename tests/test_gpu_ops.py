@@ -1,0 +1,236 @@
+"""GPU parity tests, per op: HIP kernels (through the C ABI) vs golden vectors produced by the
+reference and vs the CPU oracle on identical inputs.  fp32 tolerances are written per test."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lshm_oracle as O
+from tests.util import assert_close, assert_probe, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+KINDS = {"conv2d": 0, "tconv2d": 1, "conv1d": 2, "tconv1d": 3}
+
+
+def _F():
+    from lshm_amd import functional as Fh
+    return Fh
+
+
+def test_library_loaded():
+    from lshm_amd import _lib
+    assert _lib.load().lshm_version() >= 100
+
+
+def test_harmonics():
+    g = load_golden("harmonics")
+    out = _F().uv_harmonics(torch.tensor(O.DEFAULT_SCALES, device=DEV), torch.from_numpy(g["harmonics/uv"]).to(DEV))
+    # device sin/cos vs libm at arguments up to 2000 rad
+    assert_close(out, g["harmonics/out"], rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("kind", list(KINDS))
+@pytest.mark.parametrize("i", range(6))
+def test_conv_layer_fwd_bwd_vs_golden(kind, i):
+    g = load_golden("convops")
+    Fh = _F()
+    ch = O.CH
+    B = 2
+    nd = 2 if kind.endswith("2d") else 1
+    tr = kind.startswith("t")
+    if nd == 2:
+        hw = 128 >> i if not tr else 2 << i
+        ishape = (B, ch[i] if not tr else ch[6 - i], hw, hw)
+    else:
+        Ls = [16384, 4096, 1024, 256, 64, 16, 4]
+        ishape = (B, ch[i] if not tr else ch[6 - i], Ls[i] if not tr else Ls[6 - i])
+    cin = ishape[1]
+    cout = ch[i + 1] if not tr else ch[5 - i]
+    kk = (4, 4) if nd == 2 else (4,)
+    wshape = ((cout, cin) if not tr else (cin, cout)) + kk
+    key = f"{kind}{i}"
+    fan = (cin if not tr else cout) * int(np.prod(kk))
+    x = O.closed_form(ishape, key + ":x", 1.0, 0.2113).to(DEV).requires_grad_(True)
+    w = O.closed_form(wshape, key + ":w", (3.0 / fan) ** 0.5).to(DEV).requires_grad_(True)
+    b = O.closed_form((cout,), key + ":b", fan ** -0.5).to(DEV).requires_grad_(True)
+    y = Fh.conv_act(x, w, b, KINDS[kind], True)
+    gy = O.closed_form(tuple(y.shape), key + ":gy", 1.0, 0.3331).to(DEV)
+    (y * gy).sum().backward()
+    assert_probe(g, key + "/y", y, 1e-5, 1e-6)
+    assert_probe(g, key + "/dx", x.grad, 1e-4, 1e-6)
+    assert_probe(g, key + "/dw", w.grad, 1e-4, 1e-4)
+    ref_db = g[key + "/db"]
+    assert_close(b.grad, ref_db, 1e-4, 1e-5 * np.abs(ref_db).max() + 1e-5)
+
+
+@pytest.mark.parametrize("B,K,N,act", [(2, 16, 16, True), (5, 784, 224, True), (3, 240, 768, False), (64, 32, 768, False)])
+def test_linear_vs_torch(B, K, N, act):
+    Fh = _F()
+    x = O.closed_form((B, K), "lin:x", 1.0, 0.31).to(DEV).requires_grad_(True)
+    w = O.closed_form((N, K), "lin:w", K ** -0.5, 0.77).to(DEV).requires_grad_(True)
+    b = O.closed_form((N,), "lin:b", 0.1, 0.53).to(DEV).requires_grad_(True)
+    gy = O.closed_form((B, N), "lin:gy", 1.0, 0.91).to(DEV)
+    y = Fh.linear_act(x, w, b, act)
+    (y * gy).sum().backward()
+    xr, wr, br = (t.detach().cpu().double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    if act:
+        yr = torch.nn.functional.elu(yr)
+    (yr * gy.cpu().double()).sum().backward()
+    assert rel_err(y, yr) < 2e-6
+    assert rel_err(x.grad, xr.grad) < 5e-6
+    assert rel_err(w.grad, wr.grad) < 5e-6
+    assert rel_err(b.grad, br.grad) < 5e-6
+
+
+@pytest.mark.parametrize("name,L,C,nd,rica", [("ae2d_rica", 224, 4, 2, True), ("ae2d_norica", 224, 4, 2, False),
+                                              ("ae1d_rica", 16, 4, 1, True), ("fnet8", 64, 8, 2, False)])
+def test_autoencoder_modules_vs_golden(name, L, C, nd, rica):
+    from lshm_amd.lofar_models import AutoEncoder1DCNN, AutoEncoderCNN2
+    g = load_golden("autoencoders")
+    cls = AutoEncoderCNN2 if nd == 2 else AutoEncoder1DCNN
+    net = cls(latent_dim=L, channels=C, harmonic_scales=torch.tensor(O.DEFAULT_SCALES), rica=rica)
+    net.load_state_dict(O.closed_form_state_dict(L, C, nd, rica, name))
+    net = net.to(DEV)
+    net.harmonic_scales = net.harmonic_scales.to(DEV)
+    x, uv = O.closed_form_inputs(2, C)
+    if nd == 1:
+        x = x.flatten(2, 3)
+    x = x.to(DEV).requires_grad_(True)
+    xhat, mu = net(x, uv.to(DEV))
+    assert_probe(g, name + "/xhat", xhat, 2e-5, 2e-6)
+    assert_close(mu, g[name + "/mu"], 2e-5, 2e-6)
+    gy = O.closed_form(tuple(xhat.shape), name + ":gy", 1.0, 0.3331).to(DEV)
+    gm = O.closed_form(tuple(mu.shape), name + ":gm", 1.0, 0.7717).to(DEV)
+    ((xhat * gy).sum() + (mu * gm).sum()).backward()
+    assert_probe(g, name + "/dx", x.grad, 2e-4, 2e-6)
+    for k, p in net.named_parameters():
+        ref = float(g[f"{name}/gnorm/{k}"])
+        assert abs(p.grad.double().norm().item() - ref) <= 2e-4 * ref + 1e-7, k
+        assert_close(p.grad.reshape(-1)[:8], g[f"{name}/ghead/{k}"], 2e-4, 2e-5 * ref + 1e-7, k)
+
+
+def test_autoencoder_rejects_wrong_patch_size():
+    from lshm_amd.lofar_models import AutoEncoderCNN2
+    net = AutoEncoderCNN2(224, 4, torch.tensor(O.DEFAULT_SCALES, device=DEV), True).to(DEV)
+    with pytest.raises(RuntimeError):  # upstream: mat1 and mat2 shapes cannot be multiplied
+        net(torch.zeros(2, 4, 64, 64, device=DEV), torch.zeros(2, 2, device=DEV))
+
+
+def test_khm_vs_golden_and_oracle():
+    Fh = _F()
+    g = load_golden("latent_losses")
+    for ci in range(6):
+        Bk, K, D, p, deg = [int(v) for v in g[f"khm{ci}/cfg"]]
+        M = (0.5 + 0.5 * O.closed_form((K, D), f"khm{ci}:M", 1.0, 0.618))
+        X = 0.8 * O.closed_form((Bk, D), f"khm{ci}:X", 1.0, 0.4142) + 0.3
+        if deg:
+            X[0] = M[0]
+        Xg, Mg = X.to(DEV).requires_grad_(True), M.to(DEV).requires_grad_(True)
+        loss = Fh.khm_loss(Xg, Mg, p)
+        loss.backward()
+        ref = float(g[f"khm{ci}/loss"])
+        assert abs(loss.item() - ref) <= 3e-6 * abs(ref), (ci, loss.item(), ref)
+        _, dXo, dMo = O.khm_grads(X, M, p)
+        assert rel_err(Xg.grad, dXo) < 1e-5, ci
+        assert rel_err(Mg.grad, dMo) < 1e-5, ci
+        if not deg:
+            assert_close(Xg.grad, g[f"khm{ci}/dX"], 3e-5, 2e-6 * np.abs(g[f"khm{ci}/dX"]).max())
+            assert_close(Mg.grad, g[f"khm{ci}/dM"], 3e-5, 2e-6 * np.abs(g[f"khm{ci}/dM"]).max())
+
+
+def test_khm_known_answer_equal_distances():
+    # all d_ik = r  =>  loss = K/(K/(r^p+eps)+eps) * B / (B*K*D)   
+    Fh = _F()
+    B, K, D, p, r = 8, 4, 64, 4, 2.0
+    X = torch.zeros(B, D)
+    M = torch.zeros(K, D)
+    for k in range(K):
+        M[k, k] = r  # |x - m_k| = r for x = 0
+    loss = Fh.khm_loss(X.to(DEV), M.to(DEV), p).item()
+    eps = 1e-9
+    ref = (K / (K / (r ** p + eps) + eps)) * B / (B * K * D)
+    assert abs(loss - ref) <= 1e-6 * ref
+
+
+def test_khm_ragged_sizes_and_offline_partials():
+    Fh = _F()
+    for (N, K, D, p) in [(1, 1, 8, 2), (7, 3, 100, 4), (130, 17, 256, 4), (33, 64, 256, 3), (1000, 10, 256, 4)]:
+        X = 0.8 * O.closed_form((N, D), "rag:X", 1.0, 0.4142) + 0.3
+        M = 0.5 + 0.5 * O.closed_form((K, D), "rag:M", 1.0, 0.618)
+        Xg, Mg = X.to(DEV).requires_grad_(True), M.to(DEV).requires_grad_(True)
+        loss = Fh.khm_loss(Xg, Mg, p)
+        loss.backward()
+        lo, dXo, dMo = O.khm_grads(X, M, p)
+        assert abs(loss.item() - lo.item()) <= 5e-6 * abs(lo.item()), (N, K, D, p)
+        assert rel_err(Xg.grad, dXo) < 2e-5 and rel_err(Mg.grad, dMo) < 2e-5, (N, K, D, p)
+        num, den = Fh.khm_offline_partials(X.to(DEV), M.to(DEV), p)
+        no, do = O.khm_offline_partials(X, M, p)
+        assert rel_err(num, no) < 2e-5 and rel_err(den, do) < 2e-5, (N, K, D, p)
+        dist = Fh.khm_mean_distances(X.to(DEV), M.to(DEV), p)
+        dref = ((X[:, None, :].double() - M[None].double()) ** 2).sum(-1).pow(p / 2).mean(0)
+        assert rel_err(dist, dref) < 1e-5
+
+
+def test_kmeans_module_offline_update_and_state_dict():
+    from lshm_amd.lofar_models import Kmeans
+    mod = Kmeans(latent_dim=256, K=10, p=4)
+    assert list(mod.state_dict().keys()) == ["M"]
+    M0 = 0.5 + 0.5 * O.closed_form((10, 256), "off:M", 1.0, 0.618)
+    X = 0.8 * O.closed_form((64, 256), "off:X", 1.0, 0.4142) + 0.3
+    mod.load_state_dict({"M": M0})
+    mod = mod.to(DEV)
+    mod.offline_update(X.to(DEV))
+    assert rel_err(mod.M, O.khm_offline_update(X, M0, 4)) < 2e-5
+
+
+def test_cluster_similarity_vs_golden():
+    Fh = _F()
+    g = load_golden("latent_losses")
+    for K in (4, 10, 64):
+        M = (0.5 + 0.5 * O.closed_form((K, 256), f"sim{K}:M", 1.0, 0.618)).to(DEV).requires_grad_(True)
+        s = Fh.cluster_similarity(M)
+        s.backward()
+        ref = float(g[f"sim{K}/loss"])
+        assert abs(s.item() - ref) <= 3e-6 * abs(ref)
+        assert_close(M.grad, g[f"sim{K}/dM"], 2e-4, 2e-5 * np.abs(g[f"sim{K}/dM"]).max())
+
+
+def test_cluster_similarity_known_answers():
+    Fh = _F()
+    K, D = 6, 32
+    M = torch.zeros(K, D)
+    for k in range(K):
+        M[k, k] = 1.0 + k  # orthogonal rows: (K-1) e^0 / (e^1+eps) * K / (K D)
+    val = Fh.cluster_similarity(M.to(DEV)).item()
+    ref = (K - 1) / (np.e + 1e-9) * K / (K * D)
+    assert abs(val - ref) <= 2e-6 * ref
+
+
+def test_augmented_loss_vs_golden():
+    Fh = _F()
+    g = load_golden("latent_losses")
+    for bpb, bs in ((4, 2), (8, 8), (9, 12)):
+        Z = (0.8 * O.closed_form((bpb * bs, 256), f"aug{bpb}_{bs}:Z", 1.0, 0.4142) + 0.1).to(DEV)
+        Z.requires_grad_(True)
+        a = Fh.augmented_loss(Z, bpb, bs)
+        assert a.shape == (1,)
+        a.sum().backward()
+        ref = float(g[f"aug{bpb}_{bs}/loss"])
+        assert abs(a.item() - ref) <= 3e-6 * abs(ref)
+        assert_close(Z.grad, g[f"aug{bpb}_{bs}/dZ"], 2e-4, 2e-5 * np.abs(g[f"aug{bpb}_{bs}/dZ"]).max())
+
+
+def test_augmented_loss_ragged_rows():
+    # more rows than batch_size*bpb (ignored, zero gradient) and a trailing partial group
+    Fh = _F()
+    for rows, bpb, bs in ((20, 4, 3), (10, 4, 3), (3, 4, 2)):
+        Z = (0.8 * O.closed_form((rows, 64), "augr:Z", 1.0, 0.4142) + 0.1)
+        Zg = Z.to(DEV).requires_grad_(True)
+        a = Fh.augmented_loss(Zg, bpb, bs)
+        a.sum().backward()
+        Zo = Z.clone().requires_grad_(True)
+        ao = O.augmented_loss(Zo, bpb, bs)
+        ao.sum().backward()
+        assert abs(a.item() - ao.item()) <= 3e-6 * abs(ao.item()) + 1e-9, (rows, bpb, bs)
+        assert_close(Zg.grad, Zo.grad, 2e-4, 1e-7)

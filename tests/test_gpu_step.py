@@ -1,0 +1,123 @@
+"""GPU parity of the fused step engine (one ADMM iteration) vs the CPU oracle and vs the
+golden trajectory recorded from the reference modules + torch.optim.Adam."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lshm_oracle as O
+from tests.util import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _trainer(B, K, bpb, bs, groups=("net", "netT", "netF", "mod"), rica=True):
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    cfg = TrainConfig(Kc=K, use_rica=rica, train_groups=groups)
+    ocfg = O.StepConfig(K=K, bpb=bpb, batch_size=bs, rica=rica)
+    params, M = O.make_params(ocfg)
+    tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=bpb, default_batch=bs, device=DEV)
+    tr.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
+    x, uv = O.closed_form_inputs(B, 4)
+    tr.new_minibatch(x.to(DEV), uv.to(DEV))
+    return tr, ocfg, params, M, x, uv
+
+
+def test_closure_terms_and_gradients_vs_golden():
+    g = load_golden("closure")
+    tr, ocfg, params, M, x, uv = _trainer(8, 4, 4, 2)
+    tr.closure_only()
+    t = tr.read_terms()
+    ref = g["terms"][0]
+    names = ("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica", "total")
+    for n, r in zip(names, ref):
+        assert abs(t[n] - r) <= 1e-4 * abs(r) + 1e-7, (n, t[n], r)
+    for name in tr.layout:
+        gr = tr.view(name, tr.grads)
+        r = float(g[f"it0/gnorm/{name}"])
+        assert abs(gr.double().norm().item() - r) <= 2e-4 * r + 1e-9, (name, gr.double().norm().item(), r)
+        np.testing.assert_allclose(gr.reshape(-1)[:8].cpu().numpy(), g[f"it0/ghead/{name}"], rtol=2e-3,
+                                   atol=2e-4 * r + 1e-9, err_msg=name)
+
+
+def test_three_adam_iterations_vs_golden():
+    g = load_golden("closure")
+    tr, ocfg, params, M, x, uv = _trainer(8, 4, 4, 2)
+    ref = g["terms"]
+    for it in range(3):
+        tr.step()
+        t = tr.read_terms()
+        got = [t[k] for k in ("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica")]
+        np.testing.assert_allclose(got, ref[it][:8], rtol=1e-3, atol=1e-7)
+    tr.closure_only()
+    t = tr.read_terms()
+    got = [t[k] for k in ("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica")]
+    np.testing.assert_allclose(got, ref[3][:8], rtol=1e-3, atol=1e-7)
+    ynorm = [v.double().norm().item() for v in tr.y]
+    np.testing.assert_allclose(ynorm, g["it3/ynorm"], rtol=2e-3)
+    for name in tr.layout:
+        r = float(g[f"final/pnorm/{name}"])
+        assert abs(tr.view(name).double().norm().item() - r) <= 1e-4 * r + 1e-9, name
+        r = float(g[f"it3/gnorm/{name}"])
+        assert abs(tr.view(name, tr.grads).double().norm().item() - r) <= 5e-3 * r + 1e-9, name
+
+
+@pytest.mark.parametrize("rica", [True, False])
+def test_step_vs_oracle_full_gradients(rica):
+    """Every gradient element against oracle autograd (fp32 oracle), B=4."""
+    tr, ocfg, params, M, x, uv = _trainer(4, 5, 2, 2, rica=rica)
+    y = [0.01 * O.closed_form((x.numel(),), f"y{k}", 1.0, 0.123 + 0.1 * k) for k in range(3)]
+    for k in range(3):
+        tr.y[k].copy_(y[k].to(DEV))
+    tr.closure_only()
+    leaves = O.flat_leaves(params, M)
+    for l in leaves:
+        l.requires_grad_(True)
+    total, terms = O.closure_losses(params, M, x, uv, y, ocfg)
+    grads = torch.autograd.grad(total, leaves)
+    t = tr.read_terms()
+    assert abs(t["total"] - total.item()) <= 1e-4 * abs(total.item())
+    names = [f"{g}.{k}" for g in O.GROUPS for k in params[g]] + ["mod.M"]
+    for n, gr in zip(names, grads):
+        e = rel_err(tr.view(n, tr.grads), gr)
+        assert e < 2e-4, (n, e)
+
+
+def test_train_groups_freeze():
+    tr, ocfg, params, M, x, uv = _trainer(4, 4, 2, 2, groups=("net",))
+    before = {n: tr.view(n).clone() for n in tr.layout}
+    tr.step()
+    for n in tr.layout:
+        changed = not torch.equal(before[n], tr.view(n))
+        assert changed == n.startswith("net."), n
+
+
+def test_graph_replay_matches_eager():
+    tr, *_ = _trainer(4, 4, 2, 2)
+    tr2, *_ = _trainer(4, 4, 2, 2)
+    tr2.capture_graph()
+    for _ in range(2):
+        tr.step()
+        tr2.step()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.params, tr2.params)
+    assert torch.equal(tr.y[2], tr2.y[2])
+
+
+def test_state_dict_roundtrip_with_modules():
+    from lshm_amd.lofar_models import AutoEncoder1DCNN, AutoEncoderCNN2, Kmeans
+    tr, *_ = _trainer(4, 4, 2, 2)
+    sds = tr.state_dicts()
+    hs = torch.tensor(O.DEFAULT_SCALES)
+    net = AutoEncoderCNN2(224, 4, hs, True)
+    netT = AutoEncoder1DCNN(16, 4, hs, True)
+    mod = Kmeans(256, 4, 4)
+    net.load_state_dict(sds["net"])
+    netT.load_state_dict(sds["netT"])
+    mod.load_state_dict(sds["mod"])
+    # engine forward == module forward on the same parameters
+    net = net.to(DEV)
+    net.harmonic_scales = hs.to(DEV)
+    Mu, x1, x2, x3 = tr.encode(want_recon=True)
+    xhat, mu = net(tr.x, tr.uv)
+    assert rel_err(x1, xhat) < 1e-6 and rel_err(Mu[:, :224], mu) < 1e-6
