@@ -23,7 +23,10 @@ def assert_probe(g, name, t, rtol=1e-5, atol=1e-6):
     idx = g[f"{name}/idx"]
     p = probe(t, idx)
     assert p["n"] == int(g[f"{name}/n"]), (name, p["n"], int(g[f"{name}/n"]))
-    np.testing.assert_allclose(p["sample"], g[f"{name}/sample"], rtol=rtol, atol=atol,
+    ref = g[f"{name}/sample"]
+    # fp32 dot products of O(1) terms: the absolute error scales with the tensor's magnitude,
+    # so near-zero elements are compared against rtol * max|ref| rather than their own size
+    np.testing.assert_allclose(p["sample"], ref, rtol=rtol, atol=atol + rtol * float(np.abs(ref).max()),
                                err_msg=name + " sample")
     asum = float(g[f"{name}/asum"])
     tol = rtol * asum + atol
