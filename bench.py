@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Headline benchmark: spectrogram-patches/sec of one LSHM training step (one ADMM iteration of
+src/kharmonic_lofar.py:131-202: closure forward + backward over the 2D AE, the two 1D AEs and the
+K-harmonic / similarity / augmentation / RICA terms, Adam update of all four parameter groups,
+no-grad forward and multiplier update) on synthetic (B=256,4,128,128) patches per GPU, fp32.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` (dominant kernel,
+timed live with HIP events on the launch stream) and, at N=1, `cpu_baseline` (the oracle port of the
+same step on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+# algorithmic bytes per patch per training step: layer-wise in+out, no recompute
+STEP_BYTES_PER_PATCH = 15.04e6
+STEP_FLOP_PER_PATCH = 205.6e6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="patches per GPU")
+    ap.add_argument("--K", type=int, default=10)
+    ap.add_argument("--bpb", type=int, default=8)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters, warm=2):
+    """Average duration of fn() (enqueues on torch's current stream, which is the stream the
+    kernels are launched on) measured with HIP events."""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+def khm_roofline(dev, N=1 << 20, D=256, K=10, p=4.0):
+    """Fused K-harmonic forward+backward at the streaming shape of SURVEY 8(d): algorithmic bytes
+    = read X + M, write dX + dM = 8 (N D + K D)."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    X = torch.rand(N, D, device=dev)
+    M = torch.rand(K, D, device=dev)
+    dX = torch.empty_like(X)
+    dM = torch.empty_like(M)
+    loss = torch.zeros(1, device=dev, dtype=torch.float64)
+    nws = lib.lshm_khm_workspace_floats(N, D, K)
+    ws = torch.empty(nws, device=dev)
+    inv = 1.0 / (float(N) * K * D)
+
+    def run():
+        L.check(lib.lshm_khm_fwd_bwd(L.ptr(X), D, L.ptr(M), N, D, K, p, 1e-9, inv, 1.0, L.ptr(loss), L.ptr(dX),
+                                     D, L.ptr(dM), 0, L.ptr(ws), nws, L.stream()))
+    ms = event_time_ms(run, 10)
+    nbytes = 8.0 * (N * D + K * D)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "khm_kernel+khm_reduce (fused fwd+bwd)", "shape": f"N={N},D={D},K={K}", "bound": "hbm",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "ms": round(ms, 4), "traffic": None}
+
+
+def dominant_kernel_roofline(tr, dev):
+    """conv2d k4s2p1 data-gradient / transposed-conv kernel on the largest layer (tconv5: (B,8,64,64)
+    -> (B,4,128,128)); algorithmic bytes per launch = read input + write output (weights ignored)."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    B = tr.B
+    x = torch.randn(B, 8, 64, 64, device=dev)
+    w = torch.randn(8, 4, 4, 4, device=dev) * 0.1
+    b = torch.zeros(4, device=dev)
+    y = torch.empty(B, 4, 128, 128, device=dev)
+
+    def run():
+        L.check(lib.lshm_conv_fwd(1, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, 8, 4, 64, 64, 0, 0, 0, L.stream()))
+    ms = event_time_ms(run, 20)
+    nbytes = 4.0 * (x.numel() + y.numel())
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "igemm_kernel<Conv2dDgrad> (tconv5 forward)", "bound": "hbm", "achieved": round(ach, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "ms": round(ms, 4),
+            "bytes_per_launch": nbytes, "traffic": None}
+
+
+def cpu_baseline(args):
+    """Oracle port of the same step (torch CPU ops, the reference's per-sample / per-centroid
+    loop order for KHM, similarity and augmentation), bounded sample, host cores."""
+    from oracle import lshm_oracle as O
+    B = args.batch
+    torch.manual_seed(0)
+    cfg = O.StepConfig(K=args.K, bpb=args.bpb, batch_size=B // args.bpb)
+    params, M = O.make_params(cfg)
+    x = torch.randn(B, 4, 128, 128)
+    uv = 1000.0 * torch.randn(B, 2)
+    y = [torch.zeros(x.numel()) for _ in range(3)]
+    adam = O.AdamState(O.flat_leaves(params, M), cfg.lr)
+    times = []
+    for it in range(args.cpu_steps + 1):
+        t0 = time.perf_counter()
+        _, y, _ = O.admm_iteration(params, M, x, uv, y, cfg, adam, khm_fn=O.khm_loss_loop,
+                                   sim_fn=O.cluster_similarity_loop, aug_fn=O.augmented_loss_loop)
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]
+    return {"value": round(B / t, 2), "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{args.cpu_steps} timed ADMM iterations (median) after 1 warm-up at B={B}, K={args.K}, "
+                      f"bpb={args.bpb}, all four parameter groups under Adam",
+            "s_per_step": round(t, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    B = args.batch
+    cfg = TrainConfig(Kc=args.K)
+    tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=args.bpb, default_batch=B // args.bpb, device=dev,
+                          process_group=pg)
+    tr.init_parameters(seed=0)  # identical replicas on every rank
+    gen = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.randn(B, cfg.num_in_channels, 128, 128, generator=gen)
+    x = (x - x.mean()) / x.std()  # mimics normalize_data=True (src/lofar_tools.py:190-193)
+    uv = 1000.0 * torch.randn(B, 2, generator=gen)
+    tr.new_minibatch(x.to(dev), uv.to(dev))
+
+    use_graph = not args.no_graph
+    if use_graph:
+        try:
+            tr.capture_graph(warmup=1)
+        except Exception as e:  # report, fall back to eager launches of the same kernels
+            if rank == 0:
+                print(f"[bench] graph capture unavailable ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            use_graph = False
+            tr._graph = None
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    terms = tr.read_terms()
+    ms = dt / args.steps * 1e3
+    value = world * B * args.steps / dt
+
+    out = {"metric": "spectrogram-patches/sec per training step (AE+FFT+k-harmonic), 1/2/4/8 GPU",
+           "value": round(value, 1), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"1xMI355X-per-rank: (B={B},4,128,128) synthetic patches, 2D+1D AE + K={args.K} "
+                                  f"k-harmonic, fp32 (BASELINE.json configs[1]); one ADMM iteration = closure "
+                                  f"fwd+bwd + Adam (all 4 groups) + no-grad fwd + multiplier update",
+                      "global_batch": world * B, "per_gpu_batch": B, "K": args.K, "bpb": args.bpb,
+                      "parallelism": f"dp{world}", "launch": "hipgraph" if use_graph else "eager",
+                      "feature_stage": "v2 path (row/column 1D AEs); FFT op benchmarked separately"},
+           "loss_total": terms["total"],
+           "step_roofline": {"bound": "hbm", "achieved": round(STEP_BYTES_PER_PATCH * B / (ms * 1e-3) / 1e9, 1),
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(STEP_BYTES_PER_PATCH * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "note": "whole step, algorithmic 15.04 MB/patch (SURVEY 8d), per GPU"}}
+    if rank == 0 and not args.no_roofline:
+        out["roofline"] = dominant_kernel_roofline(tr, dev)
+        out["khm_roofline"] = khm_roofline(dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
