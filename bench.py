@@ -97,7 +97,7 @@ def dominant_kernel_roofline(tr, dev):
     y = torch.empty(B, 4, 128, 128, device=dev)
 
     def run():
-        L.check(lib.lshm_conv_fwd(1, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, 8, 4, 64, 64, 0, 0, 0, L.stream()))
+        L.check(lib.lshm_conv_fwd(1, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, 8, 4, 64, 64, 0, 0, 0, None, 0, L.stream()))
     ms = event_time_ms(run, 20)
     nbytes = 4.0 * (x.numel() + y.numel())
     ach = nbytes / (ms * 1e-3) / 1e9

@@ -54,16 +54,19 @@ int lshm_uv_harmonics(const float* uv, const float* scales, int H, int B, float*
 /* ---- convolution layers, forward + fused bias + optional ELU     src/lofar_models.py:73-78,93-98,158-163,178-183
  * x (B,Cin,Hin,Win) [1D: Hin=1, Win=L]; weight in torch layout (Conv: (Cout,Cin,k..), ConvTranspose:
  * (Cin,Cout,k..)); in_bs / out_bs are batch strides in elements (0 = dense). act: 0 none, 1 ELU. */
+/* workspace floats that let fwd / dgrad / wgrad of one layer use split-K (deep layers) */
+size_t lshm_conv_workspace_floats(int kind, int B, int Cin, int Cout, int Hin, int Win);
+/* `workspace` may be NULL for fwd / dgrad (no split-K: slower on the deep, few-position layers) */
 int lshm_conv_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B,
                   int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, int act,
-                  lshm_stream_t stream);
+                  float* workspace, size_t workspace_floats, lshm_stream_t stream);
 /* data gradient: dx = op^T(dz, w); if y_in_saved != NULL the result is multiplied by ELU'(y_in_saved)
  * (the saved *output* of the previous layer), i.e. it is already the pre-activation gradient. */
 int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved,
                     int B, int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs,
-                    lshm_stream_t stream);
-size_t lshm_conv_wgrad_workspace_floats(int kind, int B, int Cin, int Cout, int Hin, int Win);
-/* weight + bias gradient (deterministic split-K); dw/db overwritten unless accumulate != 0 */
+                    float* workspace, size_t workspace_floats, lshm_stream_t stream);
+/* weight + bias gradient (deterministic split-K); dw/db overwritten unless accumulate != 0;
+ * workspace is mandatory here (lshm_conv_workspace_floats) */
 int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float* db, int B, int Cin,
                     int Cout, int Hin, int Win, long in_bs, long out_bs, float* workspace,
                     size_t workspace_floats, int accumulate, lshm_stream_t stream);
@@ -71,12 +74,16 @@ int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float*
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t stream);
 
 /* ---- dense layers (F.linear + optional ELU)                    src/lofar_models.py:80-83,89-91,67-68 */
+size_t lshm_linear_workspace_floats(int B, int K, int N);
 int lshm_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
-                    int B, int K, int N, int act, lshm_stream_t stream);
+                    int B, int K, int N, int act, float* workspace, size_t workspace_floats,
+                    lshm_stream_t stream);
 int lshm_linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
-                      const float* x_saved, long ldxs, int B, int K, int N, lshm_stream_t stream);
+                      const float* x_saved, long ldxs, int B, int K, int N, float* workspace,
+                      size_t workspace_floats, lshm_stream_t stream);
 int lshm_linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db,
-                      int B, int K, int N, lshm_stream_t stream);
+                      int B, int K, int N, float* workspace, size_t workspace_floats,
+                      lshm_stream_t stream);
 
 /* ---- K-harmonic means                                           src/lofar_models.py:199-212
  * X (N,D) with leading dimension ldx, M (K,D).  loss_sum[0] = sum_i K/(e_i+eps) (caller divides by

@@ -37,20 +37,21 @@ _SIGNATURES = {
     "lshm_version": (c_int, []),
     "lshm_last_error_string": (C.c_char_p, []),
     "lshm_uv_harmonics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "lshm_conv_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "lshm_conv_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                              c_int, c_long, c_long, c_int, c_void_p]),
+                              c_int, c_long, c_long, c_int, c_void_p, c_size_t, c_void_p]),
     "lshm_conv_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                c_int, c_long, c_long, c_void_p]),
-    "lshm_conv_wgrad_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+                                c_int, c_long, c_long, c_void_p, c_size_t, c_void_p]),
     "lshm_conv_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, c_long, c_long, c_void_p, c_size_t, c_int, c_void_p]),
     "lshm_elu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
+    "lshm_linear_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "lshm_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,
-                                c_int, c_void_p]),
+                                c_int, c_void_p, c_size_t, c_void_p]),
     "lshm_linear_dgrad": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_int,
-                                  c_int, c_int, c_void_p]),
+                                  c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lshm_linear_wgrad": (c_int, [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int,
-                                  c_int, c_void_p]),
+                                  c_int, c_void_p, c_size_t, c_void_p]),
     "lshm_khm_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "lshm_khm_fwd_bwd": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_float, c_float,
                                  c_double, c_float, c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p,
@@ -129,6 +130,20 @@ def require_device(*tensors: torch.Tensor):
 
 def ptr(t):
     return None if t is None else t.data_ptr()
+
+
+_scratch = {}
+
+
+def scratch(device, nfloats: int):
+    """Per-device split-K scratch reused by the autograd wrappers (work on one stream is ordered,
+    so one buffer per device is enough); grows on demand."""
+    key = (device.type, device.index)
+    t = _scratch.get(key)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(int(nfloats), 1 << 20), device=device, dtype=torch.float32)
+        _scratch[key] = t
+    return t
 
 
 def stream():

@@ -59,26 +59,28 @@ int lshm_uv_harmonics(const float* uv, const float* scales, int H, int B, float*
   return uv_harmonics(uv, scales, H, B, out, ST(s));
 }
 
+size_t lshm_conv_workspace_floats(int kind, int B, int Cin, int Cout, int Hin, int Win) {
+  ConvLayer L;
+  if (make_layer(kind, B, Cin, Cout, Hin, Win, 0, 0, &L)) return 0;
+  return conv_workspace_floats(L);
+}
 int lshm_conv_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B, int Cin,
-                  int Cout, int Hin, int Win, long in_bs, long out_bs, int act, lshm_stream_t s) {
+                  int Cout, int Hin, int Win, long in_bs, long out_bs, int act, float* ws, size_t wsf,
+                  lshm_stream_t s) {
   REQUIRE(x && w && y, "conv_fwd: null pointer");
   ConvLayer L;
   int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
   if (rc) return rc;
-  return conv_layer_fwd(L, x, w, bias, y, act, ST(s));
+  return conv_layer_fwd(L, x, w, bias, y, act, ws, ws ? wsf : 0, ST(s));
 }
 int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved, int B,
-                    int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, lshm_stream_t s) {
+                    int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, float* ws, size_t wsf,
+                    lshm_stream_t s) {
   REQUIRE(dz && w && dx, "conv_dgrad: null pointer");
   ConvLayer L;
   int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
   if (rc) return rc;
-  return conv_layer_dgrad(L, dz, w, dx, y_in_saved, ST(s));
-}
-size_t lshm_conv_wgrad_workspace_floats(int kind, int B, int Cin, int Cout, int Hin, int Win) {
-  ConvLayer L;
-  if (make_layer(kind, B, Cin, Cout, Hin, Win, 0, 0, &L)) return 0;
-  return conv_wgrad_workspace_floats(L);
+  return conv_layer_dgrad(L, dz, w, dx, y_in_saved, ws, ws ? wsf : 0, ST(s));
 }
 int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float* db, int B, int Cin,
                     int Cout, int Hin, int Win, long in_bs, long out_bs, float* ws, size_t wsf,
@@ -95,20 +97,28 @@ int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream
   return elu_bwd(gy, y, dz, n, ST(s));
 }
 
+size_t lshm_linear_workspace_floats(int B, int K, int N) {
+  size_t a = igemm_workspace_floats(B, N, K, 1);
+  const size_t b = igemm_workspace_floats(B, K, N, 1), c = igemm_workspace_floats(N, K, B, 1);
+  if (b > a) a = b;
+  if (c > a) a = c;
+  return a + 16;
+}
 int lshm_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
-                    int B, int K, int N, int act, lshm_stream_t s) {
+                    int B, int K, int N, int act, float* ws, size_t wsf, lshm_stream_t s) {
   REQUIRE(x && w && y && B > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N, "linear_fwd: bad argument");
-  return linear_fwd(x, ldx, w, bias, y, ldy, B, K, N, act, ST(s));
+  return linear_fwd(x, ldx, w, bias, y, ldy, B, K, N, act, ws, ws ? wsf : 0, ST(s));
 }
 int lshm_linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
-                      const float* x_saved, long ldxs, int B, int K, int N, lshm_stream_t s) {
+                      const float* x_saved, long ldxs, int B, int K, int N, float* ws, size_t wsf,
+                      lshm_stream_t s) {
   REQUIRE(dz && w && dx && B > 0 && K > 0 && N > 0 && lddz >= N && lddx >= K, "linear_dgrad: bad argument");
-  return linear_dgrad(dz, lddz, w, dx, lddx, x_saved, ldxs, B, K, N, ST(s));
+  return linear_dgrad(dz, lddz, w, dx, lddx, x_saved, ldxs, B, K, N, ws, ws ? wsf : 0, ST(s));
 }
 int lshm_linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
-                      int K, int N, lshm_stream_t s) {
+                      int K, int N, float* ws, size_t wsf, lshm_stream_t s) {
   REQUIRE(x && dz && dw && B > 0 && K > 0 && N > 0, "linear_wgrad: bad argument");
-  return linear_wgrad(x, ldx, dz, lddz, dw, db, B, K, N, 0, ST(s));
+  return linear_wgrad(x, ldx, dz, lddz, dw, db, B, K, N, ws, ws ? wsf : 0, ST(s));
 }
 
 size_t lshm_khm_workspace_floats(int N, int D, int K) { return khm_workspace_floats(N, D, K); }

@@ -125,17 +125,26 @@ int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t 
 // --------------------------------------------------------------------------
 // reduce_partials / channel sums
 // --------------------------------------------------------------------------
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                       long n, int S, int accumulate) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// block = 16 outputs x 16 slice lanes, lanes combined through LDS in lane order (deterministic)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
+                                                              float* __restrict__ out, long n, int S,
+                                                              int accumulate) {
+  __shared__ float red[256];
+  const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + ol;
   float acc = 0.f;
-  for (int s = 0; s < S; ++s) acc += partial[(long)s * n + i];
-  out[i] = accumulate ? out[i] + acc : acc;
+  if (i < n)
+    for (int s = sl; s < S; s += 16) acc += partial[(long)s * n + i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    for (int s = 1; s < 16; ++s) acc += red[s * 16 + ol];
+    out[i] = accumulate ? out[i] + acc : acc;
+  }
 }
 int reduce_partials(const float* partial, float* out, long n, int S, int accumulate,
                     hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, partial, out, n,
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, partial, out, n,
                      S, accumulate);
   return check_launch("reduce_partials");
 }
@@ -150,14 +159,22 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   float acc = 0.f;
   for (int b = b0; b < b1; ++b) {
     const float* src = dz + (long)b * bs + (long)c * HW;
-    for (long r = threadIdx.x; r < HW; r += blockDim.x) acc += src[r];
+    if ((HW & 3) == 0) {
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+      for (long r = threadIdx.x; r < (HW >> 2); r += blockDim.x) {
+        const f32x4 v = s4[r];
+        acc += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    } else {
+      for (long r = threadIdx.x; r < HW; r += blockDim.x) acc += src[r];
+    }
   }
   const float tot = block_sum<float>(acc, red);
   if (threadIdx.x == 0) partial[(long)s * C + c] = tot;
 }
 int channel_sum_partials(const float* dz, long bs, int B, int C, long HW, float* partial, int S,
                          hipStream_t st) {
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(HW >= 256 ? 256 : 64), 0, st, dz, bs, B,
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(HW >= 1024 ? 256 : 64), 0, st, dz, bs, B,
                      C, HW, partial, S);
   return check_launch("channel_sum");
 }

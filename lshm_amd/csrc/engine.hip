@@ -165,28 +165,30 @@ static int ae_forward(const lshm_engine* e, int idx, const float* prm, const flo
   float* cat1 = ws + a.cat1;
   float* Mu = ws + e->o_Mu + a.mu_col;
   float* cat3 = ws + a.cat3;
+  float* part = ws + e->o_part;
+  const size_t pf = e->part_floats;
   int rc;
   const float* in = input;
   for (int i = 0; i < 6; ++i) {
     float* out = (i < 5) ? ws + a.act[i] : cat1;
-    if ((rc = conv_layer_fwd(a.enc[i], in, prm + a.cw[i], prm + a.cb[i], out, 1, st))) return rc;
+    if ((rc = conv_layer_fwd(a.enc[i], in, prm + a.cw[i], prm + a.cb[i], out, 1, part, pf, st))) return rc;
     in = out;
   }
-  if ((rc = linear_fwd(uvh, hd, prm + a.fcuv1w, prm + a.fcuv1b, cat1 + 768, 768 + hd, B, hd, hd, 1, st))) return rc;
+  if ((rc = linear_fwd(uvh, hd, prm + a.fcuv1w, prm + a.fcuv1b, cat1 + 768, 768 + hd, B, hd, hd, 1, part, pf, st))) return rc;
   if (c.rica) {
-    if ((rc = linear_fwd(cat1, 768 + hd, prm + a.fc1w, prm + a.fc1b, ws + a.z1, L, B, 768 + hd, L, 1, st))) return rc;
-    if ((rc = linear_fwd(ws + a.z1, L, prm + a.fc2inw, prm + a.fc2inb, Mu, D, B, L, L, 1, st))) return rc;
-    if ((rc = linear_fwd(Mu, D, prm + a.fc2outw, prm + a.fc2outb, cat3, L + hd, B, L, L, 1, st))) return rc;
+    if ((rc = linear_fwd(cat1, 768 + hd, prm + a.fc1w, prm + a.fc1b, ws + a.z1, L, B, 768 + hd, L, 1, part, pf, st))) return rc;
+    if ((rc = linear_fwd(ws + a.z1, L, prm + a.fc2inw, prm + a.fc2inb, Mu, D, B, L, L, 1, part, pf, st))) return rc;
+    if ((rc = linear_fwd(Mu, D, prm + a.fc2outw, prm + a.fc2outb, cat3, L + hd, B, L, L, 1, part, pf, st))) return rc;
   } else {
-    if ((rc = linear_fwd(cat1, 768 + hd, prm + a.fc1w, prm + a.fc1b, Mu, D, B, 768 + hd, L, 1, st))) return rc;
+    if ((rc = linear_fwd(cat1, 768 + hd, prm + a.fc1w, prm + a.fc1b, Mu, D, B, 768 + hd, L, 1, part, pf, st))) return rc;
     if ((rc = copy2d(Mu, D, cat3, L + hd, B, L, st))) return rc;
   }
-  if ((rc = linear_fwd(uvh, hd, prm + a.fcuv3w, prm + a.fcuv3b, cat3 + L, L + hd, B, hd, hd, 1, st))) return rc;
-  if ((rc = linear_fwd(cat3, L + hd, prm + a.fc3w, prm + a.fc3b, ws + a.d0, 768, B, L + hd, 768, 0, st))) return rc;
+  if ((rc = linear_fwd(uvh, hd, prm + a.fcuv3w, prm + a.fcuv3b, cat3 + L, L + hd, B, hd, hd, 1, part, pf, st))) return rc;
+  if ((rc = linear_fwd(cat3, L + hd, prm + a.fc3w, prm + a.fc3b, ws + a.d0, 768, B, L + hd, 768, 0, part, pf, st))) return rc;
   in = ws + a.d0;
   for (int i = 0; i < 6; ++i) {
     float* out = (i < 5) ? ws + a.dact[i] : ws + a.out;
-    if ((rc = conv_layer_fwd(a.dec[i], in, prm + a.tw[i], prm + a.tb[i], out, i < 5, st))) return rc;
+    if ((rc = conv_layer_fwd(a.dec[i], in, prm + a.tw[i], prm + a.tb[i], out, i < 5, part, pf, st))) return rc;
     in = out;
   }
   return LSHM_OK;
@@ -222,34 +224,34 @@ static int ae_backward(const lshm_engine* e, int idx, const float* prm, float* g
     if ((rc = conv_layer_wgrad(a.dec[i], xin, dz, grd + a.tw[i], grd + a.tb[i], part, pf, 0, st))) return rc;
     float* dx = (i == 0) ? dd0 : ((i & 1) ? gA : gB);
     // previous activation is an ELU output (except fc3's output feeding tconv0)
-    if ((rc = conv_layer_dgrad(a.dec[i], dz, prm + a.tw[i], dx, i == 0 ? nullptr : xin, st))) return rc;
+    if ((rc = conv_layer_dgrad(a.dec[i], dz, prm + a.tw[i], dx, i == 0 ? nullptr : xin, part, pf, st))) return rc;
     dz = dx;
   }
   // ---- fc3 (no activation on its output): dd0 is its pre-activation gradient
-  if ((rc = linear_wgrad(cat3, L + hd, dd0, 768, grd + a.fc3w, grd + a.fc3b, B, L + hd, 768, 0, st))) return rc;
+  if ((rc = linear_wgrad(cat3, L + hd, dd0, 768, grd + a.fc3w, grd + a.fc3b, B, L + hd, 768, part, pf, st))) return rc;
   if (c.rica) {
-    if ((rc = linear_dgrad(dd0, 768, prm + a.fc3w, dcat3, L + hd, cat3, L + hd, B, L + hd, 768, st))) return rc;
+    if ((rc = linear_dgrad(dd0, 768, prm + a.fc3w, dcat3, L + hd, cat3, L + hd, B, L + hd, 768, part, pf, st))) return rc;
   } else {
     // latent == decoder input: add the latent-loss gradient before the ELU' multiply
-    if ((rc = linear_dgrad(dd0, 768, prm + a.fc3w, dcat3, L + hd, cat3, L + hd, B, L + hd, 768, st, gMu, D, L))) return rc;
+    if ((rc = linear_dgrad(dd0, 768, prm + a.fc3w, dcat3, L + hd, cat3, L + hd, B, L + hd, 768, part, pf, st, gMu, D, L))) return rc;
   }
-  if ((rc = linear_wgrad(uvh, hd, dcat3 + L, L + hd, grd + a.fcuv3w, grd + a.fcuv3b, B, hd, hd, 0, st))) return rc;
+  if ((rc = linear_wgrad(uvh, hd, dcat3 + L, L + hd, grd + a.fcuv3w, grd + a.fcuv3b, B, hd, hd, part, pf, st))) return rc;
   const float* dzfc1;  // pre-activation gradient of fc1's output
   long ld_dzfc1;
   if (c.rica) {
-    if ((rc = linear_wgrad(Mu, D, dcat3, L + hd, grd + a.fc2outw, grd + a.fc2outb, B, L, L, 0, st))) return rc;
-    if ((rc = linear_dgrad(dcat3, L + hd, prm + a.fc2outw, dzmu, L, Mu, D, B, L, L, st, gMu, D, L))) return rc;
-    if ((rc = linear_wgrad(ws + a.z1, L, dzmu, L, grd + a.fc2inw, grd + a.fc2inb, B, L, L, 0, st))) return rc;
-    if ((rc = linear_dgrad(dzmu, L, prm + a.fc2inw, dz1, L, ws + a.z1, L, B, L, L, st))) return rc;
+    if ((rc = linear_wgrad(Mu, D, dcat3, L + hd, grd + a.fc2outw, grd + a.fc2outb, B, L, L, part, pf, st))) return rc;
+    if ((rc = linear_dgrad(dcat3, L + hd, prm + a.fc2outw, dzmu, L, Mu, D, B, L, L, part, pf, st, gMu, D, L))) return rc;
+    if ((rc = linear_wgrad(ws + a.z1, L, dzmu, L, grd + a.fc2inw, grd + a.fc2inb, B, L, L, part, pf, st))) return rc;
+    if ((rc = linear_dgrad(dzmu, L, prm + a.fc2inw, dz1, L, ws + a.z1, L, B, L, L, part, pf, st))) return rc;
     dzfc1 = dz1;
     ld_dzfc1 = L;
   } else {
     dzfc1 = dcat3;
     ld_dzfc1 = L + hd;
   }
-  if ((rc = linear_wgrad(cat1, 768 + hd, dzfc1, ld_dzfc1, grd + a.fc1w, grd + a.fc1b, B, 768 + hd, L, 0, st))) return rc;
-  if ((rc = linear_dgrad(dzfc1, ld_dzfc1, prm + a.fc1w, dcat1, 768 + hd, cat1, 768 + hd, B, 768 + hd, L, st))) return rc;
-  if ((rc = linear_wgrad(uvh, hd, dcat1 + 768, 768 + hd, grd + a.fcuv1w, grd + a.fcuv1b, B, hd, hd, 0, st))) return rc;
+  if ((rc = linear_wgrad(cat1, 768 + hd, dzfc1, ld_dzfc1, grd + a.fc1w, grd + a.fc1b, B, 768 + hd, L, part, pf, st))) return rc;
+  if ((rc = linear_dgrad(dzfc1, ld_dzfc1, prm + a.fc1w, dcat1, 768 + hd, cat1, 768 + hd, B, 768 + hd, L, part, pf, st))) return rc;
+  if ((rc = linear_wgrad(uvh, hd, dcat1 + 768, 768 + hd, grd + a.fcuv1w, grd + a.fcuv1b, B, hd, hd, part, pf, st))) return rc;
   // ---- encoder
   dz = dcat1;
   for (int i = 5; i >= 0; --i) {
@@ -257,7 +259,7 @@ static int ae_backward(const lshm_engine* e, int idx, const float* prm, float* g
     if ((rc = conv_layer_wgrad(a.enc[i], xin, dz, grd + a.cw[i], grd + a.cb[i], part, pf, 0, st))) return rc;
     if (i == 0 && !dinput) break;
     float* dx = (i == 0) ? dinput : ((i & 1) ? gA : gB);
-    if ((rc = conv_layer_dgrad(a.enc[i], dz, prm + a.cw[i], dx, i == 0 ? nullptr : xin, st))) return rc;
+    if ((rc = conv_layer_dgrad(a.enc[i], dz, prm + a.cw[i], dx, i == 0 ? nullptr : xin, part, pf, st))) return rc;
     dz = dx;
   }
   return LSHM_OK;
@@ -407,11 +409,22 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   if (rp > pf) pf = rp;
   for (int a = 0; a < 3; ++a)
     for (int i = 0; i < 6; ++i) {
-      size_t w = conv_wgrad_workspace_floats(e->ae[a].enc[i]);
+      size_t w = conv_workspace_floats(e->ae[a].enc[i]);
       if (w > pf) pf = w;
-      w = conv_wgrad_workspace_floats(e->ae[a].dec[i]);
+      w = conv_workspace_floats(e->ae[a].dec[i]);
       if (w > pf) pf = w;
     }
+  {  // dense layers: largest of the fc1 / fc3 problems
+    const int Lm = cfg->L > cfg->Lt ? cfg->L : cfg->Lt;
+    size_t w = igemm_workspace_floats(B, 768, Lm + e->hdim, 1);
+    if (w > pf) pf = w;
+    w = igemm_workspace_floats(Lm, 768 + e->hdim, B, 1);
+    if (w > pf) pf = w;
+    w = igemm_workspace_floats(768, Lm + e->hdim, B, 1);
+    if (w > pf) pf = w;
+    w = igemm_workspace_floats(B, 768 + e->hdim, Lm, 1);
+    if (w > pf) pf = w;
+  }
   e->part_floats = pf;
   e->o_part = take(cur, pf);
   const size_t ngroups = (size_t)(B + cfg->bpb - 1) / cfg->bpb;

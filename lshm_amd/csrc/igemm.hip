@@ -30,6 +30,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
   constexpr int LDB = P::B_N_FAST ? ((BN % 32 == 16) ? BN : BN + 16) : (BK + 2);
   constexpr int A_ELEMS = P::A_M_FAST ? BK * LDA : BM * LDA;
   constexpr int B_ELEMS = P::B_N_FAST ? BK * LDB : BN * LDB;
+  // elements each thread stages per K chunk
+  constexpr int NA = BM * BK / NT;
+  constexpr int NB = P::B_N_FAST ? (BK + NT / BN - 1) / (NT / BN) : (BN + NT / BK - 1) / (NT / BK);
   __shared__ float smem[A_ELEMS + B_ELEMS];
   float* As = smem;
   float* Bs = smem + A_ELEMS;
@@ -37,9 +40,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int lm = lane & 15, lk = lane >> 4;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN, z = blockIdx.z;
-  int kbeg, kend;
-  P::k_range(p, z, kbeg, kend);
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // grid.z = zgroup (e.g. output parity of the transposed conv) x K split
+  const int splits = p.sk.splits;
+  const int zg = blockIdx.z / splits, split = blockIdx.z - zg * splits;
+  const int kbeg = split * p.sk.kchunk;
+  const int kend = min(p.K, kbeg + p.sk.kchunk);
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -50,43 +56,73 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
   // per-thread fixed "fast" coordinates of the gathers
   typename P::FastA fa;
   typename P::FastB fb;
-  if (P::A_M_FAST) fa = P::a_fast(p, m0 + (t % BM), z);
-  if (P::B_N_FAST) fb = P::b_fast(p, n0 + (t % BN), z);
-
+  if (P::A_M_FAST) fa = P::a_fast(p, m0 + (t % BM), zg);
+  if (P::B_N_FAST) fb = P::b_fast(p, n0 + (t % BN), zg);
   const int wm0 = wave * (BM / 4);
 
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    // ---- stage A
+  float ra[NA], rb[NB];
+  // global -> registers for the chunk starting at k0 (issued one chunk ahead of its use)
+  auto fetch = [&](int k0) {
     if (P::A_M_FAST) {
       const int ml = t % BM;
-#pragma unroll 4
-      for (int kl = t / BM; kl < BK; kl += NT / BM) {
-        const int k = k0 + kl;
-        As[kl * LDA + ml] = (k < kend) ? P::a_load(p, fa, m0 + ml, k, z) : 0.f;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int k = k0 + t / BM + i * (NT / BM);
+        ra[i] = (k < kend) ? P::a_load(p, fa, m0 + ml, k, zg) : 0.f;
       }
     } else {
-      const int kl = t % BK;
-      const int k = k0 + kl;
-      if (k < kend) fa = P::a_fast(p, k, z);
-#pragma unroll 4
-      for (int ml = t / BK; ml < BM; ml += NT / BK)
-        As[ml * LDA + kl] = (k < kend) ? P::a_load(p, fa, m0 + ml, k, z) : 0.f;
+      const int k = k0 + t % BK;
+      if (k < kend) fa = P::a_fast(p, k, zg);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        ra[i] = (k < kend) ? P::a_load(p, fa, m0 + t / BK + i * (NT / BK), k, zg) : 0.f;
     }
-    // ---- stage B
     if (P::B_N_FAST) {
       const int nl = t % BN;
-      for (int kl = t / BN; kl < BK; kl += NT / BN) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int kl = t / BN + i * (NT / BN);
         const int k = k0 + kl;
-        Bs[kl * LDB + nl] = (k < kend) ? P::b_load(p, fb, k, n0 + nl, z) : 0.f;
+        rb[i] = (kl < BK && k < kend) ? P::b_load(p, fb, k, n0 + nl, zg) : 0.f;
       }
     } else {
-      const int kl = t % BK;
-      const int k = k0 + kl;
-      if (k < kend) fb = P::b_fast(p, k, z);
-      for (int nl = t / BK; nl < BN; nl += NT / BK)
-        Bs[nl * LDB + kl] = (k < kend) ? P::b_load(p, fb, k, n0 + nl, z) : 0.f;
+      const int k = k0 + t % BK;
+      if (k < kend) fb = P::b_fast(p, k, zg);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int nl = t / BK + i * (NT / BK);
+        rb[i] = (nl < BN && k < kend) ? P::b_load(p, fb, k, n0 + nl, zg) : 0.f;
+      }
     }
+  };
+  auto stage = [&]() {
+    if (P::A_M_FAST) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) As[(t / BM + i * (NT / BM)) * LDA + t % BM] = ra[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) As[(t / BK + i * (NT / BK)) * LDA + t % BK] = ra[i];
+    }
+    if (P::B_N_FAST) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int kl = t / BN + i * (NT / BN);
+        if (kl < BK) Bs[kl * LDB + t % BN] = rb[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int nl = t / BK + i * (NT / BK);
+        if (nl < BN) Bs[nl * LDB + t % BK] = rb[i];
+      }
+    }
+  };
+
+  if (kbeg < kend) fetch(kbeg);
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    stage();
     __syncthreads();
+    if (k0 + BK < kend) fetch(k0 + BK);  // loads stay in flight under the MFMAs below
 #pragma unroll
     for (int ks = 0; ks < BK / 4; ++ks) {
       float a[TM], b[TN];
@@ -107,11 +143,56 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
     __syncthreads();
   }
   // ---- epilogue: lane holds rows 4*lk..4*lk+3 of column lm in each 16x16 tile
+  if (splits > 1) {
+    // raw partial sums, layout [z][n][Mp] (Mp = M rounded up to 4); combined by splitk_epilogue_kernel
+    const int Mp = (p.M + 3) & ~3;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int m = m0 + wm0 + 16 * i + 4 * lk, n = n0 + 16 * j + lm;
+        if (m < Mp && n < p.N)
+          *reinterpret_cast<f32x4*>(p.sk.partial + ((long)blockIdx.z * p.N + n) * Mp + m) = acc[i][j];
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      P::store(p, m0 + wm0 + 16 * i + 4 * lk, n0 + 16 * j + lm, acc[i][j], z);
+      P::store(p, m0 + wm0 + 16 * i + 4 * lk, n0 + 16 * j + lm, acc[i][j], zg);
+}
+
+// Second stage of a split-K launch: sums the partial slabs in a fixed order (bitwise
+// reproducible) and applies the problem's own epilogue.  Block = OL outputs (groups of 4 rows)
+// x SL split lanes; lanes are combined through LDS in lane order.
+template <class P>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const typename P::Params p, int zgroups,
+                                                              int OL) {
+  __shared__ f32x4 red[256];
+  const int SL = 256 / OL;
+  const int ol = threadIdx.x % OL, sl = threadIdx.x / OL;
+  const int Mp = (p.M + 3) & ~3, M4 = Mp >> 2;
+  const long nout = (long)M4 * p.N * zgroups;
+  const long o = (long)blockIdx.x * OL + ol;
+  const int splits = p.sk.splits;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  int m = 0, n = 0, zg = 0;
+  if (o < nout) {
+    const int m4 = (int)(o % M4);
+    const long r = o / M4;
+    n = (int)(r % p.N);
+    zg = (int)(r / p.N);
+    m = 4 * m4;
+    for (int s = sl; s < splits; s += SL)
+      v += *reinterpret_cast<const f32x4*>(p.sk.partial + ((long)(zg * splits + s) * p.N + n) * Mp + m);
+  }
+  red[threadIdx.x] = v;
+  __syncthreads();
+  if (sl == 0 && o < nout) {
+    for (int s = 1; s < SL; ++s) v += red[s * OL + ol];
+    P::store(p, m, n, v, zg);
+  }
 }
 
 __device__ __forceinline__ float epi(float v, float bias, int act) {
@@ -128,7 +209,6 @@ struct Conv2dFwd {
   using Params = Conv2dFwdParams;
   struct FastA { const float* base; int iy0, ix0; };
   struct FastB { int k; };
-  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
   __device__ static FastA a_fast(const Params& p, int m, int) {
     FastA f;
     if (m >= p.M) { f.base = nullptr; f.iy0 = f.ix0 = 0; return f; }
@@ -178,7 +258,6 @@ struct Conv2dDgrad {
   using Params = Conv2dDgradParams;
   struct FastA { const float* base; int mm, nn; };
   struct FastB { int n; };
-  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
   __device__ static FastA a_fast(const Params& p, int m, int) {
     FastA f;
     if (m >= p.M) { f.base = nullptr; f.mm = f.nn = 0; return f; }
@@ -231,10 +310,6 @@ struct Conv2dWgrad {
   using Params = Conv2dWgradParams;
   struct FastA { const float* base; };
   struct FastB { const float* base; int iy0, ix0; };
-  __device__ static void k_range(const Params& p, int z, int& kb, int& ke) {
-    kb = z * p.ksplit;
-    ke = min(p.K, kb + p.ksplit);
-  }
   __device__ static FastA a_fast(const Params& p, int k, int) {
     const int hw = p.Hs * p.Ws;
     const int b = k / hw, r = k - b * hw;
@@ -256,11 +331,14 @@ struct Conv2dWgrad {
     if ((unsigned)iy >= (unsigned)Hb || (unsigned)ix >= (unsigned)Wb) return 0.f;
     return f.base[((long)cb * Hb + iy) * Wb + ix];
   }
-  __device__ static void store(const Params& p, int m, int n, f32x4 v, int z) {
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (m + i < p.M) p.partial[((long)z * p.M + m + i) * p.N + n] = v[i];
+      if (m + i < p.M) {
+        float* d = p.dw + (long)(m + i) * p.N + n;
+        *d = p.accumulate ? *d + v[i] : v[i];
+      }
   }
 };
 
@@ -274,7 +352,6 @@ struct Conv1dFwd {
   using Params = Conv1dFwdParams;
   struct FastA { const float* base; int j0; };
   struct FastB { int k; };
-  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
   __device__ static FastA a_fast(const Params& p, int m, int) {
     if (m >= p.M) return FastA{nullptr, 0};
     const int b = m / p.Lo, j = m - b * p.Lo;
@@ -317,7 +394,6 @@ struct Conv1dDgrad {
   using Params = Conv1dDgradParams;
   struct FastA { const float* base; };
   struct FastB { int n; };
-  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
   __device__ static FastA a_fast(const Params& p, int m, int) {
     if (m >= p.M) return FastA{nullptr};
     const int b = m / p.Ls, i = m - b * p.Ls;
@@ -361,10 +437,6 @@ struct Conv1dWgrad {
   using Params = Conv1dWgradParams;
   struct FastA { const float* base; };
   struct FastB { const float* base; int pos0; };
-  __device__ static void k_range(const Params& p, int z, int& kb, int& ke) {
-    kb = z * p.ksplit;
-    ke = min(p.K, kb + p.ksplit);
-  }
   __device__ static FastA a_fast(const Params& p, int k, int) {
     const int b = k / p.Ls, i = k - b * p.Ls;
     return FastA{p.s + (long)b * p.s_bs + i};
@@ -382,11 +454,14 @@ struct Conv1dWgrad {
     if ((unsigned)pos >= (unsigned)p.Lb) return 0.f;
     return f.base[(long)cb * p.Lb + pos];
   }
-  __device__ static void store(const Params& p, int m, int n, f32x4 v, int z) {
+  __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      if (m + i < p.M) p.partial[((long)z * p.M + m + i) * p.N + n] = v[i];
+      if (m + i < p.M) {
+        float* d = p.dw + (long)(m + i) * p.N + n;
+        *d = p.accumulate ? *d + v[i] : v[i];
+      }
   }
 };
 
@@ -399,7 +474,6 @@ struct Strided {
   using Params = StridedGemmParams;
   struct FastA { int i; };
   struct FastB { int i; };
-  __device__ static void k_range(const Params& p, int, int& kb, int& ke) { kb = 0; ke = p.K; }
   __device__ static FastA a_fast(const Params&, int i, int) { return FastA{i}; }
   __device__ static FastB b_fast(const Params&, int i, int) { return FastB{i}; }
   __device__ static float a_load(const Params& p, const FastA&, int m, int k, int) {
@@ -426,52 +500,99 @@ struct Strided {
 // --------------------------------------------------------------------------
 // launch helpers
 // --------------------------------------------------------------------------
+// Split-K plan: when the output tiling alone cannot fill the chip (deep layers: few output
+// positions, long K; weight gradients: tiny outputs, K = B*H*W), grid.z also splits K and a
+// second kernel combines the slabs.  Needs workspace; without one the launch is unsplit.
+struct SplitPlan { int splits, kchunk; };
+static SplitPlan plan_split(long tiles, int K, int M, int N, int zgroups, size_t ws_floats) {
+  SplitPlan sp{1, (K + 15) / 16 * 16};
+  if (tiles >= 384 || K <= 64 || ws_floats == 0) return sp;
+  long want = (768 + tiles - 1) / tiles;
+  const long maxs = K / 64;  // at least 4 K-steps per split
+  if (want > maxs) want = maxs;
+  const long Mp = (M + 3) & ~3;
+  const long per = Mp * (long)N * zgroups;
+  if (per * want > (long)ws_floats) want = (long)ws_floats / per;
+  if (want <= 1) return sp;
+  int kc = (int)((K + want - 1) / want);
+  kc = (kc + 15) / 16 * 16;
+  sp.kchunk = kc;
+  sp.splits = (K + kc - 1) / kc;
+  if (sp.splits <= 1) { sp.splits = 1; sp.kchunk = (K + 15) / 16 * 16; }
+  return sp;
+}
+
 template <class P, int BM, int BN, int BK>
-static int launch_cfg(const typename P::Params& p, int M, int N, int Z, hipStream_t st) {
-  dim3 grid(cdiv(M, BM), cdiv(N, BN), Z);
+static int launch_cfg(typename P::Params p, int M, int N, int Z, float* ws, size_t wsf, hipStream_t st) {
+  const long tiles = (long)cdiv(M, BM) * cdiv(N, BN) * Z;
+  const SplitPlan sp = plan_split(tiles, p.K, M, N, Z, ws ? wsf : 0);
+  p.sk.partial = ws;
+  p.sk.splits = sp.splits;
+  p.sk.kchunk = sp.kchunk;
+  dim3 grid(cdiv(M, BM), cdiv(N, BN), Z * sp.splits);
   hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK>), grid, dim3(256), 0, st, p);
-  return check_launch("igemm");
+  int rc = check_launch("igemm");
+  if (rc || sp.splits == 1) return rc;
+  const long nout = (long)((M + 3) / 4) * N * Z;
+  const int OL = nout >= 16384 ? 64 : 16;
+  hipLaunchKernelGGL((splitk_epilogue_kernel<P>), dim3(cdiv(nout, OL)), dim3(256), 0, st, p, Z, OL);
+  return check_launch("splitk_epilogue");
 }
 
 // choose the N tile from the real N so padding waste stays small
 template <class P, int BM>
-static int launch_by_n(const typename P::Params& p, int M, int N, int Z, hipStream_t st) {
-  if (N <= 16) return launch_cfg<P, BM, 16, 16>(p, M, N, Z, st);
-  if (N <= 32) return launch_cfg<P, BM, 32, 16>(p, M, N, Z, st);
-  if (N <= 48 || (N % 48 == 0 && N % 64 != 0)) return launch_cfg<P, BM, 48, 16>(p, M, N, Z, st);
-  return launch_cfg<P, BM, 64, 16>(p, M, N, Z, st);
+static int launch_by_n(const typename P::Params& p, int M, int N, int Z, float* ws, size_t wsf,
+                       hipStream_t st) {
+  if (N <= 16) return launch_cfg<P, BM, 16, 16>(p, M, N, Z, ws, wsf, st);
+  if (N <= 32) return launch_cfg<P, BM, 32, 16>(p, M, N, Z, ws, wsf, st);
+  if (N <= 48 || (N % 48 == 0 && N % 64 != 0)) return launch_cfg<P, BM, 48, 16>(p, M, N, Z, ws, wsf, st);
+  return launch_cfg<P, BM, 64, 16>(p, M, N, Z, ws, wsf, st);
 }
 
 template <class P>
-static int launch_auto(const typename P::Params& p, int M, int N, int Z, hipStream_t st) {
+static int launch_auto(const typename P::Params& p, int M, int N, int Z, float* ws, size_t wsf,
+                       hipStream_t st) {
   // small-M problems (deep layers, weight gradients): 64-row tiles give more workgroups
-  if (M <= 64 || (long)cdiv(M, 128) * cdiv(N, 64) * Z < 256) return launch_by_n<P, 64>(p, M, N, Z, st);
-  return launch_by_n<P, 128>(p, M, N, Z, st);
+  if (M <= 64 || (long)cdiv(M, 128) * cdiv(N, 64) * Z < 256)
+    return launch_by_n<P, 64>(p, M, N, Z, ws, wsf, st);
+  return launch_by_n<P, 128>(p, M, N, Z, ws, wsf, st);
 }
 
-int conv2d_fwd(const Conv2dFwdParams& p, hipStream_t st) {
-  return launch_auto<Conv2dFwd>(p, p.M, p.N, 1, st);
+size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {
+  // enough for the largest split the planner may choose (768 tiles' worth of slabs)
+  const long Mp = (M + 3) & ~3;
+  const long tiles = (long)cdiv(M, 128) * cdiv(N, 64) * zgroups;
+  if (tiles >= 384 || K <= 64) return 0;
+  long want = 768;  // upper bound on splits (tiles >= 1)
+  const long maxs = K / 64;
+  if (want > maxs) want = maxs;
+  return (size_t)(Mp * (long)N * zgroups * want);
 }
-int conv2d_dgrad(const Conv2dDgradParams& p, hipStream_t st) {
-  return launch_auto<Conv2dDgrad>(p, p.M, p.N, 4, st);
+
+int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st) {
+  return launch_auto<Conv2dFwd>(p, p.M, p.N, 1, ws, wsf, st);
 }
-int conv2d_wgrad(const Conv2dWgradParams& p, int nsplit, hipStream_t st) {
-  return launch_auto<Conv2dWgrad>(p, p.M, p.N, nsplit, st);
+int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st) {
+  return launch_auto<Conv2dDgrad>(p, p.M, p.N, 4, ws, wsf, st);
 }
-int conv1d_fwd(const Conv1dFwdParams& p, hipStream_t st) {
-  return launch_auto<Conv1dFwd>(p, p.M, p.N, 1, st);
+int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st) {
+  return launch_auto<Conv2dWgrad>(p, p.M, p.N, 1, ws, wsf, st);
 }
-int conv1d_dgrad(const Conv1dDgradParams& p, hipStream_t st) {
-  return launch_auto<Conv1dDgrad>(p, p.M, p.N, 1, st);
+int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st) {
+  return launch_auto<Conv1dFwd>(p, p.M, p.N, 1, ws, wsf, st);
 }
-int conv1d_wgrad(const Conv1dWgradParams& p, int nsplit, hipStream_t st) {
-  return launch_auto<Conv1dWgrad>(p, p.M, p.N, nsplit, st);
+int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st) {
+  return launch_auto<Conv1dDgrad>(p, p.M, p.N, 1, ws, wsf, st);
 }
-int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, hipStream_t st) {
-  if (a_m_fast && b_n_fast) return launch_auto<Strided<true, true>>(p, p.M, p.N, 1, st);
-  if (a_m_fast) return launch_auto<Strided<true, false>>(p, p.M, p.N, 1, st);
-  if (b_n_fast) return launch_auto<Strided<false, true>>(p, p.M, p.N, 1, st);
-  return launch_auto<Strided<false, false>>(p, p.M, p.N, 1, st);
+int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st) {
+  return launch_auto<Conv1dWgrad>(p, p.M, p.N, 1, ws, wsf, st);
+}
+int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
+                 hipStream_t st) {
+  if (a_m_fast && b_n_fast) return launch_auto<Strided<true, true>>(p, p.M, p.N, 1, ws, wsf, st);
+  if (a_m_fast) return launch_auto<Strided<true, false>>(p, p.M, p.N, 1, ws, wsf, st);
+  if (b_n_fast) return launch_auto<Strided<false, true>>(p, p.M, p.N, 1, ws, wsf, st);
+  return launch_auto<Strided<false, false>>(p, p.M, p.N, 1, ws, wsf, st);
 }
 
 }  // namespace lshm

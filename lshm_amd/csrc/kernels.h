@@ -7,12 +7,14 @@
 namespace lshm {
 
 // ---- implicit-GEMM problem descriptors (igemm.hip) -------------------------
+struct SplitK { float* partial; int splits; int kchunk; };  // filled in by the launcher
 struct Conv2dFwdParams {   // y = act(conv2d_k4s2p1(x, w) + bias) [* elu'(dact)]
   const float* x; const float* w; const float* bias; float* y; const float* dact;
   int B, Cin, H, W, Cout, Ho, Wo;
   long x_bs, y_bs;  // batch strides (elements)
   int act;
   int M, N, K;
+  SplitK sk;
 };
 struct Conv2dDgradParams {  // big = act(tconv2d_k4s2p1(small, w) + bias) [* elu'(dact)]
   const float* s; const float* w; const float* bias; float* big; const float* dact;
@@ -20,12 +22,14 @@ struct Conv2dDgradParams {  // big = act(tconv2d_k4s2p1(small, w) + bias) [* elu
   long s_bs, big_bs;
   int act;
   int M, N, K;
+  SplitK sk;
 };
 struct Conv2dWgradParams {  // partial[z] = small^T (x) im2col(big) over a K slice
-  const float* s; const float* big; float* partial;
+  const float* s; const float* big; float* dw;
   int B, Cs, Hs, Ws, Cb;
   long s_bs, big_bs;
-  int M, N, K, ksplit;
+  int M, N, K, accumulate;
+  SplitK sk;
 };
 struct Conv1dFwdParams {
   const float* x; const float* w; const float* bias; float* y; const float* dact;
@@ -33,6 +37,7 @@ struct Conv1dFwdParams {
   long x_bs, y_bs;
   int act;
   int M, N, K;
+  SplitK sk;
 };
 struct Conv1dDgradParams {
   const float* s; const float* w; const float* bias; float* big; const float* dact;
@@ -40,29 +45,35 @@ struct Conv1dDgradParams {
   long s_bs, big_bs;
   int act;
   int M, N, K;
+  SplitK sk;
 };
 struct Conv1dWgradParams {
-  const float* s; const float* big; float* partial;
+  const float* s; const float* big; float* dw;
   int B, Cs, Ls, Cb, Lb, pad;
   long s_bs, big_bs;
-  int M, N, K, ksplit;
+  int M, N, K, accumulate;
+  SplitK sk;
 };
 struct StridedGemmParams {
   const float* a; const float* b; const float* bias; float* c; const float* dact;
   long sam, sak, sbk, sbn, scm, scn, sdm, sdn;
   int act;
   int M, N, K;
+  SplitK sk;
   // optional addend applied before the ELU' multiply: c = (acc + add[m,n]) * elu'(dact), n < add_n
   const float* add; long sxm; int add_n;
 };
 
-int conv2d_fwd(const Conv2dFwdParams& p, hipStream_t st);
-int conv2d_dgrad(const Conv2dDgradParams& p, hipStream_t st);
-int conv2d_wgrad(const Conv2dWgradParams& p, int nsplit, hipStream_t st);
-int conv1d_fwd(const Conv1dFwdParams& p, hipStream_t st);
-int conv1d_dgrad(const Conv1dDgradParams& p, hipStream_t st);
-int conv1d_wgrad(const Conv1dWgradParams& p, int nsplit, hipStream_t st);
-int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, hipStream_t st);
+// ws / wsf: optional split-K scratch (null: never split)
+int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st);
+int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st);
+int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st);
+int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st);
+int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st);
+int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st);
+int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
+                 hipStream_t st);
+size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
 
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
@@ -73,28 +84,29 @@ struct ConvLayer {
   long in_bs, out_bs; // batch strides of input / output tensors (elements)
 };
 void conv_out_dims(const ConvLayer& L, int& Hout, int& Wout);
-size_t conv_wgrad_workspace_floats(const ConvLayer& L);
-// y = act(op(x,w)+b)
+// scratch (floats) that lets every problem of the layer use split-K + the bias partial sums
+size_t conv_workspace_floats(const ConvLayer& L);
+// y = act(op(x,w)+b); ws optional (null: no split-K)
 int conv_layer_fwd(const ConvLayer& L, const float* x, const float* w, const float* b, float* y,
-                   int act, hipStream_t st);
-// dx = op^T(dz, w) [* elu'(x_saved) if dact_in]; dx may be null (first layer)
+                   int act, float* ws, size_t wsf, hipStream_t st);
+// dx = op^T(dz, w) [* elu'(x_saved) if dact_in]
 int conv_layer_dgrad(const ConvLayer& L, const float* dz, const float* w, float* dx,
-                     const float* dact_in, hipStream_t st);
-// dw, db overwritten (accumulate=0) or accumulated (accumulate=1); ws >= conv_wgrad_workspace_floats
+                     const float* dact_in, float* ws, size_t wsf, hipStream_t st);
+// dw, db overwritten (accumulate=0) or accumulated (accumulate=1); ws required (>= 32784 floats)
 int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float* dw, float* db,
                      float* ws, size_t ws_floats, int accumulate, hipStream_t st);
 
 // y[B,N] (ld ldy) = act(x[B,K] (ld ldx) @ w[N,K]^T + b)
 int linear_fwd(const float* x, long ldx, const float* w, const float* b, float* y, long ldy, int B,
-               int K, int N, int act, hipStream_t st);
-// dx[B,K] (ld lddx) = dz[B,N] (ld lddz) @ w[N,K]  [* elu'(xsaved (ld ldxs))]
+               int K, int N, int act, float* ws, size_t wsf, hipStream_t st);
+// dx[B,K] (ld lddx) = (dz[B,N] (ld lddz) @ w[N,K] + add) [* elu'(xsaved (ld ldxs))]
 int linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
-                 const float* xsaved, long ldxs, int B, int K, int N, hipStream_t st,
-                 const float* add = nullptr, long ldadd = 0, int add_n = 0);
+                 const float* xsaved, long ldxs, int B, int K, int N, float* ws, size_t wsf,
+                 hipStream_t st, const float* add = nullptr, long ldadd = 0, int add_n = 0);
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t st);
 // dw[N,K] = dz^T x ; db[N] = colsum(dz)
 int linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
-                 int K, int N, int accumulate, hipStream_t st);
+                 int K, int N, float* ws, size_t wsf, hipStream_t st);
 
 // ---- elementwise / reductions (elementwise.hip) -----------------------------
 int uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, hipStream_t st);

@@ -18,142 +18,163 @@ void conv_out_dims(const ConvLayer& L, int& Ho, int& Wo) {
 
 static bool transposed(const ConvLayer& L) { return L.kind == 1 || L.kind == 3; }
 
-// split-K plan for the weight gradient: (M, N) = weight matrix, K = B * small spatial size
-struct WgradPlan { int M, N; long K; int S, ksplit, Sb; };
-static WgradPlan wgrad_plan(const ConvLayer& L) {
-  WgradPlan w;
+// GEMM shapes of the three problems of a layer
+struct LayerGemm { int M, N, K, Z; };
+static LayerGemm fwd_gemm(const ConvLayer& L) {
+  int Ho, Wo;
+  conv_out_dims(L, Ho, Wo);
+  switch (L.kind) {
+    case 0: return {L.B * Ho * Wo, L.Cout, L.Cin * 16, 1};
+    case 1: return {L.B * L.Hin * L.Win, L.Cout, L.Cin * 4, 4};
+    case 2: return {L.B * Wo, L.Cout, L.Cin * 4, 1};
+    default: return {L.B * L.Win, L.Cout * 4, L.Cin, 1};
+  }
+}
+static LayerGemm dgrad_gemm(const ConvLayer& L) {
+  int Ho, Wo;
+  conv_out_dims(L, Ho, Wo);
+  switch (L.kind) {
+    case 0: return {L.B * Ho * Wo, L.Cin, L.Cout * 4, 4};
+    case 1: return {L.B * L.Hin * L.Win, L.Cin, L.Cout * 16, 1};
+    case 2: return {L.B * Wo, L.Cin * 4, L.Cout, 1};
+    default: return {L.B * L.Win, L.Cin, L.Cout * 4, 1};
+  }
+}
+static LayerGemm wgrad_gemm(const ConvLayer& L) {
   int Ho, Wo;
   conv_out_dims(L, Ho, Wo);
   const int taps = (L.kind < 2) ? 16 : 4;
   const long small_sp = transposed(L) ? (long)L.Hin * L.Win : (long)Ho * Wo;
-  w.M = transposed(L) ? L.Cin : L.Cout;                 // small-tensor channels
-  w.N = (transposed(L) ? L.Cout : L.Cin) * taps;        // big-tensor channels x taps
-  w.K = (long)L.B * small_sp;
-  const long tiles = (long)cdiv(w.M, 64) * cdiv(w.N, 64);
-  long want = 1024 / tiles;
-  if (want < 1) want = 1;
-  long maxs = cdiv(w.K, 256);
-  if (maxs < 1) maxs = 1;
-  long S = want < maxs ? want : maxs;
-  long ks = cdiv(w.K, S);
-  ks = (ks + 15) / 16 * 16;
-  w.ksplit = (int)ks;
-  w.S = cdiv(w.K, ks);
-  w.Sb = L.B < 32 ? L.B : 32;
-  return w;
+  return {transposed(L) ? L.Cin : L.Cout, (transposed(L) ? L.Cout : L.Cin) * taps,
+          (int)((long)L.B * small_sp), 1};
 }
-size_t conv_wgrad_workspace_floats(const ConvLayer& L) {
-  const WgradPlan w = wgrad_plan(L);
-  return (size_t)w.S * w.M * w.N + (size_t)w.Sb * L.Cout + 16;
+
+#define BIAS_WS_FLOATS (128 * 256)
+static int bias_slices(const ConvLayer& L) {
+  int s = 512 / (L.Cout > 0 ? L.Cout : 1);
+  if (s < 1) s = 1;
+  if (s > 128) s = 128;
+  if (s > L.B) s = L.B;
+  return s;
+}
+
+size_t conv_workspace_floats(const ConvLayer& L) {
+  const LayerGemm f = fwd_gemm(L), d = dgrad_gemm(L), w = wgrad_gemm(L);
+  size_t a = igemm_workspace_floats(f.M, f.N, f.K, f.Z);
+  const size_t b = igemm_workspace_floats(d.M, d.N, d.K, d.Z);
+  const size_t c = igemm_workspace_floats(w.M, w.N, w.K, w.Z);
+  if (b > a) a = b;
+  if (c > a) a = c;
+  return a + BIAS_WS_FLOATS + 16;
 }
 
 int conv_layer_fwd(const ConvLayer& L, const float* x, const float* w, const float* b, float* y,
-                   int act, hipStream_t st) {
+                   int act, float* ws, size_t wsf, hipStream_t st) {
   int Ho, Wo;
   conv_out_dims(L, Ho, Wo);
   switch (L.kind) {
     case 0: {
       Conv2dFwdParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout, Ho, Wo,
-                        L.in_bs, L.out_bs, act, L.B * Ho * Wo, L.Cout, L.Cin * 16};
-      return conv2d_fwd(p, st);
+                        L.in_bs, L.out_bs, act, L.B * Ho * Wo, L.Cout, L.Cin * 16, {}};
+      return conv2d_fwd(p, ws, wsf, st);
     }
     case 1: {
       Conv2dDgradParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout,
-                          L.in_bs, L.out_bs, act, L.B * L.Hin * L.Win, L.Cout, L.Cin * 4};
-      return conv2d_dgrad(p, st);
+                          L.in_bs, L.out_bs, act, L.B * L.Hin * L.Win, L.Cout, L.Cin * 4, {}};
+      return conv2d_dgrad(p, ws, wsf, st);
     }
     case 2: {
       Conv1dFwdParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Win, L.Cout, Wo, 1,
-                        L.in_bs, L.out_bs, act, L.B * Wo, L.Cout, L.Cin * 4};
-      return conv1d_fwd(p, st);
+                        L.in_bs, L.out_bs, act, L.B * Wo, L.Cout, L.Cin * 4, {}};
+      return conv1d_fwd(p, ws, wsf, st);
     }
     default: {
       Conv1dDgradParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Win, L.Cout, Wo, 0,
-                          L.in_bs, L.out_bs, act, L.B * L.Win, L.Cout * 4, L.Cin};
-      return conv1d_dgrad(p, st);
+                          L.in_bs, L.out_bs, act, L.B * L.Win, L.Cout * 4, L.Cin, {}};
+      return conv1d_dgrad(p, ws, wsf, st);
     }
   }
 }
 
 int conv_layer_dgrad(const ConvLayer& L, const float* dz, const float* w, float* dx,
-                     const float* dact_in, hipStream_t st) {
+                     const float* dact_in, float* ws, size_t wsf, hipStream_t st) {
   int Ho, Wo;
   conv_out_dims(L, Ho, Wo);
   switch (L.kind) {
     case 0: {  // dx (big) from dz (small)
       Conv2dDgradParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Ho, Wo, L.Cin,
-                          L.out_bs, L.in_bs, 0, L.B * Ho * Wo, L.Cin, L.Cout * 4};
-      return conv2d_dgrad(p, st);
+                          L.out_bs, L.in_bs, 0, L.B * Ho * Wo, L.Cin, L.Cout * 4, {}};
+      return conv2d_dgrad(p, ws, wsf, st);
     }
     case 1: {  // dx (small) = strided conv of dz (big) with the same weight tensor
       Conv2dFwdParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Ho, Wo, L.Cin, L.Hin, L.Win,
-                        L.out_bs, L.in_bs, 0, L.B * L.Hin * L.Win, L.Cin, L.Cout * 16};
-      return conv2d_fwd(p, st);
+                        L.out_bs, L.in_bs, 0, L.B * L.Hin * L.Win, L.Cin, L.Cout * 16, {}};
+      return conv2d_fwd(p, ws, wsf, st);
     }
     case 2: {
       Conv1dDgradParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Wo, L.Cin, L.Win, 1,
-                          L.out_bs, L.in_bs, 0, L.B * Wo, L.Cin * 4, L.Cout};
-      return conv1d_dgrad(p, st);
+                          L.out_bs, L.in_bs, 0, L.B * Wo, L.Cin * 4, L.Cout, {}};
+      return conv1d_dgrad(p, ws, wsf, st);
     }
     default: {
       Conv1dFwdParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Wo, L.Cin, L.Win, 0,
-                        L.out_bs, L.in_bs, 0, L.B * L.Win, L.Cin, L.Cout * 4};
-      return conv1d_fwd(p, st);
+                        L.out_bs, L.in_bs, 0, L.B * L.Win, L.Cin, L.Cout * 4, {}};
+      return conv1d_fwd(p, ws, wsf, st);
     }
   }
 }
 
 int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float* dw, float* db,
                      float* ws, size_t ws_floats, int accumulate, hipStream_t st) {
-  if (ws_floats < conv_wgrad_workspace_floats(L)) {
+  if (!ws || ws_floats < BIAS_WS_FLOATS + 16) {
     set_last_error("conv wgrad: workspace too small");
     return LSHM_ERR_WORKSPACE;
   }
   int Ho, Wo;
   conv_out_dims(L, Ho, Wo);
-  const WgradPlan wp = wgrad_plan(L);
+  const LayerGemm g = wgrad_gemm(L);
   const bool tr = transposed(L);
   // small / big tensors of the underlying strided-conv geometry
   const float* small = tr ? x : dz;
   const float* big = tr ? dz : x;
   const long s_bs = tr ? L.in_bs : L.out_bs;
   const long big_bs = tr ? L.out_bs : L.in_bs;
-  const int Cs = wp.M, Cb = tr ? L.Cout : L.Cin;
+  const int Cs = g.M, Cb = tr ? L.Cout : L.Cin;
+  float* bias_ws = ws;
+  float* gemm_ws = ws + BIAS_WS_FLOATS;
+  const size_t gemm_wsf = ws_floats - BIAS_WS_FLOATS;
   int rc;
   if (L.kind < 2) {
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
-    Conv2dWgradParams p{small, big, ws, L.B, Cs, Hs, Ws, Cb, s_bs, big_bs,
-                        wp.M, wp.N, (int)wp.K, wp.ksplit};
-    rc = conv2d_wgrad(p, wp.S, st);
+    Conv2dWgradParams p{small, big, dw, L.B, Cs, Hs, Ws, Cb, s_bs, big_bs, g.M, g.N, g.K, accumulate, {}};
+    rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st);
   } else {
     const int Ls = tr ? L.Win : Wo, Lb = tr ? Wo : L.Win;
-    Conv1dWgradParams p{small, big, ws, L.B, Cs, Ls, Cb, Lb, tr ? 0 : 1, s_bs, big_bs,
-                        wp.M, wp.N, (int)wp.K, wp.ksplit};
-    rc = conv1d_wgrad(p, wp.S, st);
+    Conv1dWgradParams p{small, big, dw, L.B, Cs, Ls, Cb, Lb, tr ? 0 : 1, s_bs, big_bs,
+                        g.M, g.N, g.K, accumulate, {}};
+    rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st);
   }
-  if (rc) return rc;
-  rc = reduce_partials(ws, dw, (long)wp.M * wp.N, wp.S, accumulate, st);
   if (rc || !db) return rc;
-  float* bpart = ws + (size_t)wp.S * wp.M * wp.N;
-  rc = channel_sum_partials(dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, bpart, wp.Sb, st);
+  const int Sb = bias_slices(L);
+  rc = channel_sum_partials(dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, bias_ws, Sb, st);
   if (rc) return rc;
-  return reduce_partials(bpart, db, L.Cout, wp.Sb, accumulate, st);
+  return reduce_partials(bias_ws, db, L.Cout, Sb, accumulate, st);
 }
 
 // --------------------------------------------------------------------------
 // dense layers
 // --------------------------------------------------------------------------
 int linear_fwd(const float* x, long ldx, const float* w, const float* b, float* y, long ldy, int B,
-               int K, int N, int act, hipStream_t st) {
-  StridedGemmParams p{x, w, b, y, nullptr, ldx, 1, 1, K, ldy, 1, 0, 0, act, B, N, K, nullptr, 0, 0};
-  return strided_gemm(p, false, false, st);
+               int K, int N, int act, float* ws, size_t wsf, hipStream_t st) {
+  StridedGemmParams p{x, w, b, y, nullptr, ldx, 1, 1, K, ldy, 1, 0, 0, act, B, N, K, {}, nullptr, 0, 0};
+  return strided_gemm(p, false, false, ws, wsf, st);
 }
 int linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
-                 const float* xsaved, long ldxs, int B, int K, int N, hipStream_t st,
-                 const float* add, long ldadd, int add_n) {
-  StridedGemmParams p{dz, w, nullptr, dx, xsaved, lddz, 1, K, 1, lddx, 1, ldxs, 1, 0, B, K, N,
+                 const float* xsaved, long ldxs, int B, int K, int N, float* ws, size_t wsf,
+                 hipStream_t st, const float* add, long ldadd, int add_n) {
+  StridedGemmParams p{dz, w, nullptr, dx, xsaved, lddz, 1, K, 1, lddx, 1, ldxs, 1, 0, B, K, N, {},
                       add, ldadd, add_n};
-  return strided_gemm(p, false, true, st);
+  return strided_gemm(p, false, true, ws, wsf, st);
 }
 __global__ void copy2d_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst,
                               long ldd, int rows, int cols) {
@@ -168,22 +189,27 @@ int copy2d(const float* src, long lds_, float* dst, long ldd, int rows, int cols
                      src, lds_, dst, ldd, rows, cols);
   return check_launch("copy2d");
 }
-__global__ void colsum_kernel(const float* __restrict__ dz, long lddz, int B, int N,
-                              float* __restrict__ db, int accumulate) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// db[n] = sum_b dz[b, n]: one wave per 64 columns would leave the chip idle for B x 768
+// problems, so rows are split over the 4 waves of a block and combined through LDS.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz, long lddz, int B, int N,
+                                                     float* __restrict__ db) {
+  __shared__ float red[256];
+  const int nl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + nl;
   float acc = 0.f;
-  for (int b = 0; b < B; ++b) acc += dz[(long)b * lddz + n];
-  db[n] = accumulate ? db[n] + acc : acc;
+  if (n < N)
+    for (int b = part; b < B; b += 4) acc += dz[(long)b * lddz + n];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (part == 0 && n < N) db[n] = (red[nl] + red[64 + nl]) + (red[128 + nl] + red[192 + nl]);
 }
 int linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
-                 int K, int N, int accumulate, hipStream_t st) {
-  if (accumulate) { set_last_error("linear_wgrad: accumulate not supported"); return LSHM_ERR_UNSUPPORTED; }
-  StridedGemmParams p{dz, x, nullptr, dw, nullptr, 1, lddz, ldx, 1, K, 1, 0, 0, 0, N, K, B,
+                 int K, int N, float* ws, size_t wsf, hipStream_t st) {
+  StridedGemmParams p{dz, x, nullptr, dw, nullptr, 1, lddz, ldx, 1, K, 1, 0, 0, 0, N, K, B, {},
                       nullptr, 0, 0};
-  int rc = strided_gemm(p, true, true, st);
+  int rc = strided_gemm(p, true, true, ws, wsf, st);
   if (rc || !db) return rc;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, dz, lddz, B, N, db, 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, dz, lddz, B, N, db);
   return check_launch("colsum");
 }
 

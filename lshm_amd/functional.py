@@ -61,8 +61,10 @@ class _ConvAct(torch.autograd.Function):
         B, Cin, Cout, Hin, Win, oshape = _geom(kind, x, w)
         y = torch.empty(oshape, device=x.device, dtype=torch.float32)
         if B > 0:
+            nws = lib.lshm_conv_workspace_floats(kind, B, Cin, Cout, Hin, Win)
+            ws = L.scratch(x.device, nws)
             L.check(lib.lshm_conv_fwd(kind, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, Cin, Cout, Hin, Win,
-                                      0, 0, int(act), L.stream()), "conv_fwd")
+                                      0, 0, int(act), L.ptr(ws), ws.numel(), L.stream()), "conv_fwd")
         ctx.save_for_backward(x, w, y)
         ctx.kind, ctx.act, ctx.has_bias = kind, act, b is not None
         return y
@@ -84,17 +86,17 @@ class _ConvAct(torch.autograd.Function):
         if B == 0:
             return (torch.zeros_like(x), torch.zeros_like(w),
                     torch.zeros(Cout, device=x.device) if ctx.has_bias else None, None, None)
+        nws = lib.lshm_conv_workspace_floats(kind, B, Cin, Cout, Hin, Win)
+        ws = L.scratch(x.device, nws)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             L.check(lib.lshm_conv_dgrad(kind, L.ptr(dz), L.ptr(w), L.ptr(dx), None, B, Cin, Cout, Hin, Win,
-                                        0, 0, st), "conv_dgrad")
+                                        0, 0, L.ptr(ws), ws.numel(), st), "conv_dgrad")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            nws = lib.lshm_conv_wgrad_workspace_floats(kind, B, Cin, Cout, Hin, Win)
-            ws = torch.empty(nws, device=x.device, dtype=torch.float32)
             dw = torch.empty_like(w)
             db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
             L.check(lib.lshm_conv_wgrad(kind, L.ptr(x), L.ptr(dz), L.ptr(dw), L.ptr(db), B, Cin, Cout, Hin,
-                                        Win, 0, 0, L.ptr(ws), nws, 0, st), "conv_wgrad")
+                                        Win, 0, 0, L.ptr(ws), ws.numel(), 0, st), "conv_wgrad")
         return dx, dw, db, None, None
 
 
@@ -118,8 +120,10 @@ class _LinearAct(torch.autograd.Function):
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({B}x{K} and {w.shape[1]}x{N})")
         y = torch.empty((B, N), device=x.device, dtype=torch.float32)
         if B > 0:
-            L.check(L.load().lshm_linear_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), N, B, K, N, int(act),
-                                             L.stream()), "linear_fwd")
+            lib = L.load()
+            ws = L.scratch(x.device, lib.lshm_linear_workspace_floats(B, K, N))
+            L.check(lib.lshm_linear_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), N, B, K, N, int(act),
+                                        L.ptr(ws), ws.numel(), L.stream()), "linear_fwd")
         ctx.save_for_backward(x, w, y)
         ctx.act, ctx.has_bias = act, b is not None
         return y
@@ -140,15 +144,16 @@ class _LinearAct(torch.autograd.Function):
         else:
             dz = gy
         dx = dw = db = None
+        ws = L.scratch(x.device, lib.lshm_linear_workspace_floats(B, K, N))
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.check(lib.lshm_linear_dgrad(L.ptr(dz), N, L.ptr(w), L.ptr(dx), K, None, 0, B, K, N, st),
-                    "linear_dgrad")
+            L.check(lib.lshm_linear_dgrad(L.ptr(dz), N, L.ptr(w), L.ptr(dx), K, None, 0, B, K, N, L.ptr(ws),
+                                          ws.numel(), st), "linear_dgrad")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-            L.check(lib.lshm_linear_wgrad(L.ptr(x), K, L.ptr(dz), N, L.ptr(dw), L.ptr(db), B, K, N, st),
-                    "linear_wgrad")
+            L.check(lib.lshm_linear_wgrad(L.ptr(x), K, L.ptr(dz), N, L.ptr(dw), L.ptr(db), B, K, N, L.ptr(ws),
+                                          ws.numel(), st), "linear_wgrad")
         return dx, dw, db, None
 
 
