@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--only-khm", action="store_true", help="time only the K-harmonic kernel (dev aid)")
     return ap.parse_args()
 
 
@@ -149,6 +150,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         pg = dist.group.WORLD
 
+    if args.only_khm:
+        print(json.dumps({"khm_roofline": khm_roofline(dev), "khm_B256": khm_roofline(dev, N=256)}))
+        return
     from lshm_amd import KHarmonicTrainer, TrainConfig
     B = args.batch
     cfg = TrainConfig(Kc=args.K)

@@ -172,6 +172,205 @@ __global__ __launch_bounds__(NW * 64) void khm_kernel(
   }
 }
 
+// --------------------------------------------------------------------------
+// Streaming fast path for latent_dim == 256 and K <= 16 (the training configuration):
+//   * a wavefront handles 4 rows at a time, 16 lanes per row; lane j of a row owns columns
+//     64q + 4j .. 64q + 4j + 3 (q = 0..3): every load/store instruction moves four 256-byte
+//     contiguous row segments as float4 per lane;
+//   * the K squared distances are reduced over the 16 lanes of a row with DPP row rotations
+//     (pure VALU, no LDS crossbar), leaving every lane with all K values, so the soft-min
+//     scalars need no further cross-lane traffic;
+//   * centroids are read from LDS as ds_read_b128 (the four rows of a wave read the same
+//     addresses: broadcast, conflict-free);
+//   * the centroid-side sums T = W^T X ride on the matrix cores: one v_mfma_f32_16x16x4_f32 per
+//     16-column chunk with A = W (lane (cluster, row)) and B = X (lane (row, column)), exact fp32;
+//   * the next 4 rows are prefetched into registers while the current ones are processed.
+// --------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL,
+                                                               0xF, 0xF, false));
+}
+// sum over the 16 lanes of a DPP row; every lane receives the total
+__device__ __forceinline__ float row16_allsum(float v) {
+  v += dpp_mov<0x128>(v);  // row_ror:8
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<0x122>(v);  // row_ror:2
+  v += dpp_mov<0x121>(v);  // row_ror:1
+  return v;
+}
+
+// PI: compile-time integer exponent (4 = the training configuration) or 0 = runtime p
+template <int PI>
+__device__ __forceinline__ float ph_t(float s, float p, int pint) { return PI == 4 ? s * s : pow_half(s, p, pint); }
+template <int PI>
+__device__ __forceinline__ float phm1_t(float s, float p, int pint) { return PI == 4 ? s : pow_half_m1(s, p, pint); }
+// v_rcp_f32: 1 ulp, against ~10 instructions for an IEEE divide
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+
+// 4-wave workgroups, 3 per CU at the kernel's 3 waves/SIMD (12-wave workgroups measured 25% slower)
+#define KHM_FAST_WAVES 4
+#define KHM_FAST_THREADS (KHM_FAST_WAVES * 64)
+#define KHM_FAST_ROWS (KHM_FAST_WAVES * 4)
+template <int MODE, int KT, int PI>
+__global__ __launch_bounds__(KHM_FAST_THREADS) void khm256_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ Mg, int N, int K, float p,
+    int pint, float eps, float wscale, float* __restrict__ dX, long lddx, int accumulate_dx,
+    float* __restrict__ partial /* [grid][K*256 + K] */, double* __restrict__ loss_partial) {
+  constexpr int D = 256;
+  __shared__ __attribute__((aligned(16))) float Ms[KT * D];  // centroids; reused for the block combine
+  __shared__ float Ssum[16];
+  __shared__ double lred[KHM_FAST_WAVES];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 15, rg = lane >> 4;
+  for (int i = threadIdx.x; i < KT * D; i += KHM_FAST_THREADS) Ms[i] = i < K * D ? Mg[i] : 0.f;
+  __syncthreads();
+
+  f32x4 acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float s_acc = 0.f;
+  double lsum = 0.0;
+
+  const long stride = (long)gridDim.x * KHM_FAST_ROWS;
+  long row = (long)blockIdx.x * KHM_FAST_ROWS + wave * 4 + rg;
+  f32x4 xn[4];
+  auto load_rows = [&](long r) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      xn[q] = r < N ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(X + r * ldx + 64 * q + 4 * j))
+                    : (f32x4){0.f, 0.f, 0.f, 0.f};  // streamed once: keep it out of L2's way
+  };
+  load_rows(row);
+  // the loop bound is wave-uniform: all four row groups of a wave iterate together
+  for (long base = (long)blockIdx.x * KHM_FAST_ROWS + wave * 4; base < N; base += stride, row += stride) {
+    f32x4 x[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = xn[q];
+    load_rows(row + stride);
+    const bool valid = row < N;
+    float s[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      s[k] = 0.f;
+      if (k < K) {
+        // vector form so the compiler emits packed v_pk_add_f32 / v_pk_fma_f32
+        f32x4 a4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(&Ms[k * D + 64 * q + 4 * j]);
+          const f32x4 d = x[q] - m;
+          a4 = __builtin_elementwise_fma(d, d, a4);
+        }
+        s[k] = row16_allsum((a4[0] + a4[1]) + (a4[2] + a4[3]));
+      }
+    }
+    // soft-min scalars, replicated in the 16 lanes of the row
+    float w[KT];
+    float wsum = 0.f;
+    if (MODE == KHM_DIST) {
+#pragma unroll
+      for (int k = 0; k < KT; ++k) w[k] = (k < K && valid) ? ph_t<PI>(s[k], p, pint) : 0.f;
+    } else {
+      float e = 0.f;
+      float inv[KT];
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        inv[k] = 0.f;
+        if (k < K) {
+          inv[k] = fast_rcp(ph_t<PI>(s[k], p, pint) + eps);
+          e += inv[k];
+        }
+      }
+      if (MODE == KHM_FWD_BWD) {
+        const float ee = e + eps;
+        if (j == 0 && valid) lsum += (double)((float)K / ee);
+        const float ri = fast_rcp(ee);
+        const float basew = valid ? wscale * ri * ri * p : 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          w[k] = (k < K) ? basew * phm1_t<PI>(s[k], p, pint) * inv[k] * inv[k] : 0.f;
+          wsum += w[k];
+        }
+      } else {
+        const float alpha = valid ? fast_rcp(e * e + eps) : 0.f;
+#pragma unroll
+        for (int k = 0; k < KT; ++k)
+          w[k] = (k < K) ? alpha * fast_rcp(ph_t<PI>(s[k], p, pint) * s[k] + eps) : 0.f;
+      }
+    }
+    // lane (cluster j, row rg) of the MFMA A operand
+    float w_mine = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) w_mine = (j == k) ? w[k] : w_mine;
+    s_acc += w_mine;
+    if (MODE != KHM_DIST) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2)
+          acc[4 * q + e2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_mine, x[q][e2], acc[4 * q + e2], 0, 0, 0);
+    }
+    if (MODE == KHM_FWD_BWD && dX) {
+      f32x4 dx[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dx[q] = x[q] * wsum;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        if (k < K) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 m = *reinterpret_cast<const f32x4*>(&Ms[k * D + 64 * q + 4 * j]);
+            dx[q] -= m * w[k];
+          }
+        }
+      }
+      if (valid) {
+        float* dp = dX + row * lddx + 4 * j;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          f32x4* d4 = reinterpret_cast<f32x4*>(dp + 64 * q);
+          if (accumulate_dx) *d4 = *d4 + dx[q];
+          else __builtin_nontemporal_store(dx[q], d4);
+        }
+      }
+    }
+  }
+  // ---- block combine in fixed wave order (deterministic), then one slab per workgroup
+  s_acc += __shfl_xor(s_acc, 16, 64);
+  s_acc += __shfl_xor(s_acc, 32, 64);
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  if (lane == 0) lred[wave] = lsum;
+  __syncthreads();  // everyone is done reading the centroids
+  for (int wv = 0; wv < KHM_FAST_WAVES; ++wv) {
+    if (wave == wv) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 4 * rg + r;  // cluster
+          if (m < KT) {
+            const int col = 64 * (c >> 2) + 4 * j + (c & 3);
+            float* d = &Ms[m * D + col];
+            *d = wv == 0 ? acc[c][r] : *d + acc[c][r];
+          }
+        }
+      if (lane < 16) Ssum[lane] = wv == 0 ? s_acc : Ssum[lane] + s_acc;
+    }
+    __syncthreads();
+  }
+  const int slab = K * D + K;
+  float* out = partial + (size_t)blockIdx.x * slab;
+  for (int i = threadIdx.x; i < K * D; i += KHM_FAST_THREADS) out[i] = Ms[i];
+  if (threadIdx.x < K) out[K * D + threadIdx.x] = Ssum[threadIdx.x];
+  if (threadIdx.x == 0 && loss_partial) {
+    double v = 0.0;
+    for (int wv = 0; wv < KHM_FAST_WAVES; ++wv) v += lred[wv];
+    loss_partial[blockIdx.x] = v;
+  }
+}
+
 // second stage.  MODE fwd_bwd: dM[k,:] (+)= (sum S_k) M[k,:] - sum T_k ; loss = sum partial
 //               offline  : num = sum T, den = sum S
 //               dist     : dist[k] = sum S_k / N
@@ -183,22 +382,38 @@ __global__ __launch_bounds__(256) void khm_reduce_kernel(const float* __restrict
                                                          const double* __restrict__ loss_partial,
                                                          double* __restrict__ loss_out,
                                                          int accumulate) {
+  // block = 16 outputs x 16 slab lanes; lanes are combined through LDS in lane order
+  __shared__ float redt[256], reds[256];
   const int slab = K * D + K;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
   if (MODE == KHM_DIST) {
-    if (i < K) {
-      float acc = 0.f;
-      for (int b = 0; b < nblk; ++b) acc += partial[(size_t)b * slab + K * D + i];
+    const int i = blockIdx.x * 16 + ol;
+    float acc = 0.f;
+    if (i < K)
+      for (int b = sl; b < nblk; b += 16) acc += partial[(size_t)b * slab + K * D + i];
+    reds[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0 && i < K) {
+      for (int q = 1; q < 16; ++q) acc += reds[q * 16 + ol];
       out0[i] = acc / (float)N;
     }
     return;
   }
-  if (i < K * D) {
-    const int k = i / D;
-    float t = 0.f, s = 0.f;
-    for (int b = 0; b < nblk; ++b) {
+  const int i = blockIdx.x * 16 + ol;
+  const int k = i < K * D ? i / D : 0;
+  float t = 0.f, s = 0.f;
+  if (i < K * D)
+    for (int b = sl; b < nblk; b += 16) {
       t += partial[(size_t)b * slab + i];
       s += partial[(size_t)b * slab + K * D + k];
+    }
+  redt[threadIdx.x] = t;
+  reds[threadIdx.x] = s;
+  __syncthreads();
+  if (sl == 0 && i < K * D) {
+    for (int q = 1; q < 16; ++q) {
+      t += redt[q * 16 + ol];
+      s += reds[q * 16 + ol];
     }
     if (MODE == KHM_FWD_BWD) {
       const float v = s * Mg[i] - t;
@@ -218,13 +433,20 @@ __global__ __launch_bounds__(256) void khm_reduce_kernel(const float* __restrict
 }
 
 static int khm_nw(int K) { return K <= 16 ? 4 : 1; }
-static int khm_grid(int N, int K) {
+static bool khm_fast(int D, int K, long ldx, long lddx) {
+  return D == 256 && K <= 16 && (ldx % 4) == 0 && (lddx % 4) == 0;
+}
+static int khm_grid(int N, int D, int K) {
+  if (D == 256 && K <= 16) {  // fast path: 16 rows per workgroup pass, persistent grid
+    int g = cdiv(N, 16);
+    return g < 1 ? 1 : (g > 768 ? 768 : g);
+  }
   int g = cdiv(N, khm_nw(K));
   const int cap = K <= 16 ? 1024 : 512;
   return g < 1 ? 1 : (g > cap ? cap : g);
 }
 size_t khm_workspace_floats(int N, int D, int K) {
-  const size_t g = (size_t)khm_grid(N, K);
+  const size_t g = (size_t)khm_grid(N, D, K);
   return g * ((size_t)K * D + K) + 2 * g + 16;
 }
 
@@ -271,7 +493,7 @@ static int khm_run(const float* X, long ldx, const float* M, int N, int D, int K
     return LSHM_ERR_UNSUPPORTED;
   }
   if (ws_floats < khm_workspace_floats(N, D, K)) { set_last_error("khm: workspace too small"); return LSHM_ERR_WORKSPACE; }
-  const int g = khm_grid(N, K);
+  const int g = khm_grid(N, D, K);
   const size_t slab = (size_t)K * D + K;
   const size_t shmem = (size_t)khm_nw(K) * slab * sizeof(float);
   if (shmem > 150 * 1024) { set_last_error("khm: K*latent_dim too large for LDS"); return LSHM_ERR_UNSUPPORTED; }
@@ -284,12 +506,29 @@ static int khm_run(const float* X, long ldx, const float* M, int N, int D, int K
   dim3 grid(g);
   int rc;
   const int nc = cdiv(D, 64);
-  if (nc <= 1) rc = khm_launch_kt<MODE, 1>(grid, shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
+  const bool aligned = ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dX)) & 15) == 0;
+  if (khm_fast(D, K, ldx, dX ? lddx : 0) && aligned) {
+#define KHM_FAST(KTV)                                                                              \
+  do {                                                                                             \
+    if (pint == 4)                                                                                 \
+      hipLaunchKernelGGL((khm256_kernel<MODE, KTV, 4>), grid, dim3(KHM_FAST_THREADS), 0, st, X, ldx, M, N, K, p, \
+                         pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);                     \
+    else                                                                                           \
+      hipLaunchKernelGGL((khm256_kernel<MODE, KTV, 0>), grid, dim3(KHM_FAST_THREADS), 0, st, X, ldx, M, N, K, p, \
+                         pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);                     \
+  } while (0)
+    if (K <= 4) KHM_FAST(4);
+    else if (K <= 8) KHM_FAST(8);
+    else if (K <= 12) KHM_FAST(12);
+    else KHM_FAST(16);
+#undef KHM_FAST
+    rc = check_launch("khm256");
+  } else if (nc <= 1) rc = khm_launch_kt<MODE, 1>(grid, shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
   else if (nc <= 2) rc = khm_launch_kt<MODE, 2>(grid, shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
   else if (nc <= 4) rc = khm_launch_kt<MODE, 4>(grid, shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
   else rc = khm_launch_kt<MODE, 8>(grid, shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
   if (rc) return rc;
-  hipLaunchKernelGGL((khm_reduce_kernel<MODE>), dim3(cdiv(K * D, 256)), dim3(256), 0, st, partial, g,
+  hipLaunchKernelGGL((khm_reduce_kernel<MODE>), dim3(cdiv(K * D, 16)), dim3(256), 0, st, partial, g,
                      M, N, D, K, out0, out1, lpart, loss_out, accumulate);
   return check_launch("khm_reduce");
 }

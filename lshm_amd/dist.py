@@ -1,0 +1,64 @@
+"""Data-parallel plumbing: one process per GPU, ``torch.distributed`` (backend ``nccl`` is RCCL on
+ROCm; ``gloo`` for the CPU rehearsal tests).
+
+Semantics: patches are sharded over ranks by whole baselines, parameters and
+optimiser state are replicated, every loss term of the closure is a batch mean, so each rank
+computes its *share* of the global loss / gradient (already divided by the global counts) and one
+SUM all-reduce of the flat gradient arena and one of the loss-term vector per closure give the
+global-batch result on every rank.  The upstream script has no distributed code at all.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None):
+    """Initialise the default process group from torchrun's environment (RANK, WORLD_SIZE,
+    LOCAL_RANK, MASTER_ADDR/PORT).  Returns (rank, world, local_rank, group-or-None)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1:
+        return rank, world, local, None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if not dist.is_initialized():
+        kw = {}
+        if backend == "nccl" and device is not None:
+            kw["device_id"] = device
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world, local, dist.group.WORLD
+
+
+def allreduce_closure(grads: torch.Tensor, terms: torch.Tensor, group=None) -> None:
+    """The two collectives of one closure: SUM over ranks of the flat gradient arena (which
+    includes dM of the K-harmonic term) and of the loss-term vector."""
+    if group is None and not dist.is_initialized():
+        return
+    dist.all_reduce(grads, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(terms, op=dist.ReduceOp.SUM, group=group)
+
+
+def allreduce_centroid_partials(num: torch.Tensor, den: torch.Tensor, group=None) -> torch.Tensor:
+    """Offline centroid update (Zhang's recursion): SUM the numerator (K,D) and denominator (K)
+    over ranks in one buffer, then M = num/den on every rank."""
+    K, D = num.shape
+    buf = torch.cat((num.reshape(-1), den.reshape(-1)))
+    if group is not None or dist.is_initialized():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[:K * D].view(K, D) / buf[K * D:, None]
+
+
+def shard_baselines(n_baselines: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [begin, end) range of whole baselines for this rank (groups of the
+    augmented loss never straddle ranks).  Requires an even split."""
+    if n_baselines % world:
+        raise ValueError(f"{n_baselines} baselines do not split evenly over {world} ranks")
+    per = n_baselines // world
+    return rank * per, (rank + 1) * per

@@ -203,9 +203,8 @@ class KHarmonicTrainer:
             self._h, P(self.params), P(self.grads), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]),
             P(self.y[2]), P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_forward_backward")
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, group=self.pg)
-            dist.all_reduce(self.terms, group=self.pg)
+            from .dist import allreduce_closure
+            allreduce_closure(self.grads, self.terms, self.pg)
         if self._mask is not None:
             self.grads.mul_(self._mask)
 

@@ -251,3 +251,28 @@ def test_augmented_loss_ragged_rows():
         ao.sum().backward()
         assert abs(a.item() - ao.item()) <= 3e-6 * abs(ao.item()) + 1e-9, (rows, bpb, bs)
         assert_close(Zg.grad, Zo.grad, 2e-4, 1e-7)
+
+
+def test_fft_features_vs_golden_and_known_answers():
+    Fh = _F()
+    g = load_golden("fft")
+    r, _ = O.closed_form_inputs(2, 4)
+    out = Fh.fft_features((r * 3.0).to(DEV))
+    assert out.shape == (2, 8, 128, 128)
+    assert_probe(g, "fft/out", out, 2e-5, 2e-5)
+    assert_close(out[:, :, 60:68, 60:68], g["fft/crop"], 2e-5, 2e-5)
+    assert rel_err(out, O.fft_features(r * 3.0)) < 2e-6
+    # delta at the origin -> flat spectrum 1/128 in the real plane, zero imaginary plane
+    d = torch.zeros(1, 1, 128, 128)
+    d[0, 0, 0, 0] = 1.0
+    o = Fh.fft_features(d.to(DEV)).cpu()
+    assert torch.allclose(o[0, 0], torch.full((128, 128), 1.0 / 128), atol=1e-7)
+    assert o[0, 1].abs().max() < 1e-7
+    # one plane wave exp(2 pi i (3 y + 5 x)/128) real part -> two shifted peaks of height 64 (clamped to 10)
+    yy, xx = torch.meshgrid(torch.arange(128.), torch.arange(128.), indexing="ij")
+    w = torch.cos(2 * np.pi * (3 * yy + 5 * xx) / 128)[None, None]
+    o = Fh.fft_features(w.to(DEV), clamp=100.0).cpu()
+    assert abs(o[0, 0, 64 + 3, 64 + 5].item() - 64.0) < 1e-3 and abs(o[0, 0, 64 - 3, 64 - 5].item() - 64.0) < 1e-3
+    o[0, 0, 64 + 3, 64 + 5] = 0
+    o[0, 0, 64 - 3, 64 - 5] = 0
+    assert o.abs().max() < 1e-3

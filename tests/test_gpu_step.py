@@ -121,3 +121,42 @@ def test_state_dict_roundtrip_with_modules():
     Mu, x1, x2, x3 = tr.encode(want_recon=True)
     xhat, mu = net(tr.x, tr.uv)
     assert rel_err(x1, xhat) < 1e-6 and rel_err(Mu[:, :224], mu) < 1e-6
+
+
+def test_world2_shares_sum_to_global():
+    """Engine configured for world=2 on each half of the batch: the two ranks' loss / gradient
+    shares sum to the world=1 result on the whole batch (what the RCCL all-reduce computes)."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    B, K, bpb = 8, 4, 2
+    ocfg = O.StepConfig(K=K, bpb=bpb, batch_size=B // bpb)
+    params, M = O.make_params(ocfg)
+    x, uv = O.closed_form_inputs(B, 4)
+    y = [0.01 * O.closed_form((x.numel(),), f"y{k}", 1.0, 0.123 + 0.1 * k) for k in range(3)]
+
+    def run(xs, uvs, ys, world, bs):
+        tr = KHarmonicTrainer(TrainConfig(Kc=K), batch=xs.shape[0], batch_per_bline=bpb, default_batch=bs,
+                              device=DEV)
+        tr._sc.world = world  # the engine scales shares by 1/world; no process group in this test
+        import ctypes as C
+        from lshm_amd import _lib as L
+        tr.lib.lshm_engine_destroy(tr._h)
+        h = C.c_void_p()
+        L.check(tr.lib.lshm_engine_create(C.byref(tr._sc), C.byref(h)))
+        tr._h = h
+        tr.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
+        tr.new_minibatch(xs.to(DEV), uvs.to(DEV))
+        for k in range(3):
+            tr.y[k].copy_(ys[k].to(DEV))
+        tr.closure_only()
+        return tr.grads.clone(), tr.terms[:9].clone()
+
+    g_all, t_all = run(x, uv, y, 1, B // bpb)
+    h = B // 2
+    parts = []
+    for r in range(2):
+        ys = [t.view(B, -1)[r * h:(r + 1) * h].reshape(-1) for t in y]
+        parts.append(run(x[r * h:(r + 1) * h], uv[r * h:(r + 1) * h], ys, 2, B // bpb // 2))
+    g_sum = parts[0][0] + parts[1][0]
+    t_sum = parts[0][1] + parts[1][1]
+    assert rel_err(g_sum, g_all) < 2e-5
+    np.testing.assert_allclose(t_sum.cpu().numpy(), t_all.cpu().numpy(), rtol=2e-6, atol=1e-10)
