@@ -1,0 +1,175 @@
+// Direct (LDS-patch) kernels for the bandwidth-heavy outer layers of the 2-D autoencoder
+// (src/lofar_models.py:31-33 conv0/conv1 and :56-57 tconv4/tconv5, plus the data gradients with
+// the same geometry).  The generic implicit GEMM re-gathers every input element once per tap and,
+// for the transposed conv, writes each output parity with stride-2 scalar stores; here
+//   * a workgroup stages the raw input patch of its tile in LDS once (coalesced, halo included),
+//   * MFMA A-fragments are read straight out of that patch (no im2col copy),
+//   * the transposed conv computes all four output parities at once: the GEMM N dimension is
+//     (parity_y, parity_x, channel), so the 16-wide fp32 MFMA tile is full even for 4 output
+//     channels, K runs over the 3x3 input neighbourhood (taps a parity does not use have zero weight),
+//   * results go through an LDS output tile and leave as full-row float4 stores, with bias, ELU and
+//     the ELU' multiply of the backward pass fused.
+// Arithmetic is v_mfma_f32_16x16x4_f32 (exact fp32).
+#include "kernels.h"
+
+namespace lshm {
+
+// ----------------------------------------------------------------------------------------------
+// transposed conv k4 s2 p1 forward == conv k4 s2 p1 data gradient, all parities per workgroup.
+//   big[b, co, 2m+py, 2n+px] = bias[co] + sum_{cs,dy,dx} small[b, cs, m+dy, n+dx] * w[cs, co, py-2dy+1, px-2dx+1]
+//   (dy in {py-1, py}, dx in {px-1, px})
+// Tile: TH small rows x TW small columns; 4 wavefronts, each (TH*TW/16)/4 m-tiles of 16 columns.
+// ----------------------------------------------------------------------------------------------
+template <int CS, int CB, int TH, int TW>
+__global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __restrict__ small, long s_bs,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias,
+                                                             float* __restrict__ big, long big_bs,
+                                                             const float* __restrict__ dact, int Hs, int Ws,
+                                                             int act, int ntiles) {
+  constexpr int K = CS * 9, KS = (K + 3) / 4;       // k-steps of 4
+  constexpr int N = 4 * CB, NT = (N + 15) / 16;     // n-tiles of 16
+  constexpr int PH = TH + 2, PW = TW + 2;           // input patch with halo
+  constexpr int MT = TH * TW / 16;                  // m-tiles per workgroup
+  constexpr int MW = MT / 4;                        // m-tiles per wave
+  constexpr int OW = 2 * TW;                        // output tile width
+  static_assert(MT % 4 == 0, "tile must give every wave the same number of m-tiles");
+  __shared__ float patch[CS * PH * PW];
+  __shared__ __attribute__((aligned(16))) float otile[CB * 2 * TH * OW];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lm = lane & 15, lk = lane >> 4;
+  // ---- B fragments: lane (kk = lk, n = lm) of step s, tile j holds W'[4s+kk][16j+lm]
+  float bf[KS][NT];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + lk;
+    const int cs = k / 9, r = k - cs * 9;
+    const int dy = r / 3 - 1, dx = r - (r / 3) * 3 - 1;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = 16 * j + lm;
+      const int py = n / (2 * CB), px = (n / CB) & 1, co = n % CB;
+      const int ky = py - 2 * dy + 1, kx = px - 2 * dx + 1;
+      const bool ok = k < K && n < N && (dy == py - 1 || dy == py) && (dx == px - 1 || dx == px);
+      bf[s][j] = ok ? w[(((long)cs * CB + co) * 4 + ky) * 4 + kx] : 0.f;
+    }
+  }
+  // persistent over tiles: the weight fragments above are loaded once per workgroup
+  const int tiles_x = Ws / TW, tiles_y = Hs / TH;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int b = tile / (tiles_x * tiles_y);
+  const int tr_ = tile - b * (tiles_x * tiles_y);
+  const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+  const float* sb = small + (long)b * s_bs;
+  __syncthreads();  // previous tile's output pass is done with the LDS buffers
+  // ---- stage the input patch (zero outside the image): interior as float4, halo columns as scalars
+  for (int i = t; i < CS * PH * (TW / 4); i += 256) {
+    const int rowi = i / (TW / 4), c4 = i - rowi * (TW / 4);
+    const int cs = rowi / PH, py = rowi - cs * PH;
+    const int iy = m0 + py - 1;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)Hs) v = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + iy) * Ws + n0 + 4 * c4);
+    float* d = &patch[rowi * PW + 1 + 4 * c4];
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+  for (int i = t; i < CS * PH * 2; i += 256) {
+    const int rowi = i >> 1, side = i & 1;
+    const int cs = rowi / PH, py = rowi - cs * PH;
+    const int iy = m0 + py - 1, ix = side ? n0 + TW : n0 - 1;
+    float v = 0.f;
+    if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) v = sb[((long)cs * Hs + iy) * Ws + ix];
+    patch[rowi * PW + (side ? PW - 1 : 0)] = v;
+  }
+  __syncthreads();
+
+  f32x4 acc[MW][NT];
+#pragma unroll
+  for (int i = 0; i < MW; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // m-tile index -> (row in tile, first column in tile)
+  constexpr int TPR = TW / 16;  // m-tiles per tile row
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 4 * s + lk;
+    const int cs = k / 9, r = k - cs * 9;
+    const int dyp = r / 3, dxp = r - dyp * 3;  // dy+1, dx+1
+    const int koff = (k < K) ? (cs * PH + dyp) * PW + dxp : 0;
+#pragma unroll
+    for (int i = 0; i < MW; ++i) {
+      const int mt = wave * MW + i;
+      const int row = mt / TPR, col = (mt - row * TPR) * 16;
+      const float a = (k < K) ? patch[koff + row * PW + col + lm] : 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s][j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // ---- accumulators -> LDS output tile [co][2*TH][2*TW] (bias + activation applied here)
+#pragma unroll
+  for (int i = 0; i < MW; ++i) {
+    const int mt = wave * MW + i;
+    const int row = mt / TPR, col = (mt - row * TPR) * 16 + 4 * lk;  // 4 consecutive small columns
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = 16 * j + lm;
+      if (n < N) {
+        const int py = n / (2 * CB), px = (n / CB) & 1, co = n % CB;
+        const float bv = bias ? bias[co] : 0.f;
+        float* o = &otile[(co * 2 * TH + 2 * row + py) * OW + 2 * col + px];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[i][j][r] + bv;
+          o[2 * r] = act ? elu(v) : v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- coalesced float4 stores (and the ELU' multiply for the backward use)
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  float* bb = big + (long)b * big_bs;
+  const float* db = dact ? dact + (long)b * big_bs : nullptr;
+  for (int i = t; i < CB * 2 * TH * OW / 4; i += 256) {
+    const int e = 4 * i;
+    const int co = e / (2 * TH * OW), r = e - co * (2 * TH * OW);
+    const int oy = r / OW, ox = r - oy * OW;
+    const long g = ((long)co * Hb + 2 * m0 + oy) * Wb + 2 * n0 + ox;
+    f32x4 v = *reinterpret_cast<const f32x4*>(&otile[e]);
+    if (db) {
+      const f32x4 sv = *reinterpret_cast<const f32x4*>(db + g);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] *= elu_grad_from_out(sv[q]);
+    }
+    *reinterpret_cast<f32x4*>(bb + g) = v;
+  }
+  }  // tile loop
+}
+
+bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws) {
+  if (Cs == 8 && Cb == 4) return Hs % 4 == 0 && Ws % 64 == 0;
+  if (Cs == 12 && Cb == 8) return Hs % 8 == 0 && Ws % 32 == 0;
+  return false;
+}
+
+int tconv2d_direct(const float* small, long s_bs, const float* w, const float* bias, float* big,
+                   long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
+                   hipStream_t st) {
+  if (Cs == 8 && Cb == 4) {
+    const int ntiles = (Ws / 64) * (Hs / 4) * B;
+    hipLaunchKernelGGL((tconv2d_direct_kernel<8, 4, 4, 64>), dim3(ntiles < 1280 ? ntiles : 1280), dim3(256), 0, st,
+                       small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+  } else if (Cs == 12 && Cb == 8) {
+    const int ntiles = (Ws / 32) * (Hs / 8) * B;
+    hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st,
+                       small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+  } else {
+    set_last_error("tconv2d_direct: unsupported shape");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  return check_launch("tconv2d_direct");
+}
+
+}  // namespace lshm

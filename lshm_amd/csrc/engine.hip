@@ -17,6 +17,7 @@
 #include "../../include/lshm.h"
 #include "kernels.h"
 
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -61,7 +62,23 @@ struct lshm_engine {
   AEPlan ae[3];
   // shared workspace offsets
   size_t o_scales, o_uvh, o_Mu, o_gMu, o_row, o_col, o_gx1p, o_gx2, o_gx3c, o_gT, o_gFc, o_gx1,
-      o_gA, o_gB, o_dcat1, o_dz1, o_dzmu, o_dcat3, o_dd0, o_part, o_scal, o_dMscratch;
+      o_scal, o_dMscratch;
+  // Two independent "lanes" of backward scratch so the netT and netF branches (independent given
+  // AE1's output) can run concurrently on two streams; each lane has a second split-K scratch for
+  // the weight-gradient kernels, which run beside the data-gradient chain on a side stream.
+  struct Lane {
+    size_t o_gA, o_gB, o_dcat1, o_dz1, o_dzmu, o_dcat3, o_dd0, o_part, o_wpart;
+    hipStream_t wstream;    // weight-gradient side stream
+  } lane[2];
+  hipStream_t fstream;      // netF branch
+  // every fork/join edge of one engine call uses its own event (a capture that re-records one
+  // event many times crashed hipStreamEndCapture on ROCm 7.2)
+  std::vector<hipEvent_t> events;
+  mutable size_t next_event;
+  hipEvent_t take_event() const { return events[next_event++ % events.size()]; }
+  bool streams_ok;
+  int wgrad_lanes;     // how many lanes fork their weight gradients (debug knob LSHM_STREAMS)
+  bool wgrad_streams;  // weight gradients on side streams (LSHM_STREAMS=1 keeps only the netT/netF fork)
   size_t part_floats;
   size_t ws_floats;
 };
@@ -157,7 +174,7 @@ static void plan_ae(lshm_engine* e, int idx, const char* prefix, int ndim, int L
 }
 
 static int ae_forward(const lshm_engine* e, int idx, const float* prm, const float* input,
-                      float* ws, hipStream_t st) {
+                      float* ws, int ln, hipStream_t st) {
   const AEPlan& a = e->ae[idx];
   const lshm_step_config& c = e->cfg;
   const int B = c.B, hd = e->hdim, L = a.L, D = e->D;
@@ -165,7 +182,7 @@ static int ae_forward(const lshm_engine* e, int idx, const float* prm, const flo
   float* cat1 = ws + a.cat1;
   float* Mu = ws + e->o_Mu + a.mu_col;
   float* cat3 = ws + a.cat3;
-  float* part = ws + e->o_part;
+  float* part = ws + e->lane[ln].o_part;
   const size_t pf = e->part_floats;
   int rc;
   const float* in = input;
@@ -196,35 +213,66 @@ static int ae_forward(const lshm_engine* e, int idx, const float* prm, const flo
 
 // dz_out: gradient w.r.t. the AE output (B,C,P*P); gMu (B,D) holds the gradient w.r.t. the latents.
 // dinput: gradient w.r.t. the AE input, or null.
+// fork the weight gradient of a conv layer onto the lane's side stream (it only needs dz and the
+// saved input, both complete on `st` at this point); the caller joins before dz's buffer is reused
+static int wgrad_beside(const lshm_engine* e, int ln, const ConvLayer& L, const float* xin, const float* dz,
+                        float* dw, float* db, float* ws, hipStream_t st, hipEvent_t* ev_w_out) {
+  const lshm_engine::Lane& la = e->lane[ln];
+  if (!e->streams_ok || !e->wgrad_streams || ln >= e->wgrad_lanes) {
+    *ev_w_out = nullptr;
+    return conv_layer_wgrad(L, xin, dz, dw, db, ws + la.o_wpart, e->part_floats, 0, st);
+  }
+  hipError_t he;
+  hipEvent_t ev_dz = e->take_event();
+  if ((he = hipEventRecord(ev_dz, st)) != hipSuccess || (he = hipStreamWaitEvent(la.wstream, ev_dz, 0)) != hipSuccess) {
+    set_last_error("engine: stream fork failed");
+    return (int)he;
+  }
+  int rc = conv_layer_wgrad(L, xin, dz, dw, db, ws + la.o_wpart, e->part_floats, 0, la.wstream);
+  if (rc) return rc;
+  *ev_w_out = e->take_event();
+  if ((he = hipEventRecord(*ev_w_out, la.wstream)) != hipSuccess) { set_last_error("engine: event record failed"); return (int)he; }
+  return LSHM_OK;
+}
+static int wgrad_join(const lshm_engine* e, hipEvent_t ev_w, hipStream_t st) {
+  if (!e->streams_ok || !ev_w) return LSHM_OK;
+  hipError_t he = hipStreamWaitEvent(st, ev_w, 0);
+  if (he != hipSuccess) { set_last_error("engine: stream join failed"); return (int)he; }
+  return LSHM_OK;
+}
+
 static int ae_backward(const lshm_engine* e, int idx, const float* prm, float* grd,
-                       const float* input, const float* dz_out, float* dinput, float* ws,
+                       const float* input, const float* dz_out, float* dinput, float* ws, int ln,
                        hipStream_t st) {
   const AEPlan& a = e->ae[idx];
   const lshm_step_config& c = e->cfg;
   const int B = c.B, hd = e->hdim, L = a.L, D = e->D;
   const float* uvh = ws + e->o_uvh;
-  float* gA = ws + e->o_gA;
-  float* gB = ws + e->o_gB;
-  float* part = ws + e->o_part;
+  const lshm_engine::Lane& la = e->lane[ln];
+  float* gA = ws + la.o_gA;
+  float* gB = ws + la.o_gB;
+  float* part = ws + la.o_part;
   const size_t pf = e->part_floats;
-  float* dd0 = ws + e->o_dd0;
-  float* dcat3 = ws + e->o_dcat3;
-  float* dzmu = ws + e->o_dzmu;
-  float* dz1 = ws + e->o_dz1;
-  float* dcat1 = ws + e->o_dcat1;
+  float* dd0 = ws + la.o_dd0;
+  float* dcat3 = ws + la.o_dcat3;
+  float* dzmu = ws + la.o_dzmu;
+  float* dz1 = ws + la.o_dz1;
+  float* dcat1 = ws + la.o_dcat1;
   const float* Mu = ws + e->o_Mu + a.mu_col;
   const float* gMu = ws + e->o_gMu + a.mu_col;
   const float* cat1 = ws + a.cat1;
   const float* cat3 = ws + a.cat3;
   int rc;
+  hipEvent_t ev_w = nullptr;
   // ---- decoder, last layer first
   const float* dz = dz_out;
   for (int i = 5; i >= 0; --i) {
     const float* xin = (i == 0) ? ws + a.d0 : ws + a.dact[i - 1];
-    if ((rc = conv_layer_wgrad(a.dec[i], xin, dz, grd + a.tw[i], grd + a.tb[i], part, pf, 0, st))) return rc;
+    if ((rc = wgrad_beside(e, ln, a.dec[i], xin, dz, grd + a.tw[i], grd + a.tb[i], ws, st, &ev_w))) return rc;
     float* dx = (i == 0) ? dd0 : ((i & 1) ? gA : gB);
     // previous activation is an ELU output (except fc3's output feeding tconv0)
     if ((rc = conv_layer_dgrad(a.dec[i], dz, prm + a.tw[i], dx, i == 0 ? nullptr : xin, part, pf, st))) return rc;
+    if ((rc = wgrad_join(e, ev_w, st))) return rc;
     dz = dx;
   }
   // ---- fc3 (no activation on its output): dd0 is its pre-activation gradient
@@ -256,10 +304,14 @@ static int ae_backward(const lshm_engine* e, int idx, const float* prm, float* g
   dz = dcat1;
   for (int i = 5; i >= 0; --i) {
     const float* xin = (i == 0) ? input : ws + a.act[i - 1];
-    if ((rc = conv_layer_wgrad(a.enc[i], xin, dz, grd + a.cw[i], grd + a.cb[i], part, pf, 0, st))) return rc;
-    if (i == 0 && !dinput) break;
+    if ((rc = wgrad_beside(e, ln, a.enc[i], xin, dz, grd + a.cw[i], grd + a.cb[i], ws, st, &ev_w))) return rc;
+    if (i == 0 && !dinput) {
+      if ((rc = wgrad_join(e, ev_w, st))) return rc;
+      break;
+    }
     float* dx = (i == 0) ? dinput : ((i & 1) ? gA : gB);
     if ((rc = conv_layer_dgrad(a.enc[i], dz, prm + a.cw[i], dx, i == 0 ? nullptr : xin, part, pf, st))) return rc;
+    if ((rc = wgrad_join(e, ev_w, st))) return rc;
     dz = dx;
   }
   return LSHM_OK;
@@ -287,10 +339,27 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   const lshm_step_config& c = e->cfg;
   int rc;
   if ((rc = uv_harmonics_host_scales(uv, c.scales, c.H, c.B, ws + e->o_uvh, st))) return rc;
-  if ((rc = ae_forward(e, 0, prm, x, ws, st))) return rc;
+  if ((rc = ae_forward(e, 0, prm, x, ws, 0, st))) return rc;
   if ((rc = residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st))) return rc;
-  if ((rc = ae_forward(e, 1, prm, ws + e->o_row, ws, st))) return rc;
-  if ((rc = ae_forward(e, 2, prm, ws + e->o_col, ws, st))) return rc;
+  // the two 1-D autoencoders are independent: run them side by side
+  hipStream_t fst = st;
+  if (e->streams_ok) {
+    fst = e->fstream;
+    hipEvent_t evf = e->take_event();
+    if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(fst, evf, 0) != hipSuccess) {
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
+  }
+  if ((rc = ae_forward(e, 1, prm, ws + e->o_row, ws, 0, st))) return rc;
+  if ((rc = ae_forward(e, 2, prm, ws + e->o_col, ws, 1, fst))) return rc;
+  if (e->streams_ok) {
+    hipEvent_t evj = e->take_event();
+    if (hipEventRecord(evj, fst) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
+      set_last_error("engine: stream join failed");
+      return LSHM_ERR_ARG;
+    }
+  }
   return LSHM_OK;
 }
 
@@ -311,7 +380,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   // reconstruction terms; the kernel's 1/n uses the local element count, rescale for world > 1 below
   if ((rc = recon_losses_fwd_bwd(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3,
                                  c.rho, planes, c.P, scal, ws + e->o_gx1p, ws + e->o_gx2,
-                                 ws + e->o_gx3c, ws + e->o_part, st))) return rc;
+                                 ws + e->o_gx3c, ws + e->lane[0].o_part, st))) return rc;
   if (world > 1 && grd) {
     const long n = (long)planes * c.P * c.P;
     const float s = (float)(1.0 / world);
@@ -322,7 +391,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   // latent-space terms: gMu = d/dMu (alpha*khm + gamma*aug + lambda*rica), dM = alpha*khm' + beta*sim'
   const double inv_count = 1.0 / (world * (double)B * c.K * D);
   if ((rc = khm_fwd_bwd(Mu, D, M, B, D, c.K, c.p, 1e-9f, inv_count, c.alpha, scal + 7, gMu, D, dM, 0,
-                        ws + e->o_part, e->part_floats, st))) return rc;
+                        ws + e->lane[0].o_part, e->part_floats, st))) return rc;
   if ((rc = cluster_sim_fwd_bwd(M, c.K, D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 1, st))) return rc;
   const int bs_global = (int)(c.batch_size * world);
   // augmented loss: local groups, global normalisation
@@ -345,10 +414,26 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   if ((rc = check_launch("finalize_terms"))) return rc;
   if (!grd) return LSHM_OK;
   // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
-  if ((rc = ae_backward(e, 1, prm, grd, ws + e->o_row, ws + e->o_gx2, ws + e->o_gT, ws, st))) return rc;
-  if ((rc = ae_backward(e, 2, prm, grd, ws + e->o_col, ws + e->o_gx3c, ws + e->o_gFc, ws, st))) return rc;
+  hipStream_t fst = st;
+  if (e->streams_ok) {
+    fst = e->fstream;
+    hipEvent_t evf = e->take_event();
+    if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(fst, evf, 0) != hipSuccess) {
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
+  }
+  if ((rc = ae_backward(e, 1, prm, grd, ws + e->o_row, ws + e->o_gx2, ws + e->o_gT, ws, 0, st))) return rc;
+  if ((rc = ae_backward(e, 2, prm, grd, ws + e->o_col, ws + e->o_gx3c, ws + e->o_gFc, ws, 1, fst))) return rc;
+  if (e->streams_ok) {
+    hipEvent_t evj = e->take_event();
+    if (hipEventRecord(evj, fst) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
+      set_last_error("engine: stream join failed");
+      return LSHM_ERR_ARG;
+    }
+  }
   if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st))) return rc;
-  if ((rc = ae_backward(e, 0, prm, grd, x, ws + e->o_gx1, nullptr, ws, st))) return rc;
+  if ((rc = ae_backward(e, 0, prm, grd, x, ws + e->o_gx1, nullptr, ws, 0, st))) return rc;
   return LSHM_OK;
 }
 
@@ -394,14 +479,17 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->o_gFc = take(cur, (size_t)B * img);
   e->o_gx1 = take(cur, (size_t)B * img);
   const size_t gmax = (size_t)B * 8 * (cfg->P / 2) * (cfg->P / 2);
-  e->o_gA = take(cur, gmax);
-  e->o_gB = take(cur, gmax);
   const int Lmax = cfg->L > cfg->Lt ? cfg->L : cfg->Lt;
-  e->o_dcat1 = take(cur, (size_t)B * (768 + e->hdim));
-  e->o_dz1 = take(cur, (size_t)B * Lmax);
-  e->o_dzmu = take(cur, (size_t)B * Lmax);
-  e->o_dcat3 = take(cur, (size_t)B * (Lmax + e->hdim));
-  e->o_dd0 = take(cur, (size_t)B * 768);
+  for (int ln = 0; ln < 2; ++ln) {
+    lshm_engine::Lane& la = e->lane[ln];
+    la.o_gA = take(cur, gmax);
+    la.o_gB = take(cur, gmax);
+    la.o_dcat1 = take(cur, (size_t)B * (768 + e->hdim));
+    la.o_dz1 = take(cur, (size_t)B * Lmax);
+    la.o_dzmu = take(cur, (size_t)B * Lmax);
+    la.o_dcat3 = take(cur, (size_t)B * (Lmax + e->hdim));
+    la.o_dd0 = take(cur, (size_t)B * 768);
+  }
   e->o_dMscratch = take(cur, (size_t)cfg->K * e->D);
   // split-K / reduction scratch: the largest consumer among wgrads, KHM and the recon partials
   size_t pf = khm_workspace_floats(B, e->D, cfg->K);
@@ -426,7 +514,32 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     if (w > pf) pf = w;
   }
   e->part_floats = pf;
-  e->o_part = take(cur, pf);
+  for (int ln = 0; ln < 2; ++ln) {
+    e->lane[ln].o_part = take(cur, pf);
+    e->lane[ln].o_wpart = take(cur, pf);
+  }
+  // side streams / events (host objects only; a machine without a HIP device - e.g. the build
+  // container - simply runs everything on the caller's stream)
+  e->streams_ok = false;
+  {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && !getenv("LSHM_SINGLE_STREAM")) {
+      bool ok = hipStreamCreateWithFlags(&e->fstream, hipStreamNonBlocking) == hipSuccess;
+      for (int ln = 0; ln < 2 && ok; ++ln)
+        ok = ok && hipStreamCreateWithFlags(&e->lane[ln].wstream, hipStreamNonBlocking) == hipSuccess;
+      e->events.resize(192);  // > fork/join edges of one forward+backward (2 per conv layer + 4)
+      for (size_t i = 0; i < e->events.size() && ok; ++i)
+        ok = ok && hipEventCreateWithFlags(&e->events[i], hipEventDisableTiming) == hipSuccess;
+      e->next_event = 0;
+      e->streams_ok = ok;
+      const char* lv = getenv("LSHM_STREAMS");
+      // weight gradients beside the data-gradient chain: measured no gain once netT/netF overlap, and
+      // nested forks crash hipStreamEndCapture on ROCm 7.2 -> off unless LSHM_STREAMS=2 (both lanes) / 3 (lane 0)
+      e->wgrad_streams = lv && (lv[0] == '2' || lv[0] == '3');
+      e->wgrad_lanes = (lv && lv[0] == '3') ? 1 : 2;
+    }
+    (void)hipGetLastError();
+  }
   const size_t ngroups = (size_t)(B + cfg->bpb - 1) / cfg->bpb;
   e->o_scal = take(cur, 2 * (16 + ngroups));
   e->ws_floats = cur;
@@ -434,7 +547,15 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   return LSHM_OK;
 }
 
-void lshm_engine_destroy(lshm_engine* e) { delete e; }
+void lshm_engine_destroy(lshm_engine* e) {
+  if (!e) return;
+  if (e->streams_ok) {
+    (void)hipStreamDestroy(e->fstream);
+    for (int ln = 0; ln < 2; ++ln) (void)hipStreamDestroy(e->lane[ln].wstream);
+    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+  }
+  delete e;
+}
 
 long lshm_engine_param_count(const lshm_engine* e) { return e ? e->nparams : 0; }
 
@@ -481,6 +602,7 @@ int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* gra
   ENGINE_CHECK(e && params && grads && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_backward: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
   return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st);
@@ -492,6 +614,7 @@ int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_loss: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
   return losses_and_backward(e, params, nullptr, x, y1, y2, y3, terms, ws, st);
@@ -503,6 +626,7 @@ int lshm_engine_multiplier_update(lshm_engine* e, const float* params, const flo
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
   const lshm_step_config& c = e->cfg;
@@ -515,6 +639,7 @@ int lshm_engine_encode(lshm_engine* e, const float* params, const float* x, cons
   ENGINE_CHECK(e && params && x && uv && ws, "engine_encode: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
   const lshm_step_config& c = e->cfg;

@@ -75,6 +75,12 @@ int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float
                  hipStream_t st);
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
 
+// ---- direct LDS-patch kernels for the outer 2-D layers (conv_direct.hip) ----
+bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws);
+int tconv2d_direct(const float* small, long s_bs, const float* w, const float* bias, float* big,
+                   long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
+                   hipStream_t st);
+
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
 struct ConvLayer {

@@ -79,6 +79,8 @@ int conv_layer_fwd(const ConvLayer& L, const float* x, const float* w, const flo
       return conv2d_fwd(p, ws, wsf, st);
     }
     case 1: {
+      if (tconv2d_direct_supported(L.Cin, L.Cout, L.Hin, L.Win))
+        return tconv2d_direct(x, L.in_bs, w, b, y, L.out_bs, nullptr, L.B, L.Cin, L.Cout, L.Hin, L.Win, act, st);
       Conv2dDgradParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout,
                           L.in_bs, L.out_bs, act, L.B * L.Hin * L.Win, L.Cout, L.Cin * 4, {}};
       return conv2d_dgrad(p, ws, wsf, st);
@@ -102,6 +104,8 @@ int conv_layer_dgrad(const ConvLayer& L, const float* dz, const float* w, float*
   conv_out_dims(L, Ho, Wo);
   switch (L.kind) {
     case 0: {  // dx (big) from dz (small)
+      if (tconv2d_direct_supported(L.Cout, L.Cin, Ho, Wo))
+        return tconv2d_direct(dz, L.out_bs, w, nullptr, dx, L.in_bs, dact_in, L.B, L.Cout, L.Cin, Ho, Wo, 0, st);
       Conv2dDgradParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Ho, Wo, L.Cin,
                           L.out_bs, L.in_bs, 0, L.B * Ho * Wo, L.Cin, L.Cout * 4, {}};
       return conv2d_dgrad(p, ws, wsf, st);
