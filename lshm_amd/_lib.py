@@ -12,7 +12,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblshm_hip.so")
+# LSHM_LIB lets a developer A/B two builds of the same C ABI in one process launch
+LIB_PATH = os.environ.get("LSHM_LIB") or os.path.join(_HERE, "lib", "liblshm_hip.so")
 
 _lib = None
 

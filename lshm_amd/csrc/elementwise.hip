@@ -152,30 +152,42 @@ int reduce_partials(const float* partial, float* out, long n, int S, int accumul
 // partial[s*C + c] = sum over images b in slice s, all HW positions, of dz[b*bs + c*HW + r]
 __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dz, long bs, int B,
                                                           int C, long HW, float* __restrict__ partial,
-                                                          int S) {
+                                                          int S, int accumulate) {
   __shared__ float red[16];
   const int c = blockIdx.x, s = blockIdx.y;
   const int b0 = (int)((long)B * s / S), b1 = (int)((long)B * (s + 1) / S);
   float acc = 0.f;
-  for (int b = b0; b < b1; ++b) {
-    const float* src = dz + (long)b * bs + (long)c * HW;
-    if ((HW & 3) == 0) {
-      const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
-      for (long r = threadIdx.x; r < (HW >> 2); r += blockDim.x) {
-        const f32x4 v = s4[r];
-        acc += (v[0] + v[1]) + (v[2] + v[3]);
-      }
-    } else {
-      for (long r = threadIdx.x; r < HW; r += blockDim.x) acc += src[r];
+  // one flat index over (image, position) so small feature maps still use every lane
+  if ((HW & 3) == 0) {
+    const long hw4 = HW >> 2, n4 = (long)(b1 - b0) * hw4;
+    for (long i = threadIdx.x; i < n4; i += blockDim.x) {
+      const long bi = i / hw4, r = i - bi * hw4;
+      const f32x4 v = reinterpret_cast<const f32x4*>(dz + (b0 + bi) * bs + (long)c * HW)[r];
+      acc += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+  } else {
+    const long n = (long)(b1 - b0) * HW;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) {
+      const long bi = i / HW, r = i - bi * HW;
+      acc += dz[(b0 + bi) * bs + (long)c * HW + r];
     }
   }
   const float tot = block_sum<float>(acc, red);
-  if (threadIdx.x == 0) partial[(long)s * C + c] = tot;
+  if (threadIdx.x == 0) {
+    float* d = partial + (long)s * C + c;
+    *d = accumulate ? *d + tot : tot;
+  }
 }
 int channel_sum_partials(const float* dz, long bs, int B, int C, long HW, float* partial, int S,
                          hipStream_t st) {
   hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(HW >= 1024 ? 256 : 64), 0, st, dz, bs, B,
-                     C, HW, partial, S);
+                     C, HW, partial, S, 0);
+  return check_launch("channel_sum");
+}
+// single-pass variant for small tensors: db[c] (=|+=) sum_{b,r} dz[b,c,r], one workgroup per channel
+int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* db, int accumulate,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, 1), dim3(256), 0, st, dz, bs, B, C, HW, db, 1, accumulate);
   return check_launch("channel_sum");
 }
 
@@ -235,15 +247,14 @@ __global__ __launch_bounds__(256) void recon_kernel(
     __syncthreads();
   }
 }
-__global__ __launch_bounds__(256) void sum7_kernel(const double* __restrict__ partials, long nblk,
-                                                   double* __restrict__ sums7) {
+__global__ __launch_bounds__(1024) void sum7_kernel(const double* __restrict__ partials, long nblk,
+                                                    double* __restrict__ sums7) {
   __shared__ double red[16];
-  for (int q = 0; q < 7; ++q) {
-    double acc = 0.0;
-    for (long i = threadIdx.x; i < nblk; i += blockDim.x) acc += partials[i * 7 + q];
-    const double tot = block_sum<double>(acc, red);
-    if (threadIdx.x == 0) sums7[q] = tot;
-  }
+  const int q = blockIdx.x;  // one workgroup per reduced quantity
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < nblk; i += blockDim.x) acc += partials[i * 7 + q];
+  const double tot = block_sum<double>(acc, red);
+  if (threadIdx.x == 0) sums7[q] = tot;
 }
 size_t recon_partials_floats(int planes, int P) {
   return (size_t)planes * (P / TILE) * (P / TILE) * 7 * 2;
@@ -260,7 +271,7 @@ int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const
                      (float)(1.0 / n), P, part, gx1p, gx2, gx3c);
   int rc = check_launch("recon_losses");
   if (rc) return rc;
-  hipLaunchKernelGGL(sum7_kernel, dim3(1), dim3(256), 0, st, part,
+  hipLaunchKernelGGL(sum7_kernel, dim3(7), dim3(1024), 0, st, part,
                      (long)grid.x * grid.y * grid.z, sums7);
   return check_launch("recon_sum7");
 }
@@ -417,6 +428,37 @@ __global__ __launch_bounds__(1024) void logcosh_kernel(const float* __restrict__
   const double tot = block_sum<double>(acc, red);
   if (threadIdx.x == 0 && loss) loss[0] = tot * (double)scale;
 }
+// All three RICA penalties of the closure in one launch: Mu = [mu | muT | muF] (rows x (c0+c1+c2)),
+// per-segment scale; per-workgroup partial sums [grid][3] are combined by the caller's finalize kernel.
+struct Seg3 { int end[3]; float scale[3]; };
+__global__ __launch_bounds__(256) void logcosh3_kernel(const float* __restrict__ z, long ldz, int rows, int cols,
+                                                       Seg3 sg, double* __restrict__ partial,
+                                                       float* __restrict__ dz, long lddz) {
+  __shared__ double red[16];
+  double acc[3] = {0.0, 0.0, 0.0};
+  const long n = (long)rows * cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+    const int seg = c < sg.end[0] ? 0 : (c < sg.end[1] ? 1 : 2);
+    const float v = z[(long)r * ldz + c];
+    const float a = fabsf(v);
+    acc[seg] += (double)(a + log1pf(expf(-2.f * a)) - 0.69314718056f);
+    dz[(long)r * lddz + c] += sg.scale[seg] * tanhf(v);
+  }
+  for (int q = 0; q < 3; ++q) {
+    const double tot = block_sum<double>(acc[q], red);
+    if (threadIdx.x == 0) partial[blockIdx.x * 3 + q] = tot * (double)sg.scale[q];
+  }
+}
+int logcosh3_fwd_bwd(const float* z, long ldz, int rows, const int* seg_cols, const float* seg_scale,
+                     double* partial, int nblocks, float* dz, long lddz, hipStream_t st) {
+  Seg3 sg;
+  int e = 0;
+  for (int i = 0; i < 3; ++i) { e += seg_cols[i]; sg.end[i] = e; sg.scale[i] = seg_scale[i]; }
+  hipLaunchKernelGGL(logcosh3_kernel, dim3(nblocks), dim3(256), 0, st, z, ldz, rows, e, sg, partial, dz, lddz);
+  return check_launch("logcosh3");
+}
+
 int logcosh_mean_fwd_bwd(const float* z, long ldz, int rows, int cols, float scale, double* loss,
                          float* dz, long lddz, int accumulate, hipStream_t st) {
   hipLaunchKernelGGL(logcosh_kernel, dim3(1), dim3(1024), 0, st, z, ldz, rows, cols, scale, loss, dz,

@@ -319,15 +319,18 @@ static int ae_backward(const lshm_engine* e, int idx, const float* prm, float* g
 
 // scal layout (doubles): [0..6] sums7, [7] khm sum, [8] sim, [9..11] rica x3, [12] aug, [13..] aug partials
 __global__ void finalize_terms_kernel(const double* __restrict__ scal, double* __restrict__ terms,
-                                      double n_global, double rho, double khm_scale, int rica) {
+                                      double n_global, double rho, double khm_scale, int rica,
+                                      const double* __restrict__ rica_part, int nrica) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double rsum = 0.0;
+  if (rica) for (int i = 0; i < nrica; ++i) rsum += rica_part[i];
   const double l0 = scal[0] / n_global;
   const double l1 = (scal[1] + 0.5 * rho * scal[2]) / n_global;
   const double l2 = (scal[3] + 0.5 * rho * scal[4]) / n_global;
   const double l3 = (scal[5] + 0.5 * rho * scal[6]) / n_global;
   const double kd = scal[7] * khm_scale;
   const double sim = scal[8];
-  const double rc = rica ? scal[9] + scal[10] + scal[11] : 0.0;
+  const double rc = rica ? rsum : 0.0;
   const double aug = scal[12];
   terms[0] = l0; terms[1] = l1; terms[2] = l2; terms[3] = l3;
   terms[4] = kd; terms[5] = aug; terms[6] = sim; terms[7] = rc;
@@ -402,15 +405,19 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     // but only the local rows take part
     if ((rc = aug_loss_fwd_bwd(Mu, D, used, D, c.bpb, bs_global, coef_scale, scal + 12, gMu, D, 1, st))) return rc;
   }
+  double* rica_part = scal + 16 + (B + c.bpb - 1) / c.bpb;  // [LOGCOSH3_BLOCKS][3]
   if (c.rica) {
     const AEPlan* a = e->ae;
+    int cols[3];
+    float sc3[3];
     for (int i = 0; i < 3; ++i) {
-      const float s = (float)(c.rica_lambda / (world * (double)B * a[i].L));
-      if ((rc = logcosh_mean_fwd_bwd(Mu + a[i].mu_col, D, B, a[i].L, s, scal + 9 + i, gMu + a[i].mu_col, D, 1, st))) return rc;
+      cols[i] = a[i].L;
+      sc3[i] = (float)(c.rica_lambda / (world * (double)B * a[i].L));
     }
+    if ((rc = logcosh3_fwd_bwd(Mu, D, B, cols, sc3, rica_part, LOGCOSH3_BLOCKS, gMu, D, st))) return rc;
   }
   hipLaunchKernelGGL(finalize_terms_kernel, dim3(1), dim3(64), 0, st, scal, terms, n_global, (double)c.rho,
-                     (double)c.alpha * inv_count, c.rica);
+                     (double)c.alpha * inv_count, c.rica, rica_part, LOGCOSH3_BLOCKS * 3);
   if ((rc = check_launch("finalize_terms"))) return rc;
   if (!grd) return LSHM_OK;
   // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
@@ -541,7 +548,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     (void)hipGetLastError();
   }
   const size_t ngroups = (size_t)(B + cfg->bpb - 1) / cfg->bpb;
-  e->o_scal = take(cur, 2 * (16 + ngroups));
+  e->o_scal = take(cur, 2 * (16 + ngroups + 3 * LOGCOSH3_BLOCKS));
   e->ws_floats = cur;
   *out = e;
   return LSHM_OK;

@@ -128,6 +128,11 @@ int reduce_partials(const float* partial, float* out, long n, int S, int accumul
                     hipStream_t st);
 int channel_sum_partials(const float* dz, long bs, int B, int C, long HW, float* partial, int S,
                          hipStream_t st);
+int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* db, int accumulate,
+                       hipStream_t st);
+#define LOGCOSH3_BLOCKS 32
+int logcosh3_fwd_bwd(const float* z, long ldz, int rows, const int* seg_cols, const float* seg_scale,
+                     double* partial, int nblocks, float* dz, long lddz, hipStream_t st);
 // the seven reductions + gradients of src/kharmonic_lofar.py:150-158 (see elementwise.hip)
 int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
                          const float* y1, const float* y2, const float* y3, float rho, int planes,

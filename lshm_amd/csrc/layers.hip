@@ -159,6 +159,8 @@ int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float*
     rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st);
   }
   if (rc || !db) return rc;
+  if ((long)L.B * Ho * Wo <= 65536)  // small tensor: one workgroup per channel, no second stage
+    return channel_sum_direct(dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, db, accumulate, st);
   const int Sb = bias_slices(L);
   rc = channel_sum_partials(dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, bias_ws, Sb, st);
   if (rc) return rc;
