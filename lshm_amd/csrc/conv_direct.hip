@@ -173,3 +173,131 @@ int tconv2d_direct(const float* small, long s_bs, const float* w, const float* b
 }
 
 }  // namespace lshm
+
+namespace lshm {
+
+// ----------------------------------------------------------------------------------------------
+// conv k4 s2 p1 weight gradient for the outer layers (also the transposed conv's, with the roles
+// of the tensors swapped):   dW[cs, cb, ky, kx] = sum_{b,oy,ox} small[b,cs,oy,ox] big[b,cb,2oy-1+ky,2ox-1+kx]
+// GEMM view: M = Cs (<= 16), N = Cb*16 (one 16-wide MFMA tile per big channel), K = all positions.
+// A workgroup walks tiles of TH x TW small positions: the small tile and the matching big patch
+// are staged once in LDS, each wavefront takes every 4th group of 4 positions (K split over the
+// waves), fragments are read straight from the patch.  Accumulators stay in registers across all
+// tiles of the (persistent) workgroup; one slab per workgroup is combined by reduce_partials.
+// ----------------------------------------------------------------------------------------------
+template <int CS, int CB, int TH, int TW>
+__global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* __restrict__ small, long s_bs,
+                                                                  const float* __restrict__ big, long big_bs,
+                                                                  float* __restrict__ partial, int Hs, int Ws,
+                                                                  int ntiles) {
+  constexpr int TP = TH * TW;             // positions per tile
+  constexpr int LDS_S = TP + 2;           // small-tile row stride: == 2 (mod 32) -> conflict-free A reads
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
+  constexpr int NT = CB;                  // one n-tile (16 taps) per big channel
+  __shared__ float stile[16 * LDS_S];
+  __shared__ float patch[CB * PH * PW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lm = lane & 15, lk = lane >> 4;
+  for (int i = t; i < 16 * LDS_S; i += 256) stile[i] = 0.f;  // rows >= CS stay zero
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_x = Ws / TW, tiles_y = Hs / TH;
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  const int ky = lm >> 2, kx = lm & 3;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    const float* sb = small + (long)b * s_bs;
+    const float* bb = big + (long)b * big_bs;
+    __syncthreads();
+    // small tile: [cs][TH*TW] as float4 rows of TW
+    for (int i = t; i < CS * TH * (TW / 4); i += 256) {
+      const int c4 = i % (TW / 4), rr = i / (TW / 4);
+      const int row = rr % TH, cs = rr / TH;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + m0 + row) * Ws + n0 + 4 * c4);
+      float* d = &stile[cs * LDS_S + row * TW + 4 * c4];
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    // big patch: rows 2*m0-1 .. 2*m0+2*TH, cols 2*n0-1 .. 2*n0+2*TW (zero outside the image)
+    for (int i = t; i < CB * PH * (2 * TW / 4); i += 256) {
+      const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+      const int prow = rr % PH, cb = rr / PH;
+      const int iy = 2 * m0 - 1 + prow;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)iy < (unsigned)Hb) v = *reinterpret_cast<const f32x4*>(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
+      float* d = &patch[(cb * PH + prow) * PW + 1 + 4 * c4];
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    for (int i = t; i < CB * PH * 2; i += 256) {
+      const int side = i & 1, rr = i >> 1;
+      const int prow = rr % PH, cb = rr / PH;
+      const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb) v = bb[((long)cb * Hb + iy) * Wb + ix];
+      patch[(cb * PH + prow) * PW + (side ? PW - 1 : 0)] = v;
+    }
+    __syncthreads();
+    // K loop: groups of 4 consecutive positions, every 4th group per wave
+#pragma unroll 4
+    for (int s = wave; s < TP / 4; s += 4) {
+      const int p = 4 * s + lk;
+      const int oy = p / TW, ox = p - oy * TW;
+      const float a = stile[lm * LDS_S + p];
+      const int boff = (2 * oy + ky) * PW + 2 * ox + kx;
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, patch[j * PH * PW + boff], acc[j], 0, 0, 0);
+    }
+  }
+  // ---- combine the 4 waves (fixed order) and write this workgroup's slab [CS][CB*16]
+  __syncthreads();
+  // the patch is dead now: reuse it as the 4 x 16 x (N+1) combine buffer
+  static_assert(CB * PH * PW >= 4 * 16 * (CB * 16 + 1), "combine buffer must fit in the patch");
+  float (*comb)[16][CB * 16 + 1] = reinterpret_cast<float (*)[16][CB * 16 + 1]>(patch);
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) comb[wave][4 * lk + r][16 * j + lm] = acc[j][r];
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * CS * CB * 16;
+  for (int i = t; i < CS * CB * 16; i += 256) {
+    const int m = i / (CB * 16), n = i - m * (CB * 16);
+    out[i] = (comb[0][m][n] + comb[1][m][n]) + (comb[2][m][n] + comb[3][m][n]);
+  }
+}
+
+bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws) {
+  if (Cs == 8 && Cb == 4) return Hs % 4 == 0 && Ws % 64 == 0;
+  if (Cs == 12 && Cb == 8) return Hs % 8 == 0 && Ws % 32 == 0;
+  return false;
+}
+size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)768 * Cs * Cb * 16; }
+
+int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, int B, int Cs,
+                        int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st) {
+  if (wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv2d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  int grid;
+  if (Cs == 8 && Cb == 4) {
+    const int ntiles = (Ws / 64) * (Hs / 4) * B;
+    grid = ntiles < 768 ? ntiles : 768;
+    hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<8, 4, 4, 64>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
+                       big_bs, ws, Hs, Ws, ntiles);
+  } else if (Cs == 12 && Cb == 8) {
+    const int ntiles = (Ws / 32) * (Hs / 8) * B;
+    grid = ntiles < 512 ? ntiles : 512;
+    hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<12, 8, 8, 32>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
+                       big_bs, ws, Hs, Ws, ntiles);
+  } else {
+    set_last_error("conv2d_wgrad_direct: unsupported shape");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  int rc = check_launch("conv2d_wgrad_direct");
+  if (rc) return rc;
+  return reduce_partials(ws, dw, (long)Cs * Cb * 16, grid, accumulate, st);
+}
+
+}  // namespace lshm

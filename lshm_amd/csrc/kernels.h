@@ -81,6 +81,11 @@ int tconv2d_direct(const float* small, long s_bs, const float* w, const float* b
                    long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
                    hipStream_t st);
 
+bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws);
+size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb);
+int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, int B, int Cs,
+                        int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st);
+
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
 struct ConvLayer {

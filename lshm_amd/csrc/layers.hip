@@ -65,6 +65,10 @@ size_t conv_workspace_floats(const ConvLayer& L) {
   const size_t c = igemm_workspace_floats(w.M, w.N, w.K, w.Z);
   if (b > a) a = b;
   if (c > a) a = c;
+  if (L.kind < 2) {
+    const size_t d2 = conv2d_wgrad_direct_workspace_floats(w.M, w.N / 16);
+    if (d2 > a) a = d2;
+  }
   return a + BIAS_WS_FLOATS + 16;
 }
 
@@ -150,6 +154,10 @@ int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float*
   int rc;
   if (L.kind < 2) {
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
+    if (conv2d_wgrad_direct_supported(Cs, Cb, Hs, Ws) && gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
+      rc = conv2d_wgrad_direct(small, s_bs, big, big_bs, dw, L.B, Cs, Cb, Hs, Ws, gemm_ws, gemm_wsf, accumulate, st);
+      goto bias;
+    }
     Conv2dWgradParams p{small, big, dw, L.B, Cs, Hs, Ws, Cb, s_bs, big_bs, g.M, g.N, g.K, accumulate, {}};
     rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st);
   } else {
@@ -158,6 +166,7 @@ int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float*
                         g.M, g.N, g.K, accumulate, {}};
     rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st);
   }
+bias:
   if (rc || !db) return rc;
   if ((long)L.B * Ho * Wo <= 65536)  // small tensor: one workgroup per channel, no second stage
     return channel_sum_direct(dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, db, accumulate, st);
