@@ -143,6 +143,8 @@ int lshm_scale_flat(float* x, float alpha, long n, lshm_stream_t stream);
 /* out[0] = a.b (double); workspace >= 512 floats */
 int lshm_dot_flat(const float* a, const float* b, long n, double* out, float* workspace,
                   lshm_stream_t stream);
+/* out[0] = sum |a_i| (double); workspace >= 512 floats          src/lbfgsnew.py:531 (flat_grad.abs().sum()) */
+int lshm_asum_flat(const float* a, long n, double* out, float* workspace, lshm_stream_t stream);
 
 /* ---- FFT feature step: fftn(dims 2,3, ortho) -> fftshift -> cat(Re,Im) -> clamp
  *      Demo.ipynb:169-175, src/lofar_tools.py:24-30.  x (B,C,128,128) -> out (B,2C,128,128) */

@@ -203,6 +203,11 @@ int lshm_dot_flat(const float* a, const float* b, long n, double* out, float* ws
   return dot_flat(a, b, n, out, ws, ST(s));
 }
 
+int lshm_asum_flat(const float* a, long n, double* out, float* ws, lshm_stream_t s) {
+  REQUIRE(a && out && ws && n >= 0, "asum: bad argument");
+  return asum_flat(a, n, out, ws, ST(s));
+}
+
 int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv, lshm_stream_t s) {
   REQUIRE(x && out && B > 0 && C > 0, "fft2: bad argument");
   return fft2_ortho_shift_cat_clamp(x, out, B, C, clampv, ST(s));

@@ -394,6 +394,23 @@ __global__ __launch_bounds__(256) void dot_stage2(const double* __restrict__ par
   const double tot = block_sum<double>(acc, red);
   if (threadIdx.x == 0) out[0] = tot;
 }
+__global__ void dot_stage2(const double* __restrict__ part, int nb, double* __restrict__ out);
+__global__ __launch_bounds__(256) void asum_stage1(const float* __restrict__ a, long n, double* __restrict__ part) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    acc += (double)fabsf(a[i]);
+  const double tot = block_sum<double>(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+int asum_flat(const float* a, long n, double* out, float* ws, hipStream_t st) {
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(asum_stage1, dim3(DOT_BLOCKS), dim3(256), 0, st, a, n, part);
+  int rc = check_launch("asum1");
+  if (rc) return rc;
+  hipLaunchKernelGGL(dot_stage2, dim3(1), dim3(256), 0, st, part, DOT_BLOCKS, out);
+  return check_launch("asum2");
+}
 int dot_flat(const float* a, const float* b, long n, double* out, float* ws, hipStream_t st) {
   double* part = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(dot_stage1, dim3(DOT_BLOCKS), dim3(256), 0, st, a, b, n, part);

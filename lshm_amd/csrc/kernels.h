@@ -155,6 +155,7 @@ int adam_step_flat(float* p, const float* g, float* m, float* v, long n, float l
 int axpy_flat(float* y, const float* x, float alpha, long n, hipStream_t st);
 int dot_flat(const float* a, const float* b, long n, double* out, float* ws, hipStream_t st);
 int scale_flat(float* x, float alpha, long n, hipStream_t st);
+int asum_flat(const float* a, long n, double* out, float* ws, hipStream_t st);
 int logcosh_mean_fwd_bwd(const float* z, long ldz, int rows, int cols, float scale, double* loss,
                          float* dz, long lddz, int accumulate, hipStream_t st);
 

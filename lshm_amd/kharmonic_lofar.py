@@ -250,6 +250,38 @@ class KHarmonicTrainer:
         else:
             self._step_impl()
 
+    # ------------------------------------------------------------------ LBFGS (src/kharmonic_lofar.py:93)
+    def make_lbfgs(self, history_size=7, max_iter=4, line_search_fn=True, batch_mode=True, **kw):
+        """LBFGSNew over the flat arena (defaults = the commented-out line 93 of the upstream script).
+        The arena is exposed as ONE parameter whose .grad is the engine's gradient buffer."""
+        from .lbfgsnew import LBFGSNew
+        self._flat_param = torch.nn.Parameter(self.params, requires_grad=True)
+        self._flat_param.grad = self.grads
+        return LBFGSNew([self._flat_param], history_size=history_size, max_iter=max_iter,
+                        line_search_fn=line_search_fn, batch_mode=batch_mode, **kw)
+
+    def lbfgs_closure(self):
+        """Closure protocol of the upstream script (:132-182): gradients only when autograd is enabled
+        (LBFGSNew disables it inside the line search); returns the (all-reduced) total loss."""
+        if torch.is_grad_enabled():
+            self._closure_fwd_bwd()
+        else:
+            P = L.ptr
+            L.check(self.lib.lshm_engine_forward_loss(
+                self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+                P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_forward_loss")
+            if self.world > 1:
+                import torch.distributed as dist
+                dist.all_reduce(self.terms, group=self.pg)
+        return self.terms[8]
+
+    def step_lbfgs(self, opt):
+        """One ADMM iteration with the LBFGS update instead of Adam."""
+        if self._flat_param.grad is not self.grads:
+            self._flat_param.grad = self.grads
+        opt.step(self.lbfgs_closure)
+        self._multipliers()
+
     def closure_only(self):
         """Closure forward + backward without the update (gradients in ``self.grads``)."""
         self._closure_fwd_bwd()

@@ -272,6 +272,27 @@ def main():
             a1, h, a2, a3, *_ = three(x)
             ys = [ys[0] + cfg.rho * (x - a1).view(-1), ys[1] + cfg.rho * (h - a2).view(-1),
                   ys[2] + cfg.rho * (h - a3).reshape(-1)]
+    # ---------------- (5) LBFGSNew trajectories on a small deterministic regression problem ---
+    import lbfgsnew as ref_lbfgs
+    from tests.lbfgs_problem import make_problem
+    gl = {}
+    for mode, kw in (("batch", dict(history_size=7, max_iter=4, line_search_fn=True, batch_mode=True)),
+                     ("full", dict(history_size=7, max_iter=6, line_search_fn=True, batch_mode=False)),
+                     ("fixed", dict(history_size=5, max_iter=3, line_search_fn=False, batch_mode=False, lr=0.05))):
+        params, closure_for = make_problem()
+        opt = ref_lbfgs.LBFGSNew(params, **kw)
+        losses, ts = [], []
+        for it in range(4):
+            closure = closure_for(opt, it if mode == "batch" else 0)
+            l0 = opt.step(closure)
+            losses.append(float(l0))
+            ts.append(float(opt.state[opt._params[0]]["t"]))
+        gl[f"{mode}/loss"] = np.array(losses)
+        gl[f"{mode}/t"] = np.array(ts)
+        gl[f"{mode}/final"] = torch.cat([p.detach().reshape(-1) for p in params]).numpy()
+        gl[f"{mode}/func_evals"] = np.int64(opt.state[opt._params[0]]["func_evals"])
+    np.savez_compressed(os.path.join(HERE, "lbfgs.npz"), **gl)
+
     g["terms"] = np.array(log)
     for nm, p_ in zip(names, plist):
         g[f"final/pnorm/{nm}"] = p_.detach().double().norm().item()

@@ -160,3 +160,49 @@ def test_world2_shares_sum_to_global():
     t_sum = parts[0][1] + parts[1][1]
     assert rel_err(g_sum, g_all) < 2e-5
     np.testing.assert_allclose(t_sum.cpu().numpy(), t_all.cpu().numpy(), rtol=2e-6, atol=1e-10)
+
+
+def test_lbfgs_step_matches_oracle_driven_lbfgs():
+    """Engine closures + LBFGSNew on the flat arena vs the same optimiser driven by the CPU oracle."""
+    from lshm_amd.lbfgsnew import LBFGSNew
+    tr, ocfg, params, M, x, uv = _trainer(4, 4, 2, 2)
+    opt = tr.make_lbfgs(history_size=7, max_iter=2, line_search_fn=True, batch_mode=True)
+    tr.step_lbfgs(opt)
+    t_gpu = tr.read_terms()
+    # oracle side: same optimiser class over the oracle's leaves (fp32 CPU)
+    leaves = O.flat_leaves(params, M)
+    for l in leaves:
+        l.requires_grad_(True)
+    y = [torch.zeros(x.numel()) for _ in range(3)]
+    oopt = LBFGSNew(leaves, history_size=7, max_iter=2, line_search_fn=True, batch_mode=True)
+
+    def closure():
+        if torch.is_grad_enabled():
+            oopt.zero_grad()
+        total, _ = O.closure_losses(params, M, x, uv, y, ocfg)
+        if total.requires_grad:
+            total.backward()
+        return total
+    oopt.step(closure)
+    names = [f"{g}.{k}" for g in O.GROUPS for k in params[g]] + ["mod.M"]
+    for n, l in zip(names, leaves):
+        assert rel_err(tr.view(n), l.detach()) < 5e-4, n
+    y_new = O.multiplier_update(params, x, uv, y, ocfg)
+    for k in range(3):
+        assert rel_err(tr.y[k], y_new[k]) < 2e-3
+
+
+def test_step_with_k64_clusters():
+    """Config 5's K=64 (generic KHM path, one wave per row)."""
+    tr, ocfg, params, M, x, uv = _trainer(4, 64, 2, 2)
+    tr.closure_only()
+    leaves = O.flat_leaves(params, M)
+    for l in leaves:
+        l.requires_grad_(True)
+    y = [torch.zeros(x.numel()) for _ in range(3)]
+    total, terms = O.closure_losses(params, M, x, uv, y, ocfg)
+    grads = torch.autograd.grad(total, leaves)
+    t = tr.read_terms()
+    assert abs(t["total"] - total.item()) <= 1e-4 * abs(total.item())
+    assert abs(t["kdist"] - terms[4].item()) <= 1e-4 * abs(terms[4].item())
+    assert rel_err(tr.view("mod.M", tr.grads), grads[-1]) < 2e-4
