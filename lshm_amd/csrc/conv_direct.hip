@@ -301,3 +301,121 @@ int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
 }
 
 }  // namespace lshm
+
+namespace lshm {
+
+// ----------------------------------------------------------------------------------------------
+// conv k4 s2 p1 forward for the outer layers (also the transposed conv's data gradient):
+//   y[b,co,oy,ox] = bias[co] + sum_{ci,ky,kx} w[co,ci,ky,kx] x[b,ci,2oy-1+ky,2ox-1+kx]
+// M = 16 consecutive ox per MFMA tile, N = Cout (<= 16), K steps = (ci, ky) with the 4 kx taps.
+// The input patch of a TH x TW output tile sits in LDS once; A fragments are read at
+// patch[ci][2oy+ky][2ox+kx] (bank = 2*lane + kx: conflict-free); weights live in registers.
+// ----------------------------------------------------------------------------------------------
+template <int CIN, int COUT, int TH, int TW>
+__global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restrict__ x, long x_bs,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ y, long y_bs,
+                                                            const float* __restrict__ dact, int Ho, int Wo,
+                                                            int act, int ntiles) {
+  constexpr int KS = CIN * 4;  // k-steps: (ci, ky), 4 kx taps each
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
+  constexpr int MT = TH * TW / 16, MW = MT / 4, TPR = TW / 16;
+  static_assert(MT % 4 == 0 && COUT <= 16, "tile / channel limits");
+  __shared__ float patch[CIN * PH * PW];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lm = lane & 15, lk = lane >> 4;
+  // B fragment of step s: lane (kk = kx = lk, n = co = lm) -> w[co][ci][ky][kx]
+  float bf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) bf[s] = lm < COUT ? w[((long)lm * CIN * 4 + s) * 4 + lk] : 0.f;
+  const float bv = (bias && lm < COUT) ? bias[lm] : 0.f;
+
+  const int tiles_x = Wo / TW, tiles_y = Ho / TH;
+  const int H = 2 * Ho, W = 2 * Wo;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    const float* xb = x + (long)b * x_bs;
+    __syncthreads();
+    for (int i = t; i < CIN * PH * (2 * TW / 4); i += 256) {
+      const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+      const int prow = rr % PH, ci = rr / PH;
+      const int iy = 2 * m0 - 1 + prow;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)iy < (unsigned)H) v = *reinterpret_cast<const f32x4*>(xb + ((long)ci * H + iy) * W + 2 * n0 + 4 * c4);
+      float* d = &patch[(ci * PH + prow) * PW + 1 + 4 * c4];
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+    for (int i = t; i < CIN * PH * 2; i += 256) {
+      const int side = i & 1, rr = i >> 1;
+      const int prow = rr % PH, ci = rr / PH;
+      const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[((long)ci * H + iy) * W + ix];
+      patch[(ci * PH + prow) * PW + (side ? PW - 1 : 0)] = v;
+    }
+    __syncthreads();
+    f32x4 acc[MW];
+#pragma unroll
+    for (int i = 0; i < MW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int ci = s >> 2, ky = s & 3;
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        const int mt = wave * MW + i;
+        const int row = mt / TPR, col = (mt - row * TPR) * 16;
+        const float a = patch[(ci * PH + 2 * row + ky) * PW + 2 * (col + lm) + lk];
+        acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s], acc[i], 0, 0, 0);
+      }
+    }
+    // lane holds 4 consecutive ox of channel lm
+    if (lm < COUT) {
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        const int mt = wave * MW + i;
+        const int row = mt / TPR, col = (mt - row * TPR) * 16 + 4 * lk;
+        const long g = (long)b * y_bs + ((long)lm * Ho + m0 + row) * Wo + n0 + col;
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[i][r] + bv;
+          o[r] = act ? elu(v) : v;
+        }
+        if (dact) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(dact + g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] *= elu_grad_from_out(sv[r]);
+        }
+        *reinterpret_cast<f32x4*>(y + g) = o;
+      }
+    }
+  }
+}
+
+bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo) {
+  if (Cin == 4 && Cout == 8) return Ho % 4 == 0 && Wo % 64 == 0;
+  if (Cin == 8 && Cout == 12) return Ho % 8 == 0 && Wo % 32 == 0;
+  return false;
+}
+
+int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
+                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st) {
+  if (Cin == 4 && Cout == 8) {
+    const int ntiles = (Wo / 64) * (Ho / 4) * B;
+    hipLaunchKernelGGL((conv2d_direct_kernel<4, 8, 4, 64>), dim3(ntiles < 1280 ? ntiles : 1280), dim3(256), 0, st, x,
+                       x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+  } else if (Cin == 8 && Cout == 12) {
+    const int ntiles = (Wo / 32) * (Ho / 8) * B;
+    hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x,
+                       x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+  } else {
+    set_last_error("conv2d_direct: unsupported shape");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  return check_launch("conv2d_direct");
+}
+
+}  // namespace lshm

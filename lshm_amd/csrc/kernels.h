@@ -81,6 +81,9 @@ int tconv2d_direct(const float* small, long s_bs, const float* w, const float* b
                    long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
                    hipStream_t st);
 
+bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo);
+int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
+                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st);
 bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws);
 size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb);
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, int B, int Cs,

@@ -78,6 +78,8 @@ int conv_layer_fwd(const ConvLayer& L, const float* x, const float* w, const flo
   conv_out_dims(L, Ho, Wo);
   switch (L.kind) {
     case 0: {
+      if (conv2d_direct_supported(L.Cin, L.Cout, Ho, Wo))
+        return conv2d_direct(x, L.in_bs, w, b, y, L.out_bs, nullptr, L.B, L.Cin, L.Cout, Ho, Wo, act, st);
       Conv2dFwdParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout, Ho, Wo,
                         L.in_bs, L.out_bs, act, L.B * Ho * Wo, L.Cout, L.Cin * 16, {}};
       return conv2d_fwd(p, ws, wsf, st);
@@ -115,6 +117,8 @@ int conv_layer_dgrad(const ConvLayer& L, const float* dz, const float* w, float*
       return conv2d_dgrad(p, ws, wsf, st);
     }
     case 1: {  // dx (small) = strided conv of dz (big) with the same weight tensor
+      if (conv2d_direct_supported(L.Cout, L.Cin, L.Hin, L.Win))
+        return conv2d_direct(dz, L.out_bs, w, nullptr, dx, L.in_bs, dact_in, L.B, L.Cout, L.Cin, L.Hin, L.Win, 0, st);
       Conv2dFwdParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Ho, Wo, L.Cin, L.Hin, L.Win,
                         L.out_bs, L.in_bs, 0, L.B * L.Hin * L.Win, L.Cin, L.Cout * 16, {}};
       return conv2d_fwd(p, ws, wsf, st);
