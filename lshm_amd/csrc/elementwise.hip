@@ -142,6 +142,29 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     out[i] = accumulate ? out[i] + acc : acc;
   }
 }
+// same with an explicit slab stride (slabs that carry more than one output array)
+__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* __restrict__ partial,
+                                                                      long stride, float* __restrict__ out,
+                                                                      long n, int S, int accumulate) {
+  __shared__ float red[256];
+  const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  const long i = (long)blockIdx.x * 16 + ol;
+  float acc = 0.f;
+  if (i < n)
+    for (int s = sl; s < S; s += 16) acc += partial[(long)s * stride + i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    for (int s = 1; s < 16; ++s) acc += red[s * 16 + ol];
+    out[i] = accumulate ? out[i] + acc : acc;
+  }
+}
+int reduce_partials_strided(const float* partial, long stride, float* out, long n, int S, int accumulate,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, partial, stride,
+                     out, n, S, accumulate);
+  return check_launch("reduce_partials");
+}
 int reduce_partials(const float* partial, float* out, long n, int S, int accumulate,
                     hipStream_t st) {
   hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, partial, out, n,

@@ -89,6 +89,12 @@ size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb);
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, int B, int Cs,
                         int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st);
 
+bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls);
+size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb);
+int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
+                        int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
+                        size_t wsf, int accumulate, hipStream_t st);
+
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
 struct ConvLayer {
@@ -134,6 +140,8 @@ int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t 
 // reduce_partials: out[i] (=|+=) sum_{s<S} partial[s*n + i]
 int reduce_partials(const float* partial, float* out, long n, int S, int accumulate,
                     hipStream_t st);
+int reduce_partials_strided(const float* partial, long stride, float* out, long n, int S, int accumulate,
+                            hipStream_t st);
 int channel_sum_partials(const float* dz, long bs, int B, int C, long HW, float* partial, int S,
                          hipStream_t st);
 int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* db, int accumulate,

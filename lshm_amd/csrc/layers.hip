@@ -68,6 +68,9 @@ size_t conv_workspace_floats(const ConvLayer& L) {
   if (L.kind < 2) {
     const size_t d2 = conv2d_wgrad_direct_workspace_floats(w.M, w.N / 16);
     if (d2 > a) a = d2;
+  } else {
+    const size_t d1 = conv1d_wgrad_direct_workspace_floats(w.M, w.N / 4);
+    if (d1 > a) a = d1;
   }
   return a + BIAS_WS_FLOATS + 16;
 }
@@ -166,6 +169,10 @@ int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float*
     rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st);
   } else {
     const int Ls = tr ? L.Win : Wo, Lb = tr ? Wo : L.Win;
+    if (conv1d_wgrad_direct_supported(Cs, Cb, Ls) && gemm_wsf >= conv1d_wgrad_direct_workspace_floats(Cs, Cb))
+      // weight and bias gradient in one pass (dz is `big` for the transposed conv, `small` otherwise)
+      return conv1d_wgrad_direct(small, s_bs, big, big_bs, dw, db, tr ? 2 : 1, L.Cout, L.B, Cs, Cb, Ls, Lb,
+                                 tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st);
     Conv1dWgradParams p{small, big, dw, L.B, Cs, Ls, Cb, Lb, tr ? 0 : 1, s_bs, big_bs,
                         g.M, g.N, g.K, accumulate, {}};
     rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st);
