@@ -71,7 +71,7 @@ int lshm_conv_fwd(int kind, const float* x, const float* w, const float* bias, f
   ConvLayer L;
   int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
   if (rc) return rc;
-  return conv_layer_fwd(L, x, w, bias, y, act, ws, ws ? wsf : 0, ST(s));
+  return conv_layer_fwd(L, ConvFwdIO{x, w, bias, y}, act, ws, ws ? wsf : 0, ST(s));
 }
 int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved, int B,
                     int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, float* ws, size_t wsf,
@@ -80,7 +80,7 @@ int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const 
   ConvLayer L;
   int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
   if (rc) return rc;
-  return conv_layer_dgrad(L, dz, w, dx, y_in_saved, ws, ws ? wsf : 0, ST(s));
+  return conv_layer_dgrad(L, ConvDgradIO{dz, w, dx, y_in_saved}, ws, ws ? wsf : 0, ST(s));
 }
 int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float* db, int B, int Cin,
                     int Cout, int Hin, int Win, long in_bs, long out_bs, float* ws, size_t wsf,
@@ -89,7 +89,7 @@ int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float*
   ConvLayer L;
   int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
   if (rc) return rc;
-  return conv_layer_wgrad(L, x, dz, dw, db, ws, wsf, accumulate, ST(s));
+  return conv_layer_wgrad(L, ConvWgradIO{x, dz, dw, db}, ws, wsf, accumulate, ST(s));
 }
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t s) {
   REQUIRE(gy && y && dz && n >= 0, "elu_bwd: bad argument");
@@ -107,18 +107,18 @@ size_t lshm_linear_workspace_floats(int B, int K, int N) {
 int lshm_linear_fwd(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
                     int B, int K, int N, int act, float* ws, size_t wsf, lshm_stream_t s) {
   REQUIRE(x && w && y && B > 0 && K > 0 && N > 0 && ldx >= K && ldy >= N, "linear_fwd: bad argument");
-  return linear_fwd(x, ldx, w, bias, y, ldy, B, K, N, act, ws, ws ? wsf : 0, ST(s));
+  return linear_fwd(LinFwdIO{x, w, bias, y}, ldx, ldy, B, K, N, act, ws, ws ? wsf : 0, ST(s));
 }
 int lshm_linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
                       const float* x_saved, long ldxs, int B, int K, int N, float* ws, size_t wsf,
                       lshm_stream_t s) {
   REQUIRE(dz && w && dx && B > 0 && K > 0 && N > 0 && lddz >= N && lddx >= K, "linear_dgrad: bad argument");
-  return linear_dgrad(dz, lddz, w, dx, lddx, x_saved, ldxs, B, K, N, ws, ws ? wsf : 0, ST(s));
+  return linear_dgrad(LinDgradIO{dz, w, dx, x_saved, nullptr}, lddz, lddx, ldxs, 0, 0, B, K, N, ws, ws ? wsf : 0, ST(s));
 }
 int lshm_linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
                       int K, int N, float* ws, size_t wsf, lshm_stream_t s) {
   REQUIRE(x && dz && dw && B > 0 && K > 0 && N > 0, "linear_wgrad: bad argument");
-  return linear_wgrad(x, ldx, dz, lddz, dw, db, B, K, N, ws, ws ? wsf : 0, ST(s));
+  return linear_wgrad(LinWgradIO{x, dz, dw, db}, ldx, lddz, B, K, N, ws, ws ? wsf : 0, ST(s));
 }
 
 size_t lshm_khm_workspace_floats(int N, int D, int K) { return khm_workspace_floats(N, D, K); }

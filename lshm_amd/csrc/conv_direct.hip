@@ -432,10 +432,17 @@ namespace lshm {
 // stride == 8 (mod 32): the (channel, tap, position) lanes of a B fragment hit 32 distinct banks).
 // ----------------------------------------------------------------------------------------------
 template <int CS, int CB, int TL>
-__global__ __launch_bounds__(256) void conv1d_wgrad_direct_kernel(const float* __restrict__ small, long s_bs,
-                                                                  const float* __restrict__ big, long big_bs,
-                                                                  float* __restrict__ partial, int Ls, int Lb,
+__global__ __launch_bounds__(256) void conv1d_wgrad_direct_kernel(const float* __restrict__ small0,
+                                                                  const float* __restrict__ small1, long s_bs,
+                                                                  const float* __restrict__ big0,
+                                                                  const float* __restrict__ big1, long big_bs,
+                                                                  float* __restrict__ partial0,
+                                                                  float* __restrict__ partial1, int Ls, int Lb,
                                                                   int pad, int bias_from, int ntiles) {
+  // blockIdx.y selects one of two independent problems of the same shape (netT / netF)
+  const float* small = blockIdx.y ? small1 : small0;
+  const float* big = blockIdx.y ? big1 : big0;
+  float* partial = blockIdx.y ? partial1 : partial0;
   constexpr int LDS_S = TL + 2;
   constexpr int BL = 4 * TL + 8;  // == 8 (mod 32)
   constexpr int NT = CB / 4;      // 16 columns = 4 big channels x 4 taps
@@ -524,35 +531,37 @@ bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls) {
 }
 size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)768 * (Cs * Cb * 4 + 16); }
 
-// out layout after the reduce: dw (Cs*Cb*4 floats) then 16 bias sums in `bias16`
+// second problem (small2, big2, dw2, db2) optional: both run in one launch
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
-                        size_t wsf, int accumulate, hipStream_t st) {
-  if (wsf < conv1d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv1d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
+                        size_t wsf, int accumulate, hipStream_t st, const float* small2, const float* big2,
+                        float* dw2, float* db2) {
+  const int G = small2 ? 2 : 1;
+  if (wsf < G * conv1d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv1d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   int grid, slab;
   if (!db) bias_from = 0;
+  float* ws2 = ws + conv1d_wgrad_direct_workspace_floats(Cs, Cb);
+  const int ntiles = (Ls / 256) * B;
+  grid = ntiles < 768 / G ? ntiles : 768 / G;
   if (Cs == 8 && Cb == 4) {
-    const int ntiles = (Ls / 256) * B;
-    grid = ntiles < 768 ? ntiles : 768;
     slab = 8 * 4 * 4 + 16;
-    hipLaunchKernelGGL((conv1d_wgrad_direct_kernel<8, 4, 256>), dim3(grid), dim3(256), 0, st, small, s_bs, big, big_bs,
-                       ws, Ls, Lb, pad, bias_from, ntiles);
+    hipLaunchKernelGGL((conv1d_wgrad_direct_kernel<8, 4, 256>), dim3(grid, G), dim3(256), 0, st, small, small2, s_bs,
+                       big, big2, big_bs, ws, ws2, Ls, Lb, pad, bias_from, ntiles);
   } else if (Cs == 12 && Cb == 8) {
-    const int ntiles = (Ls / 256) * B;
-    grid = ntiles < 768 ? ntiles : 768;
     slab = 12 * 8 * 4 + 16;
-    hipLaunchKernelGGL((conv1d_wgrad_direct_kernel<12, 8, 256>), dim3(grid), dim3(256), 0, st, small, s_bs, big, big_bs,
-                       ws, Ls, Lb, pad, bias_from, ntiles);
+    hipLaunchKernelGGL((conv1d_wgrad_direct_kernel<12, 8, 256>), dim3(grid, G), dim3(256), 0, st, small, small2, s_bs,
+                       big, big2, big_bs, ws, ws2, Ls, Lb, pad, bias_from, ntiles);
   } else {
     set_last_error("conv1d_wgrad_direct: unsupported shape");
     return LSHM_ERR_UNSUPPORTED;
   }
   int rc = check_launch("conv1d_wgrad_direct");
   if (rc) return rc;
-  // one strided reduce over the slabs: weights, then (optionally) the bias entries
-  rc = reduce_partials_strided(ws, slab, dw, (long)Cs * Cb * 4, grid, accumulate, st);
+  // strided reduces over the slabs: weights, then (optionally) the bias entries
+  rc = reduce_partials_strided(ws, slab, dw, (long)Cs * Cb * 4, grid, accumulate, st, small2 ? ws2 : nullptr, dw2);
   if (rc || !bias_from) return rc;
-  return reduce_partials_strided(ws + (long)Cs * Cb * 4, slab, db, nbias, grid, accumulate, st);
+  return reduce_partials_strided(ws + (long)Cs * Cb * 4, slab, db, nbias, grid, accumulate, st,
+                                 small2 ? ws2 + (long)Cs * Cb * 4 : nullptr, db2);
 }
 
 }  // namespace lshm

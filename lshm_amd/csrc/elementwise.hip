@@ -125,28 +125,16 @@ int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t 
 // --------------------------------------------------------------------------
 // reduce_partials / channel sums
 // --------------------------------------------------------------------------
-// block = 16 outputs x 16 slice lanes, lanes combined through LDS in lane order (deterministic)
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ partial,
-                                                              float* __restrict__ out, long n, int S,
-                                                              int accumulate) {
+// same with an explicit slab stride (slabs that carry more than one output array) and an optional
+// second (partial, out) pair handled by blockIdx.y == 1
+__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* __restrict__ partial0,
+                                                                      const float* __restrict__ partial1,
+                                                                      long stride, float* __restrict__ out0,
+                                                                      float* __restrict__ out1, long n, int S,
+                                                                      int accumulate) {
   __shared__ float red[256];
-  const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  const long i = (long)blockIdx.x * 16 + ol;
-  float acc = 0.f;
-  if (i < n)
-    for (int s = sl; s < S; s += 16) acc += partial[(long)s * n + i];
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  if (sl == 0 && i < n) {
-    for (int s = 1; s < 16; ++s) acc += red[s * 16 + ol];
-    out[i] = accumulate ? out[i] + acc : acc;
-  }
-}
-// same with an explicit slab stride (slabs that carry more than one output array)
-__global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const float* __restrict__ partial,
-                                                                      long stride, float* __restrict__ out,
-                                                                      long n, int S, int accumulate) {
-  __shared__ float red[256];
+  const float* partial = blockIdx.y ? partial1 : partial0;
+  float* out = blockIdx.y ? out1 : out0;
   const int ol = threadIdx.x & 15, sl = threadIdx.x >> 4;
   const long i = (long)blockIdx.x * 16 + ol;
   float acc = 0.f;
@@ -160,23 +148,24 @@ __global__ __launch_bounds__(256) void reduce_partials_strided_kernel(const floa
   }
 }
 int reduce_partials_strided(const float* partial, long stride, float* out, long n, int S, int accumulate,
-                            hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, partial, stride,
-                     out, n, S, accumulate);
+                            hipStream_t st, const float* partial2, float* out2) {
+  hipLaunchKernelGGL(reduce_partials_strided_kernel, dim3(cdiv(n, 16), partial2 ? 2 : 1), dim3(256), 0, st,
+                     partial, partial2, stride, out, out2, n, S, accumulate);
   return check_launch("reduce_partials");
 }
 int reduce_partials(const float* partial, float* out, long n, int S, int accumulate,
-                    hipStream_t st) {
-  hipLaunchKernelGGL(reduce_partials_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, partial, out, n,
-                     S, accumulate);
-  return check_launch("reduce_partials");
+                    hipStream_t st, const float* partial2, float* out2) {
+  return reduce_partials_strided(partial, n, out, n, S, accumulate, st, partial2, out2);
 }
 
 // partial[s*C + c] = sum over images b in slice s, all HW positions, of dz[b*bs + c*HW + r]
-__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dz, long bs, int B,
-                                                          int C, long HW, float* __restrict__ partial,
-                                                          int S, int accumulate) {
+__global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restrict__ dz0,
+                                                          const float* __restrict__ dz1, long bs, int B,
+                                                          int C, long HW, float* __restrict__ partial0,
+                                                          float* __restrict__ partial1, int S, int accumulate) {
   __shared__ float red[16];
+  const float* dz = blockIdx.z ? dz1 : dz0;
+  float* partial = blockIdx.z ? partial1 : partial0;
   const int c = blockIdx.x, s = blockIdx.y;
   const int b0 = (int)((long)B * s / S), b1 = (int)((long)B * (s + 1) / S);
   float acc = 0.f;
@@ -202,15 +191,16 @@ __global__ __launch_bounds__(256) void channel_sum_kernel(const float* __restric
   }
 }
 int channel_sum_partials(const float* dz, long bs, int B, int C, long HW, float* partial, int S,
-                         hipStream_t st) {
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S), dim3(HW >= 1024 ? 256 : 64), 0, st, dz, bs, B,
-                     C, HW, partial, S, 0);
+                         hipStream_t st, const float* dz2, float* partial2) {
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, S, dz2 ? 2 : 1), dim3(HW >= 1024 ? 256 : 64), 0, st, dz, dz2,
+                     bs, B, C, HW, partial, partial2, S, 0);
   return check_launch("channel_sum");
 }
 // single-pass variant for small tensors: db[c] (=|+=) sum_{b,r} dz[b,c,r], one workgroup per channel
 int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* db, int accumulate,
-                       hipStream_t st) {
-  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, 1), dim3(256), 0, st, dz, bs, B, C, HW, db, 1, accumulate);
+                       hipStream_t st, const float* dz2, float* db2) {
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(C, 1, dz2 ? 2 : 1), dim3(256), 0, st, dz, dz2, bs, B, C, HW, db,
+                     db2, 1, accumulate);
   return check_launch("channel_sum");
 }
 

@@ -63,22 +63,12 @@ struct lshm_engine {
   // shared workspace offsets
   size_t o_scales, o_uvh, o_Mu, o_gMu, o_row, o_col, o_gx1p, o_gx2, o_gx3c, o_gT, o_gFc, o_gx1,
       o_scal, o_dMscratch;
-  // Two independent "lanes" of backward scratch so the netT and netF branches (independent given
-  // AE1's output) can run concurrently on two streams; each lane has a second split-K scratch for
-  // the weight-gradient kernels, which run beside the data-gradient chain on a side stream.
+  // Two "lanes" of backward scratch: netT and netF (independent given AE1's output, identical
+  // shapes) run as pairs inside the same launches, each with its own lane; o_part/o_wpart of a
+  // lane are adjacent and together form the split-K scratch of a paired launch.
   struct Lane {
     size_t o_gA, o_gB, o_dcat1, o_dz1, o_dzmu, o_dcat3, o_dd0, o_part, o_wpart;
-    hipStream_t wstream;    // weight-gradient side stream
   } lane[2];
-  hipStream_t fstream;      // netF branch
-  // every fork/join edge of one engine call uses its own event (a capture that re-records one
-  // event many times crashed hipStreamEndCapture on ROCm 7.2)
-  std::vector<hipEvent_t> events;
-  mutable size_t next_event;
-  hipEvent_t take_event() const { return events[next_event++ % events.size()]; }
-  bool streams_ok;
-  int wgrad_lanes;     // how many lanes fork their weight gradients (debug knob LSHM_STREAMS)
-  bool wgrad_streams;  // weight gradients on side streams (LSHM_STREAMS=1 keeps only the netT/netF fork)
   size_t part_floats;
   size_t ws_floats;
 };
@@ -173,146 +163,158 @@ static void plan_ae(lshm_engine* e, int idx, const char* prefix, int ndim, int L
   a.out = take(cur, (size_t)B * c.C * PP);
 }
 
-static int ae_forward(const lshm_engine* e, int idx, const float* prm, const float* input,
+// Forward of one autoencoder (G == 1) or of two autoencoders of identical shape that share every
+// launch (G == 2: netT and netF).  idx[] = AE indices, input[] = their input tensors.
+static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* prm, const float* const* input,
                       float* ws, int ln, hipStream_t st) {
-  const AEPlan& a = e->ae[idx];
   const lshm_step_config& c = e->cfg;
-  const int B = c.B, hd = e->hdim, L = a.L, D = e->D;
+  const AEPlan& a0 = e->ae[idx[0]];
+  const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
   const float* uvh = ws + e->o_uvh;
-  float* cat1 = ws + a.cat1;
-  float* Mu = ws + e->o_Mu + a.mu_col;
-  float* cat3 = ws + a.cat3;
-  float* part = ws + e->lane[ln].o_part;
-  const size_t pf = e->part_floats;
+  float* part = ws + e->lane[ln].o_part;  // a pair uses the lane's two adjacent scratch regions
+  const size_t pf = e->part_floats * (G > 1 ? 2 : 1);
   int rc;
-  const float* in = input;
+  const float* in[2];
+  float* out[2];
+  for (int g = 0; g < G; ++g) in[g] = input[g];
+  auto A = [&](int g) -> const AEPlan& { return e->ae[idx[g]]; };
   for (int i = 0; i < 6; ++i) {
-    float* out = (i < 5) ? ws + a.act[i] : cat1;
-    if ((rc = conv_layer_fwd(a.enc[i], in, prm + a.cw[i], prm + a.cb[i], out, 1, part, pf, st))) return rc;
-    in = out;
+    ConvFwdIO io[2];
+    for (int g = 0; g < G; ++g) {
+      out[g] = (i < 5) ? ws + A(g).act[i] : ws + A(g).cat1;
+      io[g] = ConvFwdIO{in[g], prm + A(g).cw[i], prm + A(g).cb[i], out[g]};
+    }
+    if ((rc = conv_layer_fwd(a0.enc[i], io[0], 1, part, pf, st, G > 1 ? &io[1] : nullptr))) return rc;
+    for (int g = 0; g < G; ++g) in[g] = out[g];
   }
-  if ((rc = linear_fwd(uvh, hd, prm + a.fcuv1w, prm + a.fcuv1b, cat1 + 768, 768 + hd, B, hd, hd, 1, part, pf, st))) return rc;
+  LinFwdIO l[2];
+  auto lin = [&](long ldx, long ldy, int K, int N, int act) {
+    return linear_fwd(l[0], ldx, ldy, B, K, N, act, part, pf, st, G > 1 ? &l[1] : nullptr);
+  };
+  for (int g = 0; g < G; ++g) l[g] = LinFwdIO{uvh, prm + A(g).fcuv1w, prm + A(g).fcuv1b, ws + A(g).cat1 + 768};
+  if ((rc = lin(hd, 768 + hd, hd, hd, 1))) return rc;
   if (c.rica) {
-    if ((rc = linear_fwd(cat1, 768 + hd, prm + a.fc1w, prm + a.fc1b, ws + a.z1, L, B, 768 + hd, L, 1, part, pf, st))) return rc;
-    if ((rc = linear_fwd(ws + a.z1, L, prm + a.fc2inw, prm + a.fc2inb, Mu, D, B, L, L, 1, part, pf, st))) return rc;
-    if ((rc = linear_fwd(Mu, D, prm + a.fc2outw, prm + a.fc2outb, cat3, L + hd, B, L, L, 1, part, pf, st))) return rc;
+    for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat1, prm + A(g).fc1w, prm + A(g).fc1b, ws + A(g).z1};
+    if ((rc = lin(768 + hd, L, 768 + hd, L, 1))) return rc;
+    for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).z1, prm + A(g).fc2inw, prm + A(g).fc2inb, ws + e->o_Mu + A(g).mu_col};
+    if ((rc = lin(L, D, L, L, 1))) return rc;
+    for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + e->o_Mu + A(g).mu_col, prm + A(g).fc2outw, prm + A(g).fc2outb, ws + A(g).cat3};
+    if ((rc = lin(D, L + hd, L, L, 1))) return rc;
   } else {
-    if ((rc = linear_fwd(cat1, 768 + hd, prm + a.fc1w, prm + a.fc1b, Mu, D, B, 768 + hd, L, 1, part, pf, st))) return rc;
-    if ((rc = copy2d(Mu, D, cat3, L + hd, B, L, st))) return rc;
+    for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat1, prm + A(g).fc1w, prm + A(g).fc1b, ws + e->o_Mu + A(g).mu_col};
+    if ((rc = lin(768 + hd, D, 768 + hd, L, 1))) return rc;
+    for (int g = 0; g < G; ++g)
+      if ((rc = copy2d(ws + e->o_Mu + A(g).mu_col, D, ws + A(g).cat3, L + hd, B, L, st))) return rc;
   }
-  if ((rc = linear_fwd(uvh, hd, prm + a.fcuv3w, prm + a.fcuv3b, cat3 + L, L + hd, B, hd, hd, 1, part, pf, st))) return rc;
-  if ((rc = linear_fwd(cat3, L + hd, prm + a.fc3w, prm + a.fc3b, ws + a.d0, 768, B, L + hd, 768, 0, part, pf, st))) return rc;
-  in = ws + a.d0;
+  for (int g = 0; g < G; ++g) l[g] = LinFwdIO{uvh, prm + A(g).fcuv3w, prm + A(g).fcuv3b, ws + A(g).cat3 + L};
+  if ((rc = lin(hd, L + hd, hd, hd, 1))) return rc;
+  for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat3, prm + A(g).fc3w, prm + A(g).fc3b, ws + A(g).d0};
+  if ((rc = lin(L + hd, 768, L + hd, 768, 0))) return rc;
+  for (int g = 0; g < G; ++g) in[g] = ws + A(g).d0;
   for (int i = 0; i < 6; ++i) {
-    float* out = (i < 5) ? ws + a.dact[i] : ws + a.out;
-    if ((rc = conv_layer_fwd(a.dec[i], in, prm + a.tw[i], prm + a.tb[i], out, i < 5, part, pf, st))) return rc;
-    in = out;
+    ConvFwdIO io[2];
+    for (int g = 0; g < G; ++g) {
+      out[g] = (i < 5) ? ws + A(g).dact[i] : ws + A(g).out;
+      io[g] = ConvFwdIO{in[g], prm + A(g).tw[i], prm + A(g).tb[i], out[g]};
+    }
+    if ((rc = conv_layer_fwd(a0.dec[i], io[0], i < 5, part, pf, st, G > 1 ? &io[1] : nullptr))) return rc;
+    for (int g = 0; g < G; ++g) in[g] = out[g];
   }
   return LSHM_OK;
 }
 
-// dz_out: gradient w.r.t. the AE output (B,C,P*P); gMu (B,D) holds the gradient w.r.t. the latents.
-// dinput: gradient w.r.t. the AE input, or null.
-// fork the weight gradient of a conv layer onto the lane's side stream (it only needs dz and the
-// saved input, both complete on `st` at this point); the caller joins before dz's buffer is reused
-static int wgrad_beside(const lshm_engine* e, int ln, const ConvLayer& L, const float* xin, const float* dz,
-                        float* dw, float* db, float* ws, hipStream_t st, hipEvent_t* ev_w_out) {
-  const lshm_engine::Lane& la = e->lane[ln];
-  if (!e->streams_ok || !e->wgrad_streams || ln >= e->wgrad_lanes) {
-    *ev_w_out = nullptr;
-    return conv_layer_wgrad(L, xin, dz, dw, db, ws + la.o_wpart, e->part_floats, 0, st);
-  }
-  hipError_t he;
-  hipEvent_t ev_dz = e->take_event();
-  if ((he = hipEventRecord(ev_dz, st)) != hipSuccess || (he = hipStreamWaitEvent(la.wstream, ev_dz, 0)) != hipSuccess) {
-    set_last_error("engine: stream fork failed");
-    return (int)he;
-  }
-  int rc = conv_layer_wgrad(L, xin, dz, dw, db, ws + la.o_wpart, e->part_floats, 0, la.wstream);
-  if (rc) return rc;
-  *ev_w_out = e->take_event();
-  if ((he = hipEventRecord(*ev_w_out, la.wstream)) != hipSuccess) { set_last_error("engine: event record failed"); return (int)he; }
-  return LSHM_OK;
-}
-static int wgrad_join(const lshm_engine* e, hipEvent_t ev_w, hipStream_t st) {
-  if (!e->streams_ok || !ev_w) return LSHM_OK;
-  hipError_t he = hipStreamWaitEvent(st, ev_w, 0);
-  if (he != hipSuccess) { set_last_error("engine: stream join failed"); return (int)he; }
-  return LSHM_OK;
-}
-
-static int ae_backward(const lshm_engine* e, int idx, const float* prm, float* grd,
-                       const float* input, const float* dz_out, float* dinput, float* ws, int ln,
+// Backward of one (G == 1) or two same-shape (G == 2) autoencoders.  dz_out[g]: gradient w.r.t. the
+// AE output (B,C,P*P); gMu (B,D) holds the gradient w.r.t. the latents; dinput[g]: gradient w.r.t.
+// the AE input, or null.  With G == 2, lane 0 holds problem 0's scratch and lane 1 problem 1's.
+static int ae_backward(const lshm_engine* e, int G, const int* idx, const float* prm, float* grd,
+                       const float* const* input, const float* const* dz_out, float* const* dinput, float* ws,
                        hipStream_t st) {
-  const AEPlan& a = e->ae[idx];
   const lshm_step_config& c = e->cfg;
-  const int B = c.B, hd = e->hdim, L = a.L, D = e->D;
+  const AEPlan& a0 = e->ae[idx[0]];
+  const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
   const float* uvh = ws + e->o_uvh;
-  const lshm_engine::Lane& la = e->lane[ln];
-  float* gA = ws + la.o_gA;
-  float* gB = ws + la.o_gB;
-  float* part = ws + la.o_part;
-  const size_t pf = e->part_floats;
-  float* dd0 = ws + la.o_dd0;
-  float* dcat3 = ws + la.o_dcat3;
-  float* dzmu = ws + la.o_dzmu;
-  float* dz1 = ws + la.o_dz1;
-  float* dcat1 = ws + la.o_dcat1;
-  const float* Mu = ws + e->o_Mu + a.mu_col;
-  const float* gMu = ws + e->o_gMu + a.mu_col;
-  const float* cat1 = ws + a.cat1;
-  const float* cat3 = ws + a.cat3;
+  float* part = ws + e->lane[0].o_part;  // lane 0's fwd + wgrad scratch are adjacent: 2x for a pair
+  const size_t pf = e->part_floats * (G > 1 ? 2 : 1);
+  auto A = [&](int g) -> const AEPlan& { return e->ae[idx[g]]; };
+  auto LA = [&](int g) -> const lshm_engine::Lane& { return e->lane[g]; };
   int rc;
-  hipEvent_t ev_w = nullptr;
+  const float* dz[2];
+  for (int g = 0; g < G; ++g) dz[g] = dz_out[g];
   // ---- decoder, last layer first
-  const float* dz = dz_out;
   for (int i = 5; i >= 0; --i) {
-    const float* xin = (i == 0) ? ws + a.d0 : ws + a.dact[i - 1];
-    if ((rc = wgrad_beside(e, ln, a.dec[i], xin, dz, grd + a.tw[i], grd + a.tb[i], ws, st, &ev_w))) return rc;
-    float* dx = (i == 0) ? dd0 : ((i & 1) ? gA : gB);
-    // previous activation is an ELU output (except fc3's output feeding tconv0)
-    if ((rc = conv_layer_dgrad(a.dec[i], dz, prm + a.tw[i], dx, i == 0 ? nullptr : xin, part, pf, st))) return rc;
-    if ((rc = wgrad_join(e, ev_w, st))) return rc;
-    dz = dx;
+    ConvWgradIO wg[2];
+    ConvDgradIO dg[2];
+    float* dx[2];
+    for (int g = 0; g < G; ++g) {
+      const float* xin = (i == 0) ? ws + A(g).d0 : ws + A(g).dact[i - 1];
+      dx[g] = (i == 0) ? ws + LA(g).o_dd0 : ws + ((i & 1) ? LA(g).o_gA : LA(g).o_gB);
+      wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).tw[i], grd + A(g).tb[i]};
+      // previous activation is an ELU output (except fc3's output feeding tconv0)
+      dg[g] = ConvDgradIO{dz[g], prm + A(g).tw[i], dx[g], i == 0 ? nullptr : xin};
+    }
+    if ((rc = conv_layer_wgrad(a0.dec[i], wg[0], part, pf, 0, st, G > 1 ? &wg[1] : nullptr))) return rc;
+    if ((rc = conv_layer_dgrad(a0.dec[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
+    for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
+  LinWgradIO lw[2];
+  LinDgradIO ld[2];
+  auto wgrad = [&](long ldx, long lddz, int K, int N) {
+    return linear_wgrad(lw[0], ldx, lddz, B, K, N, part, pf, st, G > 1 ? &lw[1] : nullptr);
+  };
+  auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
+    return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr);
+  };
   // ---- fc3 (no activation on its output): dd0 is its pre-activation gradient
-  if ((rc = linear_wgrad(cat3, L + hd, dd0, 768, grd + a.fc3w, grd + a.fc3b, B, L + hd, 768, part, pf, st))) return rc;
-  if (c.rica) {
-    if ((rc = linear_dgrad(dd0, 768, prm + a.fc3w, dcat3, L + hd, cat3, L + hd, B, L + hd, 768, part, pf, st))) return rc;
-  } else {
-    // latent == decoder input: add the latent-loss gradient before the ELU' multiply
-    if ((rc = linear_dgrad(dd0, 768, prm + a.fc3w, dcat3, L + hd, cat3, L + hd, B, L + hd, 768, part, pf, st, gMu, D, L))) return rc;
-  }
-  if ((rc = linear_wgrad(uvh, hd, dcat3 + L, L + hd, grd + a.fcuv3w, grd + a.fcuv3b, B, hd, hd, part, pf, st))) return rc;
-  const float* dzfc1;  // pre-activation gradient of fc1's output
+  for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{ws + A(g).cat3, ws + LA(g).o_dd0, grd + A(g).fc3w, grd + A(g).fc3b};
+  if ((rc = wgrad(L + hd, 768, L + hd, 768))) return rc;
+  // (rica == 0: latent == decoder input, so the latent-loss gradient is added before the ELU' multiply)
+  for (int g = 0; g < G; ++g)
+    ld[g] = LinDgradIO{ws + LA(g).o_dd0, prm + A(g).fc3w, ws + LA(g).o_dcat3, ws + A(g).cat3,
+                       c.rica ? nullptr : ws + e->o_gMu + A(g).mu_col};
+  if ((rc = dgrad(768, L + hd, L + hd, D, L, L + hd, 768))) return rc;
+  for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{uvh, ws + LA(g).o_dcat3 + L, grd + A(g).fcuv3w, grd + A(g).fcuv3b};
+  if ((rc = wgrad(hd, L + hd, hd, hd))) return rc;
   long ld_dzfc1;
+  size_t LaneOff[2];  // offset of the pre-activation gradient of fc1's output inside the workspace
   if (c.rica) {
-    if ((rc = linear_wgrad(Mu, D, dcat3, L + hd, grd + a.fc2outw, grd + a.fc2outb, B, L, L, part, pf, st))) return rc;
-    if ((rc = linear_dgrad(dcat3, L + hd, prm + a.fc2outw, dzmu, L, Mu, D, B, L, L, part, pf, st, gMu, D, L))) return rc;
-    if ((rc = linear_wgrad(ws + a.z1, L, dzmu, L, grd + a.fc2inw, grd + a.fc2inb, B, L, L, part, pf, st))) return rc;
-    if ((rc = linear_dgrad(dzmu, L, prm + a.fc2inw, dz1, L, ws + a.z1, L, B, L, L, part, pf, st))) return rc;
-    dzfc1 = dz1;
+    for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{ws + e->o_Mu + A(g).mu_col, ws + LA(g).o_dcat3, grd + A(g).fc2outw, grd + A(g).fc2outb};
+    if ((rc = wgrad(D, L + hd, L, L))) return rc;
+    for (int g = 0; g < G; ++g)
+      ld[g] = LinDgradIO{ws + LA(g).o_dcat3, prm + A(g).fc2outw, ws + LA(g).o_dzmu, ws + e->o_Mu + A(g).mu_col,
+                         ws + e->o_gMu + A(g).mu_col};
+    if ((rc = dgrad(L + hd, L, D, D, L, L, L))) return rc;
+    for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{ws + A(g).z1, ws + LA(g).o_dzmu, grd + A(g).fc2inw, grd + A(g).fc2inb};
+    if ((rc = wgrad(L, L, L, L))) return rc;
+    for (int g = 0; g < G; ++g) ld[g] = LinDgradIO{ws + LA(g).o_dzmu, prm + A(g).fc2inw, ws + LA(g).o_dz1, ws + A(g).z1, nullptr};
+    if ((rc = dgrad(L, L, L, 0, 0, L, L))) return rc;
+    for (int g = 0; g < G; ++g) LaneOff[g] = LA(g).o_dz1;
     ld_dzfc1 = L;
   } else {
-    dzfc1 = dcat3;
+    for (int g = 0; g < G; ++g) LaneOff[g] = LA(g).o_dcat3;
     ld_dzfc1 = L + hd;
   }
-  if ((rc = linear_wgrad(cat1, 768 + hd, dzfc1, ld_dzfc1, grd + a.fc1w, grd + a.fc1b, B, 768 + hd, L, part, pf, st))) return rc;
-  if ((rc = linear_dgrad(dzfc1, ld_dzfc1, prm + a.fc1w, dcat1, 768 + hd, cat1, 768 + hd, B, 768 + hd, L, part, pf, st))) return rc;
-  if ((rc = linear_wgrad(uvh, hd, dcat1 + 768, 768 + hd, grd + a.fcuv1w, grd + a.fcuv1b, B, hd, hd, part, pf, st))) return rc;
+  for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{ws + A(g).cat1, ws + LaneOff[g], grd + A(g).fc1w, grd + A(g).fc1b};
+  if ((rc = wgrad(768 + hd, ld_dzfc1, 768 + hd, L))) return rc;
+  for (int g = 0; g < G; ++g) ld[g] = LinDgradIO{ws + LaneOff[g], prm + A(g).fc1w, ws + LA(g).o_dcat1, ws + A(g).cat1, nullptr};
+  if ((rc = dgrad(ld_dzfc1, 768 + hd, 768 + hd, 0, 0, 768 + hd, L))) return rc;
+  for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{uvh, ws + LA(g).o_dcat1 + 768, grd + A(g).fcuv1w, grd + A(g).fcuv1b};
+  if ((rc = wgrad(hd, 768 + hd, hd, hd))) return rc;
   // ---- encoder
-  dz = dcat1;
+  for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_dcat1;
   for (int i = 5; i >= 0; --i) {
-    const float* xin = (i == 0) ? input : ws + a.act[i - 1];
-    if ((rc = wgrad_beside(e, ln, a.enc[i], xin, dz, grd + a.cw[i], grd + a.cb[i], ws, st, &ev_w))) return rc;
-    if (i == 0 && !dinput) {
-      if ((rc = wgrad_join(e, ev_w, st))) return rc;
-      break;
+    ConvWgradIO wg[2];
+    ConvDgradIO dg[2];
+    float* dx[2];
+    for (int g = 0; g < G; ++g) {
+      const float* xin = (i == 0) ? input[g] : ws + A(g).act[i - 1];
+      dx[g] = (i == 0) ? dinput[g] : ws + ((i & 1) ? LA(g).o_gA : LA(g).o_gB);
+      wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).cw[i], grd + A(g).cb[i]};
+      dg[g] = ConvDgradIO{dz[g], prm + A(g).cw[i], dx[g], i == 0 ? nullptr : xin};
     }
-    float* dx = (i == 0) ? dinput : ((i & 1) ? gA : gB);
-    if ((rc = conv_layer_dgrad(a.enc[i], dz, prm + a.cw[i], dx, i == 0 ? nullptr : xin, part, pf, st))) return rc;
-    if ((rc = wgrad_join(e, ev_w, st))) return rc;
-    dz = dx;
+    if ((rc = conv_layer_wgrad(a0.enc[i], wg[0], part, pf, 0, st, G > 1 ? &wg[1] : nullptr))) return rc;
+    if (i == 0 && !dinput[0]) break;
+    if ((rc = conv_layer_dgrad(a0.enc[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
+    for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
   return LSHM_OK;
 }
@@ -342,28 +344,16 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   const lshm_step_config& c = e->cfg;
   int rc;
   if ((rc = uv_harmonics_host_scales(uv, c.scales, c.H, c.B, ws + e->o_uvh, st))) return rc;
-  if ((rc = ae_forward(e, 0, prm, x, ws, 0, st))) return rc;
+  {
+    const int i0[1] = {0};
+    const float* in0[1] = {x};
+    if ((rc = ae_forward(e, 1, i0, prm, in0, ws, 0, st))) return rc;
+  }
   if ((rc = residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st))) return rc;
-  // the two 1-D autoencoders are independent: run them side by side
-  hipStream_t fst = st;
-  if (e->streams_ok) {
-    fst = e->fstream;
-    hipEvent_t evf = e->take_event();
-    if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(fst, evf, 0) != hipSuccess) {
-      set_last_error("engine: stream fork failed");
-      return LSHM_ERR_ARG;
-    }
-  }
-  if ((rc = ae_forward(e, 1, prm, ws + e->o_row, ws, 0, st))) return rc;
-  if ((rc = ae_forward(e, 2, prm, ws + e->o_col, ws, 1, fst))) return rc;
-  if (e->streams_ok) {
-    hipEvent_t evj = e->take_event();
-    if (hipEventRecord(evj, fst) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
-      set_last_error("engine: stream join failed");
-      return LSHM_ERR_ARG;
-    }
-  }
-  return LSHM_OK;
+  // the two 1-D autoencoders have identical shapes and are independent: every launch carries both
+  const int i12[2] = {1, 2};
+  const float* in12[2] = {ws + e->o_row, ws + e->o_col};
+  return ae_forward(e, 2, i12, prm, in12, ws, 0, st);
 }
 
 // losses (and, when grd != null, every gradient) after three_forward
@@ -421,26 +411,21 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   if ((rc = check_launch("finalize_terms"))) return rc;
   if (!grd) return LSHM_OK;
   // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
-  hipStream_t fst = st;
-  if (e->streams_ok) {
-    fst = e->fstream;
-    hipEvent_t evf = e->take_event();
-    if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(fst, evf, 0) != hipSuccess) {
-      set_last_error("engine: stream fork failed");
-      return LSHM_ERR_ARG;
-    }
-  }
-  if ((rc = ae_backward(e, 1, prm, grd, ws + e->o_row, ws + e->o_gx2, ws + e->o_gT, ws, 0, st))) return rc;
-  if ((rc = ae_backward(e, 2, prm, grd, ws + e->o_col, ws + e->o_gx3c, ws + e->o_gFc, ws, 1, fst))) return rc;
-  if (e->streams_ok) {
-    hipEvent_t evj = e->take_event();
-    if (hipEventRecord(evj, fst) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
-      set_last_error("engine: stream join failed");
-      return LSHM_ERR_ARG;
-    }
+  {
+    const int i12[2] = {1, 2};
+    const float* in12[2] = {ws + e->o_row, ws + e->o_col};
+    const float* dz12[2] = {ws + e->o_gx2, ws + e->o_gx3c};
+    float* di12[2] = {ws + e->o_gT, ws + e->o_gFc};
+    if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, st))) return rc;
   }
   if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st))) return rc;
-  if ((rc = ae_backward(e, 0, prm, grd, x, ws + e->o_gx1, nullptr, ws, 0, st))) return rc;
+  {
+    const int i0[1] = {0};
+    const float* in0[1] = {x};
+    const float* dz0[1] = {ws + e->o_gx1};
+    float* di0[1] = {nullptr};
+    if ((rc = ae_backward(e, 1, i0, prm, grd, in0, dz0, di0, ws, st))) return rc;
+  }
   return LSHM_OK;
 }
 
@@ -525,28 +510,6 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     e->lane[ln].o_part = take(cur, pf);
     e->lane[ln].o_wpart = take(cur, pf);
   }
-  // side streams / events (host objects only; a machine without a HIP device - e.g. the build
-  // container - simply runs everything on the caller's stream)
-  e->streams_ok = false;
-  {
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && !getenv("LSHM_SINGLE_STREAM")) {
-      bool ok = hipStreamCreateWithFlags(&e->fstream, hipStreamNonBlocking) == hipSuccess;
-      for (int ln = 0; ln < 2 && ok; ++ln)
-        ok = ok && hipStreamCreateWithFlags(&e->lane[ln].wstream, hipStreamNonBlocking) == hipSuccess;
-      e->events.resize(192);  // > fork/join edges of one forward+backward (2 per conv layer + 4)
-      for (size_t i = 0; i < e->events.size() && ok; ++i)
-        ok = ok && hipEventCreateWithFlags(&e->events[i], hipEventDisableTiming) == hipSuccess;
-      e->next_event = 0;
-      e->streams_ok = ok;
-      const char* lv = getenv("LSHM_STREAMS");
-      // weight gradients beside the data-gradient chain: measured no gain once netT/netF overlap, and
-      // nested forks crash hipStreamEndCapture on ROCm 7.2 -> off unless LSHM_STREAMS=2 (both lanes) / 3 (lane 0)
-      e->wgrad_streams = lv && (lv[0] == '2' || lv[0] == '3');
-      e->wgrad_lanes = (lv && lv[0] == '3') ? 1 : 2;
-    }
-    (void)hipGetLastError();
-  }
   const size_t ngroups = (size_t)(B + cfg->bpb - 1) / cfg->bpb;
   e->o_scal = take(cur, 2 * (16 + ngroups + 3 * LOGCOSH3_BLOCKS));
   e->ws_floats = cur;
@@ -554,15 +517,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   return LSHM_OK;
 }
 
-void lshm_engine_destroy(lshm_engine* e) {
-  if (!e) return;
-  if (e->streams_ok) {
-    (void)hipStreamDestroy(e->fstream);
-    for (int ln = 0; ln < 2; ++ln) (void)hipStreamDestroy(e->lane[ln].wstream);
-    for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
-  }
-  delete e;
-}
+void lshm_engine_destroy(lshm_engine* e) { delete e; }
 
 long lshm_engine_param_count(const lshm_engine* e) { return e ? e->nparams : 0; }
 
@@ -609,7 +564,6 @@ int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* gra
   ENGINE_CHECK(e && params && grads && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_backward: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
   return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st);
@@ -621,7 +575,6 @@ int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_loss: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
   return losses_and_backward(e, params, nullptr, x, y1, y2, y3, terms, ws, st);
@@ -633,7 +586,6 @@ int lshm_engine_multiplier_update(lshm_engine* e, const float* params, const flo
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
   const lshm_step_config& c = e->cfg;
@@ -646,7 +598,6 @@ int lshm_engine_encode(lshm_engine* e, const float* params, const float* x, cons
   ENGINE_CHECK(e && params && x && uv && ws, "engine_encode: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
   const lshm_step_config& c = e->cfg;

@@ -20,8 +20,19 @@ namespace lshm {
 // --------------------------------------------------------------------------
 // mainloop
 // --------------------------------------------------------------------------
+// Two problems of identical shape (the row- and column-vectorised 1-D autoencoders) can share one
+// launch: grid.z carries a group index and each group has its own parameter block.
+template <class P>
+struct Pair {
+  typename P::Params p[2];
+  int zper;  // z-blocks per group (zgroups * splits)
+};
+
 template <class P, int BM, int BN, int BK>
-__global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) {
+__global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
+  const int grp = blockIdx.z / pp.zper;
+  const int zblk = blockIdx.z - grp * pp.zper;
+  const typename P::Params& p = pp.p[grp];
   constexpr int NT = 256;
   constexpr int TM = BM / 64, TN = BN / 16;
   // LDS leading dimensions: [k][m]/[k][n] images need ld == 16 (mod 32), [m][k]/[n][k]
@@ -43,9 +54,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   // grid.z = zgroup (e.g. output parity of the transposed conv) x K split
   const int splits = p.sk.splits;
-  const int zg = blockIdx.z / splits, split = blockIdx.z - zg * splits;
+  const int zg = zblk / splits, split = zblk - zg * splits;
   const int kbeg = split * p.sk.kchunk;
   const int kend = min(p.K, kbeg + p.sk.kchunk);
+  // kchunk is a multiple of BK: lets the compiler hoist the tap decode / bounds tests of the
+  // gathers out of the K loop (they depend on k only through k % 16)
+  __builtin_assume((kbeg & (BK - 1)) == 0);
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -61,15 +75,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
   const int wm0 = wave * (BM / 4);
 
   float ra[NA], rb[NB];
+  // "fast" operands are affine in the K-chunk index: element i of this thread sits at
+  // base + off[i] + chunk * step, with tap decode and bounds tests done once, before the K loop
+  int aoff[NA], boff[NB];
+  unsigned avalid = 0, bvalid = 0;
+  const float* abase = nullptr;
+  const float* bbase = nullptr;
+  long astep = 0, bstep = 0;
+  if constexpr (P::A_M_FAST) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      bool ok;
+      P::a_affine(p, fa, m0 + t % BM, t / BM + i * (NT / BM), zg, aoff[i], ok);
+      avalid |= (unsigned)ok << i;
+    }
+    astep = P::a_step(p, BK);
+    abase = P::a_base(p, fa) + (long)(kbeg / BK) * astep;
+  }
+  if constexpr (P::B_N_FAST) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      bool ok;
+      const int kl = t / BN + i * (NT / BN);
+      P::b_affine(p, fb, n0 + t % BN, kl, zg, boff[i], ok);
+      bvalid |= (unsigned)(ok && kl < BK) << i;
+    }
+    bstep = P::b_step(p, BK);
+    bbase = P::b_base(p) + (long)(kbeg / BK) * bstep;
+  }
   // global -> registers for the chunk starting at k0 (issued one chunk ahead of its use)
   auto fetch = [&](int k0) {
-    if (P::A_M_FAST) {
-      const int ml = t % BM;
+    const int krem = kend - k0;  // elements of this chunk that exist
+    if constexpr (P::A_M_FAST) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
-        const int k = k0 + t / BM + i * (NT / BM);
-        ra[i] = (k < kend) ? P::a_load(p, fa, m0 + ml, k, zg) : 0.f;
+        const int kl = t / BM + i * (NT / BM);
+        ra[i] = ((avalid >> i) & 1u) && kl < krem ? abase[aoff[i]] : 0.f;
       }
+      abase += astep;
     } else {
       const int k = k0 + t % BK;
       if (k < kend) fa = P::a_fast(p, k, zg);
@@ -77,14 +120,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
       for (int i = 0; i < NA; ++i)
         ra[i] = (k < kend) ? P::a_load(p, fa, m0 + t / BK + i * (NT / BK), k, zg) : 0.f;
     }
-    if (P::B_N_FAST) {
-      const int nl = t % BN;
+    if constexpr (P::B_N_FAST) {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int kl = t / BN + i * (NT / BN);
-        const int k = k0 + kl;
-        rb[i] = (kl < BK && k < kend) ? P::b_load(p, fb, k, n0 + nl, zg) : 0.f;
+        rb[i] = ((bvalid >> i) & 1u) && kl < krem ? bbase[boff[i]] : 0.f;
       }
+      bbase += bstep;
     } else {
       const int k = k0 + t % BK;
       if (k < kend) fb = P::b_fast(p, k, zg);
@@ -152,7 +194,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
       for (int j = 0; j < TN; ++j) {
         const int m = m0 + wm0 + 16 * i + 4 * lk, n = n0 + 16 * j + lm;
         if (m < Mp && n < p.N)
-          *reinterpret_cast<f32x4*>(p.sk.partial + ((long)blockIdx.z * p.N + n) * Mp + m) = acc[i][j];
+          *reinterpret_cast<f32x4*>(p.sk.partial + ((long)zblk * p.N + n) * Mp + m) = acc[i][j];
       }
     return;
   }
@@ -167,8 +209,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const typename P::Params p) 
 // reproducible) and applies the problem's own epilogue.  Block = OL outputs (groups of 4 rows)
 // x SL split lanes; lanes are combined through LDS in lane order.
 template <class P>
-__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const typename P::Params p, int zgroups,
-                                                              int OL) {
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const Pair<P> pp, int zgroups, int OL) {
+  const typename P::Params& p = pp.p[blockIdx.y];
   __shared__ f32x4 red[256];
   const int SL = 256 / OL;
   const int ol = threadIdx.x % OL, sl = threadIdx.x / OL;
@@ -224,11 +266,19 @@ struct Conv2dFwd {
     if (!f.base) return 0.f;
     const int ci = k >> 4, iy = f.iy0 + ((k >> 2) & 3), ix = f.ix0 + (k & 3);
     if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) return 0.f;
-    return f.base[((long)ci * p.H + iy) * p.W + ix];
+    return f.base[(ci * p.H + iy) * p.W + ix];
   }
+  // element (m, k = kl + chunk*BK): offset = (ci*H + iy)*W + ix, ci = kl/16 + chunk*BK/16
+  __device__ static void a_affine(const Params& p, const FastA& f, int, int kl, int, int& off, bool& ok) {
+    const int iy = f.iy0 + ((kl >> 2) & 3), ix = f.ix0 + (kl & 3);
+    ok = f.base && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+    off = ((kl >> 4) * p.H + iy) * p.W + ix;
+  }
+  __device__ static long a_step(const Params& p, int bk) { return (long)(bk / 16) * p.H * p.W; }
+  __device__ static const float* a_base(const Params& p, const FastA& f) { return f.base ? f.base : p.x; }
   __device__ static FastB b_fast(const Params&, int k, int) { return FastB{k}; }
   __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
-    return n < p.N ? p.w[(long)n * p.K + k] : 0.f;
+    return n < p.N ? p.w[n * p.K + k] : 0.f;
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (m >= p.M || n >= p.N) return;
@@ -273,14 +323,28 @@ struct Conv2dDgrad {
     const int cs = k >> 2, tt = (k >> 1) & 1, u = k & 1;
     const int iy = f.mm + (z >> 1) - tt, ix = f.nn + (z & 1) - u;
     if ((unsigned)iy >= (unsigned)p.Hs || (unsigned)ix >= (unsigned)p.Ws) return 0.f;
-    return f.base[((long)cs * p.Hs + iy) * p.Ws + ix];
+    return f.base[(cs * p.Hs + iy) * p.Ws + ix];
   }
+  __device__ static void a_affine(const Params& p, const FastA& f, int, int kl, int z, int& off, bool& ok) {
+    const int iy = f.mm + (z >> 1) - ((kl >> 1) & 1), ix = f.nn + (z & 1) - (kl & 1);
+    ok = f.base && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+    off = ((kl >> 2) * p.Hs + iy) * p.Ws + ix;
+  }
+  __device__ static long a_step(const Params& p, int bk) { return (long)(bk / 4) * p.Hs * p.Ws; }
+  __device__ static const float* a_base(const Params& p, const FastA& f) { return f.base ? f.base : p.s; }
+  __device__ static void b_affine(const Params& p, const FastB&, int n, int kl, int z, int& off, bool& ok) {
+    const int ky = 2 * ((kl >> 1) & 1) + 1 - (z >> 1), kx = 2 * (kl & 1) + 1 - (z & 1);
+    ok = n < p.N;
+    off = (((kl >> 2) * p.Cb + n) * 4 + ky) * 4 + kx;
+  }
+  __device__ static long b_step(const Params& p, int bk) { return (long)(bk / 4) * p.Cb * 16; }
+  __device__ static const float* b_base(const Params& p) { return p.w; }
   __device__ static FastB b_fast(const Params&, int n, int) { return FastB{n}; }
   __device__ static float b_load(const Params& p, const FastB&, int k, int n, int z) {
     if (n >= p.N) return 0.f;
     const int cs = k >> 2, tt = (k >> 1) & 1, u = k & 1;
     const int ky = 2 * tt + 1 - (z >> 1), kx = 2 * u + 1 - (z & 1);
-    return p.w[(((long)cs * p.Cb + n) * 4 + ky) * 4 + kx];
+    return p.w[((cs * p.Cb + n) * 4 + ky) * 4 + kx];
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int z) {
     if (n >= p.N) return;
@@ -316,7 +380,7 @@ struct Conv2dWgrad {
     return FastA{p.s + (long)b * p.s_bs + r};
   }
   __device__ static float a_load(const Params& p, const FastA& f, int m, int, int) {
-    return m < p.M ? f.base[(long)m * p.Hs * p.Ws] : 0.f;
+    return m < p.M ? f.base[m * p.Hs * p.Ws] : 0.f;
   }
   __device__ static FastB b_fast(const Params& p, int k, int) {
     const int hw = p.Hs * p.Ws;
@@ -329,7 +393,7 @@ struct Conv2dWgrad {
     const int cb = n >> 4, iy = f.iy0 + ((n >> 2) & 3), ix = f.ix0 + (n & 3);
     const int Hb = 2 * p.Hs, Wb = 2 * p.Ws;
     if ((unsigned)iy >= (unsigned)Hb || (unsigned)ix >= (unsigned)Wb) return 0.f;
-    return f.base[((long)cb * Hb + iy) * Wb + ix];
+    return f.base[(cb * Hb + iy) * Wb + ix];
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;
@@ -357,15 +421,22 @@ struct Conv1dFwd {
     const int b = m / p.Lo, j = m - b * p.Lo;
     return FastA{p.x + (long)b * p.x_bs, 4 * j - p.pad};
   }
+  __device__ static void a_affine(const Params& p, const FastA& f, int, int kl, int, int& off, bool& ok) {
+    const int pos = f.j0 + (kl & 3);
+    ok = f.base && (unsigned)pos < (unsigned)p.L;
+    off = (kl >> 2) * p.L + pos;
+  }
+  __device__ static long a_step(const Params& p, int bk) { return (long)(bk / 4) * p.L; }
+  __device__ static const float* a_base(const Params& p, const FastA& f) { return f.base ? f.base : p.x; }
   __device__ static float a_load(const Params& p, const FastA& f, int, int k, int) {
     if (!f.base) return 0.f;
     const int ci = k >> 2, pos = f.j0 + (k & 3);
     if ((unsigned)pos >= (unsigned)p.L) return 0.f;
-    return f.base[(long)ci * p.L + pos];
+    return f.base[ci * p.L + pos];
   }
   __device__ static FastB b_fast(const Params&, int k, int) { return FastB{k}; }
   __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
-    return n < p.N ? p.w[(long)n * p.K + k] : 0.f;
+    return n < p.N ? p.w[n * p.K + k] : 0.f;
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (m >= p.M || n >= p.N) return;
@@ -399,12 +470,24 @@ struct Conv1dDgrad {
     const int b = m / p.Ls, i = m - b * p.Ls;
     return FastA{p.s + (long)b * p.s_bs + i};
   }
+  __device__ static void a_affine(const Params& p, const FastA& f, int, int kl, int, int& off, bool& ok) {
+    ok = f.base != nullptr;
+    off = kl * p.Ls;
+  }
+  __device__ static long a_step(const Params& p, int bk) { return (long)bk * p.Ls; }
+  __device__ static const float* a_base(const Params& p, const FastA& f) { return f.base ? f.base : p.s; }
+  __device__ static void b_affine(const Params& p, const FastB&, int n, int kl, int, int& off, bool& ok) {
+    ok = n < p.N;
+    off = kl * p.N + n;
+  }
+  __device__ static long b_step(const Params& p, int bk) { return (long)bk * p.N; }
+  __device__ static const float* b_base(const Params& p) { return p.w; }
   __device__ static float a_load(const Params& p, const FastA& f, int, int k, int) {
-    return f.base ? f.base[(long)k * p.Ls] : 0.f;
+    return f.base ? f.base[k * p.Ls] : 0.f;
   }
   __device__ static FastB b_fast(const Params&, int n, int) { return FastB{n}; }
   __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
-    return n < p.N ? p.w[(long)k * p.N + n] : 0.f;
+    return n < p.N ? p.w[k * p.N + n] : 0.f;
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;
@@ -442,7 +525,7 @@ struct Conv1dWgrad {
     return FastA{p.s + (long)b * p.s_bs + i};
   }
   __device__ static float a_load(const Params& p, const FastA& f, int m, int, int) {
-    return m < p.M ? f.base[(long)m * p.Ls] : 0.f;
+    return m < p.M ? f.base[m * p.Ls] : 0.f;
   }
   __device__ static FastB b_fast(const Params& p, int k, int) {
     const int b = k / p.Ls, i = k - b * p.Ls;
@@ -452,7 +535,7 @@ struct Conv1dWgrad {
     if (n >= p.N) return 0.f;
     const int cb = n >> 2, pos = f.pos0 + (n & 3);
     if ((unsigned)pos >= (unsigned)p.Lb) return 0.f;
-    return f.base[(long)cb * p.Lb + pos];
+    return f.base[cb * p.Lb + pos];
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;
@@ -476,6 +559,18 @@ struct Strided {
   struct FastB { int i; };
   __device__ static FastA a_fast(const Params&, int i, int) { return FastA{i}; }
   __device__ static FastB b_fast(const Params&, int i, int) { return FastB{i}; }
+  __device__ static void a_affine(const Params& p, const FastA&, int m, int kl, int, int& off, bool& ok) {
+    ok = m < p.M;
+    off = (int)(m * p.sam + kl * p.sak);
+  }
+  __device__ static long a_step(const Params& p, int bk) { return (long)bk * p.sak; }
+  __device__ static const float* a_base(const Params& p, const FastA&) { return p.a; }
+  __device__ static void b_affine(const Params& p, const FastB&, int n, int kl, int, int& off, bool& ok) {
+    ok = n < p.N;
+    off = (int)(kl * p.sbk + n * p.sbn);
+  }
+  __device__ static long b_step(const Params& p, int bk) { return (long)bk * p.sbk; }
+  __device__ static const float* b_base(const Params& p) { return p.b; }
   __device__ static float a_load(const Params& p, const FastA&, int m, int k, int) {
     return m < p.M ? p.a[(long)m * p.sam + (long)k * p.sak] : 0.f;
   }
@@ -503,9 +598,10 @@ struct Strided {
 // Split-K plan: when the output tiling alone cannot fill the chip (deep layers: few output
 // positions, long K; weight gradients: tiny outputs, K = B*H*W), grid.z also splits K and a
 // second kernel combines the slabs.  Needs workspace; without one the launch is unsplit.
+#define IGEMM_BK 32  // K elements staged per main-loop iteration
 struct SplitPlan { int splits, kchunk; };
 static SplitPlan plan_split(long tiles, int K, int M, int N, int zgroups, size_t ws_floats) {
-  SplitPlan sp{1, (K + 15) / 16 * 16};
+  SplitPlan sp{1, (K + IGEMM_BK - 1) / IGEMM_BK * IGEMM_BK};
   if (tiles >= 384 || K <= 64 || ws_floats == 0) return sp;
   long want = (768 + tiles - 1) / tiles;
   const long maxs = K / 64;  // at least 4 K-steps per split
@@ -515,47 +611,56 @@ static SplitPlan plan_split(long tiles, int K, int M, int N, int zgroups, size_t
   if (per * want > (long)ws_floats) want = (long)ws_floats / per;
   if (want <= 1) return sp;
   int kc = (int)((K + want - 1) / want);
-  kc = (kc + 15) / 16 * 16;
+  kc = (kc + IGEMM_BK - 1) / IGEMM_BK * IGEMM_BK;
   sp.kchunk = kc;
   sp.splits = (K + kc - 1) / kc;
-  if (sp.splits <= 1) { sp.splits = 1; sp.kchunk = (K + 15) / 16 * 16; }
+  if (sp.splits <= 1) { sp.splits = 1; sp.kchunk = (K + IGEMM_BK - 1) / IGEMM_BK * IGEMM_BK; }
   return sp;
 }
 
 template <class P, int BM, int BN, int BK>
-static int launch_cfg(typename P::Params p, int M, int N, int Z, float* ws, size_t wsf, hipStream_t st) {
-  const long tiles = (long)cdiv(M, BM) * cdiv(N, BN) * Z;
-  const SplitPlan sp = plan_split(tiles, p.K, M, N, Z, ws ? wsf : 0);
-  p.sk.partial = ws;
-  p.sk.splits = sp.splits;
-  p.sk.kchunk = sp.kchunk;
-  dim3 grid(cdiv(M, BM), cdiv(N, BN), Z * sp.splits);
-  hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK>), grid, dim3(256), 0, st, p);
+static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1, int M, int N, int Z,
+                      float* ws, size_t wsf, hipStream_t st) {
+  const int G = p1 ? 2 : 1;
+  const size_t wsg = ws ? wsf / G : 0;  // split-K scratch per group
+  const long tiles = (long)cdiv(M, BM) * cdiv(N, BN) * Z * G;
+  const SplitPlan sp = plan_split(tiles, p0.K, M, N, Z, wsg);
+  Pair<P> pp;
+  pp.p[0] = p0;
+  pp.p[1] = p1 ? *p1 : p0;
+  for (int g = 0; g < 2; ++g) {
+    pp.p[g].sk.partial = ws ? ws + (size_t)g * wsg : nullptr;
+    pp.p[g].sk.splits = sp.splits;
+    pp.p[g].sk.kchunk = sp.kchunk;
+  }
+  pp.zper = Z * sp.splits;
+  dim3 grid(cdiv(M, BM), cdiv(N, BN), Z * sp.splits * G);
+  hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK>), grid, dim3(256), 0, st, pp);
   int rc = check_launch("igemm");
   if (rc || sp.splits == 1) return rc;
   const long nout = (long)((M + 3) / 4) * N * Z;
   const int OL = nout >= 16384 ? 64 : 16;
-  hipLaunchKernelGGL((splitk_epilogue_kernel<P>), dim3(cdiv(nout, OL)), dim3(256), 0, st, p, Z, OL);
+  hipLaunchKernelGGL((splitk_epilogue_kernel<P>), dim3(cdiv(nout, OL), G), dim3(256), 0, st, pp, Z, OL);
   return check_launch("splitk_epilogue");
 }
 
 // choose the N tile from the real N so padding waste stays small
 template <class P, int BM>
-static int launch_by_n(const typename P::Params& p, int M, int N, int Z, float* ws, size_t wsf,
-                       hipStream_t st) {
-  if (N <= 16) return launch_cfg<P, BM, 16, 16>(p, M, N, Z, ws, wsf, st);
-  if (N <= 32) return launch_cfg<P, BM, 32, 16>(p, M, N, Z, ws, wsf, st);
-  if (N <= 48 || (N % 48 == 0 && N % 64 != 0)) return launch_cfg<P, BM, 48, 16>(p, M, N, Z, ws, wsf, st);
-  return launch_cfg<P, BM, 64, 16>(p, M, N, Z, ws, wsf, st);
+static int launch_by_n(const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
+                       float* ws, size_t wsf, hipStream_t st) {
+  if (N <= 16) return launch_cfg<P, BM, 16, IGEMM_BK>(p, p1, M, N, Z, ws, wsf, st);
+  if (N <= 32) return launch_cfg<P, BM, 32, IGEMM_BK>(p, p1, M, N, Z, ws, wsf, st);
+  if (N <= 48 || (N % 48 == 0 && N % 64 != 0)) return launch_cfg<P, BM, 48, IGEMM_BK>(p, p1, M, N, Z, ws, wsf, st);
+  return launch_cfg<P, BM, 64, IGEMM_BK>(p, p1, M, N, Z, ws, wsf, st);
 }
 
 template <class P>
-static int launch_auto(const typename P::Params& p, int M, int N, int Z, float* ws, size_t wsf,
-                       hipStream_t st) {
+static int launch_auto(const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
+                       float* ws, size_t wsf, hipStream_t st) {
   // small-M problems (deep layers, weight gradients): 64-row tiles give more workgroups
   if (M <= 64 || (long)cdiv(M, 128) * cdiv(N, 64) * Z < 256)
-    return launch_by_n<P, 64>(p, M, N, Z, ws, wsf, st);
-  return launch_by_n<P, 128>(p, M, N, Z, ws, wsf, st);
+    return launch_by_n<P, 64>(p, p1, M, N, Z, ws, wsf, st);
+  return launch_by_n<P, 128>(p, p1, M, N, Z, ws, wsf, st);
 }
 
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {
@@ -569,30 +674,30 @@ size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {
   return (size_t)(Mp * (long)N * zgroups * want);
 }
 
-int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st) {
-  return launch_auto<Conv2dFwd>(p, p.M, p.N, 1, ws, wsf, st);
+int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dFwdParams* p1) {
+  return launch_auto<Conv2dFwd>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
-int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st) {
-  return launch_auto<Conv2dDgrad>(p, p.M, p.N, 4, ws, wsf, st);
+int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dDgradParams* p1) {
+  return launch_auto<Conv2dDgrad>(p, p1, p.M, p.N, 4, ws, wsf, st);
 }
-int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st) {
-  return launch_auto<Conv2dWgrad>(p, p.M, p.N, 1, ws, wsf, st);
+int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dWgradParams* p1) {
+  return launch_auto<Conv2dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
-int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st) {
-  return launch_auto<Conv1dFwd>(p, p.M, p.N, 1, ws, wsf, st);
+int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1) {
+  return launch_auto<Conv1dFwd>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
-int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st) {
-  return launch_auto<Conv1dDgrad>(p, p.M, p.N, 1, ws, wsf, st);
+int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dDgradParams* p1) {
+  return launch_auto<Conv1dDgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
-int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st) {
-  return launch_auto<Conv1dWgrad>(p, p.M, p.N, 1, ws, wsf, st);
+int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1) {
+  return launch_auto<Conv1dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
-                 hipStream_t st) {
-  if (a_m_fast && b_n_fast) return launch_auto<Strided<true, true>>(p, p.M, p.N, 1, ws, wsf, st);
-  if (a_m_fast) return launch_auto<Strided<true, false>>(p, p.M, p.N, 1, ws, wsf, st);
-  if (b_n_fast) return launch_auto<Strided<false, true>>(p, p.M, p.N, 1, ws, wsf, st);
-  return launch_auto<Strided<false, false>>(p, p.M, p.N, 1, ws, wsf, st);
+                 hipStream_t st, const StridedGemmParams* p1) {
+  if (a_m_fast && b_n_fast) return launch_auto<Strided<true, true>>(p, p1, p.M, p.N, 1, ws, wsf, st);
+  if (a_m_fast) return launch_auto<Strided<true, false>>(p, p1, p.M, p.N, 1, ws, wsf, st);
+  if (b_n_fast) return launch_auto<Strided<false, true>>(p, p1, p.M, p.N, 1, ws, wsf, st);
+  return launch_auto<Strided<false, false>>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 
 }  // namespace lshm

@@ -65,14 +65,15 @@ struct StridedGemmParams {
 };
 
 // ws / wsf: optional split-K scratch (null: never split)
-int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st);
-int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st);
-int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st);
-int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st);
-int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st);
-int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st);
+// p1 (optional): a second problem of identical shape run in the same launch (ws is split in two)
+int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dFwdParams* p1 = nullptr);
+int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dDgradParams* p1 = nullptr);
+int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dWgradParams* p1 = nullptr);
+int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1 = nullptr);
+int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dDgradParams* p1 = nullptr);
+int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1 = nullptr);
 int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
-                 hipStream_t st);
+                 hipStream_t st, const StridedGemmParams* p1 = nullptr);
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
 
 // ---- direct LDS-patch kernels for the outer 2-D layers (conv_direct.hip) ----
@@ -93,7 +94,8 @@ bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls);
 size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb);
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
-                        size_t wsf, int accumulate, hipStream_t st);
+                        size_t wsf, int accumulate, hipStream_t st, const float* small2 = nullptr,
+                        const float* big2 = nullptr, float* dw2 = nullptr, float* db2 = nullptr);
 
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
@@ -105,28 +107,36 @@ struct ConvLayer {
 };
 void conv_out_dims(const ConvLayer& L, int& Hout, int& Wout);
 // scratch (floats) that lets every problem of the layer use split-K + the bias partial sums
+// (twice that when two problems share a launch)
 size_t conv_workspace_floats(const ConvLayer& L);
+// pointer bundles; every layer function takes one bundle and, optionally, a second one for an
+// independent problem of identical shape that rides in the same launches (netT / netF)
+struct ConvFwdIO { const float* x; const float* w; const float* b; float* y; };
+struct ConvDgradIO { const float* dz; const float* w; float* dx; const float* dact_in; };
+struct ConvWgradIO { const float* x; const float* dz; float* dw; float* db; };
 // y = act(op(x,w)+b); ws optional (null: no split-K)
-int conv_layer_fwd(const ConvLayer& L, const float* x, const float* w, const float* b, float* y,
-                   int act, float* ws, size_t wsf, hipStream_t st);
+int conv_layer_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, float* ws, size_t wsf, hipStream_t st,
+                   const ConvFwdIO* io2 = nullptr);
 // dx = op^T(dz, w) [* elu'(x_saved) if dact_in]
-int conv_layer_dgrad(const ConvLayer& L, const float* dz, const float* w, float* dx,
-                     const float* dact_in, float* ws, size_t wsf, hipStream_t st);
-// dw, db overwritten (accumulate=0) or accumulated (accumulate=1); ws required (>= 32784 floats)
-int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float* dw, float* db,
-                     float* ws, size_t ws_floats, int accumulate, hipStream_t st);
+int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_t wsf, hipStream_t st,
+                     const ConvDgradIO* io2 = nullptr);
+// dw, db overwritten (accumulate=0) or accumulated (accumulate=1); ws required
+int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_t ws_floats, int accumulate,
+                     hipStream_t st, const ConvWgradIO* io2 = nullptr);
 
+struct LinFwdIO { const float* x; const float* w; const float* b; float* y; };
+struct LinDgradIO { const float* dz; const float* w; float* dx; const float* xsaved; const float* add; };
+struct LinWgradIO { const float* x; const float* dz; float* dw; float* db; };
 // y[B,N] (ld ldy) = act(x[B,K] (ld ldx) @ w[N,K]^T + b)
-int linear_fwd(const float* x, long ldx, const float* w, const float* b, float* y, long ldy, int B,
-               int K, int N, int act, float* ws, size_t wsf, hipStream_t st);
-// dx[B,K] (ld lddx) = (dz[B,N] (ld lddz) @ w[N,K] + add) [* elu'(xsaved (ld ldxs))]
-int linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
-                 const float* xsaved, long ldxs, int B, int K, int N, float* ws, size_t wsf,
-                 hipStream_t st, const float* add = nullptr, long ldadd = 0, int add_n = 0);
+int linear_fwd(const LinFwdIO& io, long ldx, long ldy, int B, int K, int N, int act, float* ws, size_t wsf,
+               hipStream_t st, const LinFwdIO* io2 = nullptr);
+// dx[B,K] (ld lddx) = (dz[B,N] (ld lddz) @ w[N,K] + add[:, :add_n] (ld ldadd)) [* elu'(xsaved (ld ldxs))]
+int linear_dgrad(const LinDgradIO& io, long lddz, long lddx, long ldxs, long ldadd, int add_n, int B, int K,
+                 int N, float* ws, size_t wsf, hipStream_t st, const LinDgradIO* io2 = nullptr);
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t st);
 // dw[N,K] = dz^T x ; db[N] = colsum(dz)
-int linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
-                 int K, int N, float* ws, size_t wsf, hipStream_t st);
+int linear_wgrad(const LinWgradIO& io, long ldx, long lddz, int B, int K, int N, float* ws, size_t wsf,
+                 hipStream_t st, const LinWgradIO* io2 = nullptr);
 
 // ---- elementwise / reductions (elementwise.hip) -----------------------------
 int uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, hipStream_t st);
@@ -139,13 +149,13 @@ int residual_split(const float* x, const float* x1, float* out_row, float* out_c
 int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t st);
 // reduce_partials: out[i] (=|+=) sum_{s<S} partial[s*n + i]
 int reduce_partials(const float* partial, float* out, long n, int S, int accumulate,
-                    hipStream_t st);
+                    hipStream_t st, const float* partial2 = nullptr, float* out2 = nullptr);
 int reduce_partials_strided(const float* partial, long stride, float* out, long n, int S, int accumulate,
-                            hipStream_t st);
+                            hipStream_t st, const float* partial2 = nullptr, float* out2 = nullptr);
 int channel_sum_partials(const float* dz, long bs, int B, int C, long HW, float* partial, int S,
-                         hipStream_t st);
+                         hipStream_t st, const float* dz2 = nullptr, float* partial2 = nullptr);
 int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* db, int accumulate,
-                       hipStream_t st);
+                       hipStream_t st, const float* dz2 = nullptr, float* db2 = nullptr);
 #define LOGCOSH3_BLOCKS 32
 int logcosh3_fwd_bwd(const float* z, long ldz, int rows, const int* seg_cols, const float* seg_scale,
                      double* partial, int nblocks, float* dz, long lddz, hipStream_t st);

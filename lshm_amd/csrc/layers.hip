@@ -1,8 +1,11 @@
 // Layer-level dispatch: maps the four convolution flavours of the autoencoders
 // (src/lofar_models.py:31-57, 115-142) and the dense layers onto the implicit
-// GEMM problems of igemm.hip.  A transposed convolution's forward is the
-// data-gradient problem of the matching strided convolution and vice versa, so
-// three GEMM problems per dimensionality cover forward, dgrad and wgrad of both.
+// GEMM problems of igemm.hip and the direct kernels of conv_direct.hip.  A
+// transposed convolution's forward is the data-gradient problem of the matching
+// strided convolution and vice versa, so three GEMM problems per dimensionality
+// cover forward, dgrad and wgrad of both.  Every function accepts a second
+// pointer bundle: two independent problems of identical shape (the row- and
+// column-vectorised 1-D autoencoders) then share each launch.
 #include "kernels.h"
 
 namespace lshm {
@@ -49,7 +52,7 @@ static LayerGemm wgrad_gemm(const ConvLayer& L) {
           (int)((long)L.B * small_sp), 1};
 }
 
-#define BIAS_WS_FLOATS (128 * 256)
+#define BIAS_WS_FLOATS (2 * 128 * 256)
 static int bias_slices(const ConvLayer& L) {
   int s = 512 / (L.Cout > 0 ? L.Cout : 1);
   if (s < 1) s = 1;
@@ -75,72 +78,118 @@ size_t conv_workspace_floats(const ConvLayer& L) {
   return a + BIAS_WS_FLOATS + 16;
 }
 
-int conv_layer_fwd(const ConvLayer& L, const float* x, const float* w, const float* b, float* y,
-                   int act, float* ws, size_t wsf, hipStream_t st) {
+// ---- problem descriptors from pointer bundles ---------------------------------------------
+static Conv2dFwdParams p_conv2d_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, int Ho, int Wo) {
+  return Conv2dFwdParams{io.x, io.w, io.b, io.y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout, Ho, Wo,
+                         L.in_bs, L.out_bs, act, L.B * Ho * Wo, L.Cout, L.Cin * 16, {}};
+}
+static Conv2dDgradParams p_tconv2d_fwd(const ConvLayer& L, const ConvFwdIO& io, int act) {
+  return Conv2dDgradParams{io.x, io.w, io.b, io.y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout,
+                           L.in_bs, L.out_bs, act, L.B * L.Hin * L.Win, L.Cout, L.Cin * 4, {}};
+}
+static Conv1dFwdParams p_conv1d_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, int Wo) {
+  return Conv1dFwdParams{io.x, io.w, io.b, io.y, nullptr, L.B, L.Cin, L.Win, L.Cout, Wo, 1,
+                         L.in_bs, L.out_bs, act, L.B * Wo, L.Cout, L.Cin * 4, {}};
+}
+static Conv1dDgradParams p_tconv1d_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, int Wo) {
+  return Conv1dDgradParams{io.x, io.w, io.b, io.y, nullptr, L.B, L.Cin, L.Win, L.Cout, Wo, 0,
+                           L.in_bs, L.out_bs, act, L.B * L.Win, L.Cout * 4, L.Cin, {}};
+}
+
+int conv_layer_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, float* ws, size_t wsf, hipStream_t st,
+                   const ConvFwdIO* io2) {
   int Ho, Wo;
   conv_out_dims(L, Ho, Wo);
   switch (L.kind) {
     case 0: {
-      if (conv2d_direct_supported(L.Cin, L.Cout, Ho, Wo))
-        return conv2d_direct(x, L.in_bs, w, b, y, L.out_bs, nullptr, L.B, L.Cin, L.Cout, Ho, Wo, act, st);
-      Conv2dFwdParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout, Ho, Wo,
-                        L.in_bs, L.out_bs, act, L.B * Ho * Wo, L.Cout, L.Cin * 16, {}};
-      return conv2d_fwd(p, ws, wsf, st);
+      if (!io2 && conv2d_direct_supported(L.Cin, L.Cout, Ho, Wo))
+        return conv2d_direct(io.x, L.in_bs, io.w, io.b, io.y, L.out_bs, nullptr, L.B, L.Cin, L.Cout, Ho, Wo, act, st);
+      const Conv2dFwdParams p = p_conv2d_fwd(L, io, act, Ho, Wo);
+      if (!io2) return conv2d_fwd(p, ws, wsf, st);
+      const Conv2dFwdParams q = p_conv2d_fwd(L, *io2, act, Ho, Wo);
+      return conv2d_fwd(p, ws, wsf, st, &q);
     }
     case 1: {
-      if (tconv2d_direct_supported(L.Cin, L.Cout, L.Hin, L.Win))
-        return tconv2d_direct(x, L.in_bs, w, b, y, L.out_bs, nullptr, L.B, L.Cin, L.Cout, L.Hin, L.Win, act, st);
-      Conv2dDgradParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout,
-                          L.in_bs, L.out_bs, act, L.B * L.Hin * L.Win, L.Cout, L.Cin * 4, {}};
-      return conv2d_dgrad(p, ws, wsf, st);
+      if (!io2 && tconv2d_direct_supported(L.Cin, L.Cout, L.Hin, L.Win))
+        return tconv2d_direct(io.x, L.in_bs, io.w, io.b, io.y, L.out_bs, nullptr, L.B, L.Cin, L.Cout, L.Hin, L.Win,
+                              act, st);
+      const Conv2dDgradParams p = p_tconv2d_fwd(L, io, act);
+      if (!io2) return conv2d_dgrad(p, ws, wsf, st);
+      const Conv2dDgradParams q = p_tconv2d_fwd(L, *io2, act);
+      return conv2d_dgrad(p, ws, wsf, st, &q);
     }
     case 2: {
-      Conv1dFwdParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Win, L.Cout, Wo, 1,
-                        L.in_bs, L.out_bs, act, L.B * Wo, L.Cout, L.Cin * 4, {}};
-      return conv1d_fwd(p, ws, wsf, st);
+      const Conv1dFwdParams p = p_conv1d_fwd(L, io, act, Wo);
+      if (!io2) return conv1d_fwd(p, ws, wsf, st);
+      const Conv1dFwdParams q = p_conv1d_fwd(L, *io2, act, Wo);
+      return conv1d_fwd(p, ws, wsf, st, &q);
     }
     default: {
-      Conv1dDgradParams p{x, w, b, y, nullptr, L.B, L.Cin, L.Win, L.Cout, Wo, 0,
-                          L.in_bs, L.out_bs, act, L.B * L.Win, L.Cout * 4, L.Cin, {}};
-      return conv1d_dgrad(p, ws, wsf, st);
+      const Conv1dDgradParams p = p_tconv1d_fwd(L, io, act, Wo);
+      if (!io2) return conv1d_dgrad(p, ws, wsf, st);
+      const Conv1dDgradParams q = p_tconv1d_fwd(L, *io2, act, Wo);
+      return conv1d_dgrad(p, ws, wsf, st, &q);
     }
   }
 }
 
-int conv_layer_dgrad(const ConvLayer& L, const float* dz, const float* w, float* dx,
-                     const float* dact_in, float* ws, size_t wsf, hipStream_t st) {
+static Conv2dDgradParams p_conv2d_dgrad(const ConvLayer& L, const ConvDgradIO& io, int Ho, int Wo) {
+  return Conv2dDgradParams{io.dz, io.w, nullptr, io.dx, io.dact_in, L.B, L.Cout, Ho, Wo, L.Cin,
+                           L.out_bs, L.in_bs, 0, L.B * Ho * Wo, L.Cin, L.Cout * 4, {}};
+}
+static Conv2dFwdParams p_tconv2d_dgrad(const ConvLayer& L, const ConvDgradIO& io, int Ho, int Wo) {
+  return Conv2dFwdParams{io.dz, io.w, nullptr, io.dx, io.dact_in, L.B, L.Cout, Ho, Wo, L.Cin, L.Hin, L.Win,
+                         L.out_bs, L.in_bs, 0, L.B * L.Hin * L.Win, L.Cin, L.Cout * 16, {}};
+}
+static Conv1dDgradParams p_conv1d_dgrad(const ConvLayer& L, const ConvDgradIO& io, int Wo) {
+  return Conv1dDgradParams{io.dz, io.w, nullptr, io.dx, io.dact_in, L.B, L.Cout, Wo, L.Cin, L.Win, 1,
+                           L.out_bs, L.in_bs, 0, L.B * Wo, L.Cin * 4, L.Cout, {}};
+}
+static Conv1dFwdParams p_tconv1d_dgrad(const ConvLayer& L, const ConvDgradIO& io, int Wo) {
+  return Conv1dFwdParams{io.dz, io.w, nullptr, io.dx, io.dact_in, L.B, L.Cout, Wo, L.Cin, L.Win, 0,
+                         L.out_bs, L.in_bs, 0, L.B * L.Win, L.Cin, L.Cout * 4, {}};
+}
+
+int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_t wsf, hipStream_t st,
+                     const ConvDgradIO* io2) {
   int Ho, Wo;
   conv_out_dims(L, Ho, Wo);
   switch (L.kind) {
     case 0: {  // dx (big) from dz (small)
-      if (tconv2d_direct_supported(L.Cout, L.Cin, Ho, Wo))
-        return tconv2d_direct(dz, L.out_bs, w, nullptr, dx, L.in_bs, dact_in, L.B, L.Cout, L.Cin, Ho, Wo, 0, st);
-      Conv2dDgradParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Ho, Wo, L.Cin,
-                          L.out_bs, L.in_bs, 0, L.B * Ho * Wo, L.Cin, L.Cout * 4, {}};
-      return conv2d_dgrad(p, ws, wsf, st);
+      if (!io2 && tconv2d_direct_supported(L.Cout, L.Cin, Ho, Wo))
+        return tconv2d_direct(io.dz, L.out_bs, io.w, nullptr, io.dx, L.in_bs, io.dact_in, L.B, L.Cout, L.Cin, Ho, Wo,
+                              0, st);
+      const Conv2dDgradParams p = p_conv2d_dgrad(L, io, Ho, Wo);
+      if (!io2) return conv2d_dgrad(p, ws, wsf, st);
+      const Conv2dDgradParams q = p_conv2d_dgrad(L, *io2, Ho, Wo);
+      return conv2d_dgrad(p, ws, wsf, st, &q);
     }
     case 1: {  // dx (small) = strided conv of dz (big) with the same weight tensor
-      if (conv2d_direct_supported(L.Cout, L.Cin, L.Hin, L.Win))
-        return conv2d_direct(dz, L.out_bs, w, nullptr, dx, L.in_bs, dact_in, L.B, L.Cout, L.Cin, L.Hin, L.Win, 0, st);
-      Conv2dFwdParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Ho, Wo, L.Cin, L.Hin, L.Win,
-                        L.out_bs, L.in_bs, 0, L.B * L.Hin * L.Win, L.Cin, L.Cout * 16, {}};
-      return conv2d_fwd(p, ws, wsf, st);
+      if (!io2 && conv2d_direct_supported(L.Cout, L.Cin, L.Hin, L.Win))
+        return conv2d_direct(io.dz, L.out_bs, io.w, nullptr, io.dx, L.in_bs, io.dact_in, L.B, L.Cout, L.Cin, L.Hin,
+                             L.Win, 0, st);
+      const Conv2dFwdParams p = p_tconv2d_dgrad(L, io, Ho, Wo);
+      if (!io2) return conv2d_fwd(p, ws, wsf, st);
+      const Conv2dFwdParams q = p_tconv2d_dgrad(L, *io2, Ho, Wo);
+      return conv2d_fwd(p, ws, wsf, st, &q);
     }
     case 2: {
-      Conv1dDgradParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Wo, L.Cin, L.Win, 1,
-                          L.out_bs, L.in_bs, 0, L.B * Wo, L.Cin * 4, L.Cout, {}};
-      return conv1d_dgrad(p, ws, wsf, st);
+      const Conv1dDgradParams p = p_conv1d_dgrad(L, io, Wo);
+      if (!io2) return conv1d_dgrad(p, ws, wsf, st);
+      const Conv1dDgradParams q = p_conv1d_dgrad(L, *io2, Wo);
+      return conv1d_dgrad(p, ws, wsf, st, &q);
     }
     default: {
-      Conv1dFwdParams p{dz, w, nullptr, dx, dact_in, L.B, L.Cout, Wo, L.Cin, L.Win, 0,
-                        L.out_bs, L.in_bs, 0, L.B * L.Win, L.Cin, L.Cout * 4, {}};
-      return conv1d_fwd(p, ws, wsf, st);
+      const Conv1dFwdParams p = p_tconv1d_dgrad(L, io, Wo);
+      if (!io2) return conv1d_fwd(p, ws, wsf, st);
+      const Conv1dFwdParams q = p_tconv1d_dgrad(L, *io2, Wo);
+      return conv1d_fwd(p, ws, wsf, st, &q);
     }
   }
 }
 
-int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float* dw, float* db,
-                     float* ws, size_t ws_floats, int accumulate, hipStream_t st) {
+int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_t ws_floats, int accumulate,
+                     hipStream_t st, const ConvWgradIO* io2) {
   if (!ws || ws_floats < BIAS_WS_FLOATS + 16) {
     set_last_error("conv wgrad: workspace too small");
     return LSHM_ERR_WORKSPACE;
@@ -150,57 +199,82 @@ int conv_layer_wgrad(const ConvLayer& L, const float* x, const float* dz, float*
   const LayerGemm g = wgrad_gemm(L);
   const bool tr = transposed(L);
   // small / big tensors of the underlying strided-conv geometry
-  const float* small = tr ? x : dz;
-  const float* big = tr ? dz : x;
   const long s_bs = tr ? L.in_bs : L.out_bs;
   const long big_bs = tr ? L.out_bs : L.in_bs;
   const int Cs = g.M, Cb = tr ? L.Cout : L.Cin;
+  auto small_of = [&](const ConvWgradIO& q) { return tr ? q.x : q.dz; };
+  auto big_of = [&](const ConvWgradIO& q) { return tr ? q.dz : q.x; };
   float* bias_ws = ws;
   float* gemm_ws = ws + BIAS_WS_FLOATS;
   const size_t gemm_wsf = ws_floats - BIAS_WS_FLOATS;
+  const int G = io2 ? 2 : 1;
   int rc;
   if (L.kind < 2) {
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
-    if (conv2d_wgrad_direct_supported(Cs, Cb, Hs, Ws) && gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
-      rc = conv2d_wgrad_direct(small, s_bs, big, big_bs, dw, L.B, Cs, Cb, Hs, Ws, gemm_ws, gemm_wsf, accumulate, st);
-      goto bias;
+    if (!io2 && conv2d_wgrad_direct_supported(Cs, Cb, Hs, Ws) &&
+        gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
+      rc = conv2d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, L.B, Cs, Cb, Hs, Ws, gemm_ws, gemm_wsf,
+                               accumulate, st);
+    } else {
+      Conv2dWgradParams p{small_of(io), big_of(io), io.dw, L.B, Cs, Hs, Ws, Cb, s_bs, big_bs,
+                          g.M, g.N, g.K, accumulate, {}};
+      if (io2) {
+        Conv2dWgradParams q = p;
+        q.s = small_of(*io2); q.big = big_of(*io2); q.dw = io2->dw;
+        rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st, &q);
+      } else {
+        rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st);
+      }
     }
-    Conv2dWgradParams p{small, big, dw, L.B, Cs, Hs, Ws, Cb, s_bs, big_bs, g.M, g.N, g.K, accumulate, {}};
-    rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st);
   } else {
     const int Ls = tr ? L.Win : Wo, Lb = tr ? Wo : L.Win;
-    if (conv1d_wgrad_direct_supported(Cs, Cb, Ls) && gemm_wsf >= conv1d_wgrad_direct_workspace_floats(Cs, Cb))
+    if (conv1d_wgrad_direct_supported(Cs, Cb, Ls) && gemm_wsf >= G * conv1d_wgrad_direct_workspace_floats(Cs, Cb))
       // weight and bias gradient in one pass (dz is `big` for the transposed conv, `small` otherwise)
-      return conv1d_wgrad_direct(small, s_bs, big, big_bs, dw, db, tr ? 2 : 1, L.Cout, L.B, Cs, Cb, Ls, Lb,
-                                 tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st);
-    Conv1dWgradParams p{small, big, dw, L.B, Cs, Ls, Cb, Lb, tr ? 0 : 1, s_bs, big_bs,
+      return conv1d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.Cout, L.B, Cs,
+                                 Cb, Ls, Lb, tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st,
+                                 io2 ? small_of(*io2) : nullptr, io2 ? big_of(*io2) : nullptr,
+                                 io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr);
+    Conv1dWgradParams p{small_of(io), big_of(io), io.dw, L.B, Cs, Ls, Cb, Lb, tr ? 0 : 1, s_bs, big_bs,
                         g.M, g.N, g.K, accumulate, {}};
-    rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st);
+    if (io2) {
+      Conv1dWgradParams q = p;
+      q.s = small_of(*io2); q.big = big_of(*io2); q.dw = io2->dw;
+      rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st, &q);
+    } else {
+      rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st);
+    }
   }
-bias:
-  if (rc || !db) return rc;
+  if (rc || !io.db) return rc;
+  const float* dz2 = io2 ? io2->dz : nullptr;
+  float* db2 = io2 ? io2->db : nullptr;
   if ((long)L.B * Ho * Wo <= 65536)  // small tensor: one workgroup per channel, no second stage
-    return channel_sum_direct(dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, db, accumulate, st);
+    return channel_sum_direct(io.dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, io.db, accumulate, st, dz2, db2);
   const int Sb = bias_slices(L);
-  rc = channel_sum_partials(dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, bias_ws, Sb, st);
+  float* bias_ws2 = bias_ws + BIAS_WS_FLOATS / 2;
+  rc = channel_sum_partials(io.dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, bias_ws, Sb, st, dz2, bias_ws2);
   if (rc) return rc;
-  return reduce_partials(bias_ws, db, L.Cout, Sb, accumulate, st);
+  return reduce_partials(bias_ws, io.db, L.Cout, Sb, accumulate, st, io2 ? bias_ws2 : nullptr, db2);
 }
 
 // --------------------------------------------------------------------------
 // dense layers
 // --------------------------------------------------------------------------
-int linear_fwd(const float* x, long ldx, const float* w, const float* b, float* y, long ldy, int B,
-               int K, int N, int act, float* ws, size_t wsf, hipStream_t st) {
-  StridedGemmParams p{x, w, b, y, nullptr, ldx, 1, 1, K, ldy, 1, 0, 0, act, B, N, K, {}, nullptr, 0, 0};
-  return strided_gemm(p, false, false, ws, wsf, st);
+int linear_fwd(const LinFwdIO& io, long ldx, long ldy, int B, int K, int N, int act, float* ws, size_t wsf,
+               hipStream_t st, const LinFwdIO* io2) {
+  StridedGemmParams p{io.x, io.w, io.b, io.y, nullptr, ldx, 1, 1, K, ldy, 1, 0, 0, act, B, N, K, {}, nullptr, 0, 0};
+  if (!io2) return strided_gemm(p, false, false, ws, wsf, st);
+  StridedGemmParams q = p;
+  q.a = io2->x; q.b = io2->w; q.bias = io2->b; q.c = io2->y;
+  return strided_gemm(p, false, false, ws, wsf, st, &q);
 }
-int linear_dgrad(const float* dz, long lddz, const float* w, float* dx, long lddx,
-                 const float* xsaved, long ldxs, int B, int K, int N, float* ws, size_t wsf,
-                 hipStream_t st, const float* add, long ldadd, int add_n) {
-  StridedGemmParams p{dz, w, nullptr, dx, xsaved, lddz, 1, K, 1, lddx, 1, ldxs, 1, 0, B, K, N, {},
-                      add, ldadd, add_n};
-  return strided_gemm(p, false, true, ws, wsf, st);
+int linear_dgrad(const LinDgradIO& io, long lddz, long lddx, long ldxs, long ldadd, int add_n, int B, int K,
+                 int N, float* ws, size_t wsf, hipStream_t st, const LinDgradIO* io2) {
+  StridedGemmParams p{io.dz, io.w, nullptr, io.dx, io.xsaved, lddz, 1, K, 1, lddx, 1, ldxs, 1, 0, B, K, N, {},
+                      io.add, ldadd, add_n};
+  if (!io2) return strided_gemm(p, false, true, ws, wsf, st);
+  StridedGemmParams q = p;
+  q.a = io2->dz; q.b = io2->w; q.c = io2->dx; q.dact = io2->xsaved; q.add = io2->add;
+  return strided_gemm(p, false, true, ws, wsf, st, &q);
 }
 __global__ void copy2d_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst,
                               long ldd, int rows, int cols) {
@@ -215,11 +289,14 @@ int copy2d(const float* src, long lds_, float* dst, long ldd, int rows, int cols
                      src, lds_, dst, ldd, rows, cols);
   return check_launch("copy2d");
 }
-// db[n] = sum_b dz[b, n]: one wave per 64 columns would leave the chip idle for B x 768
-// problems, so rows are split over the 4 waves of a block and combined through LDS.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz, long lddz, int B, int N,
-                                                     float* __restrict__ db) {
+// db[n] = sum_b dz[b, n]: rows are split over the 4 waves of a block and combined through LDS;
+// blockIdx.y selects the optional second problem.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz0, const float* __restrict__ dz1,
+                                                     long lddz, int B, int N, float* __restrict__ db0,
+                                                     float* __restrict__ db1) {
   __shared__ float red[256];
+  const float* dz = blockIdx.y ? dz1 : dz0;
+  float* db = blockIdx.y ? db1 : db0;
   const int nl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + nl;
   float acc = 0.f;
@@ -229,13 +306,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   __syncthreads();
   if (part == 0 && n < N) db[n] = (red[nl] + red[64 + nl]) + (red[128 + nl] + red[192 + nl]);
 }
-int linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
-                 int K, int N, float* ws, size_t wsf, hipStream_t st) {
-  StridedGemmParams p{dz, x, nullptr, dw, nullptr, 1, lddz, ldx, 1, K, 1, 0, 0, 0, N, K, B, {},
+int linear_wgrad(const LinWgradIO& io, long ldx, long lddz, int B, int K, int N, float* ws, size_t wsf,
+                 hipStream_t st, const LinWgradIO* io2) {
+  StridedGemmParams p{io.dz, io.x, nullptr, io.dw, nullptr, 1, lddz, ldx, 1, K, 1, 0, 0, 0, N, K, B, {},
                       nullptr, 0, 0};
-  int rc = strided_gemm(p, true, true, ws, wsf, st);
-  if (rc || !db) return rc;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64)), dim3(256), 0, st, dz, lddz, B, N, db);
+  int rc;
+  if (io2) {
+    StridedGemmParams q = p;
+    q.a = io2->dz; q.b = io2->x; q.c = io2->dw;
+    rc = strided_gemm(p, true, true, ws, wsf, st, &q);
+  } else {
+    rc = strided_gemm(p, true, true, ws, wsf, st);
+  }
+  if (rc || !io.db) return rc;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), io2 ? 2 : 1), dim3(256), 0, st, io.dz,
+                     io2 ? io2->dz : nullptr, lddz, B, N, io.db, io2 ? io2->db : nullptr);
   return check_launch("colsum");
 }
 
