@@ -462,16 +462,34 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_direct_kernel(const float* _
   for (int i = 0; i < 16; ++i) bsum[i] = 0.f;
 
   const int tiles_per = Ls / TL;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // software pipeline over tiles: the next tile is loaded into registers while the MFMAs of the
+  // current one run out of LDS
+  constexpr int NS = CS * (TL / 256), NBG = CB * (4 * TL / 256);
+  float rs[NS], rbg[NBG];
+  auto load_tile = [&](int tile) {
     const int b = tile / tiles_per, l0 = (tile - b * tiles_per) * TL;
     const float* sb = small + (long)b * s_bs;
     const float* bb = big + (long)b * big_bs;
-    __syncthreads();
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+      for (int q = 0; q < TL / 256; ++q) rs[cs * (TL / 256) + q] = sb[(long)cs * Ls + l0 + q * 256 + t];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+      for (int q = 0; q < 4 * TL / 256; ++q) {
+        const long g = 4L * l0 - pad + q * 256 + t;
+        rbg[cb * (4 * TL / 256) + q] = (g >= 0 && g < Lb) ? bb[(long)cb * Lb + g] : 0.f;
+      }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile's MFMAs are done with the LDS buffers
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs)
 #pragma unroll
       for (int q = 0; q < TL / 256; ++q) {
-        const float v = sb[(long)cs * Ls + l0 + q * 256 + t];
+        const float v = rs[cs * (TL / 256) + q];
         stile[cs * LDS_S + q * 256 + t] = v;
         if (bias_from == 1) bsum[cs] += v;
       }
@@ -479,13 +497,12 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_direct_kernel(const float* _
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int q = 0; q < 4 * TL / 256; ++q) {
-        const int i = q * 256 + t;
-        const long g = 4L * l0 - pad + i;
-        const float v = (g >= 0 && g < Lb) ? bb[(long)cb * Lb + g] : 0.f;
-        btile[cb * BL + i] = v;
+        const float v = rbg[cb * (4 * TL / 256) + q];
+        btile[cb * BL + q * 256 + t] = v;
         if (bias_from == 2) bsum[cb] += v;
       }
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
 #pragma unroll 4
     for (int s = wave; s < TL / 4; s += 4) {
       const int p = 4 * s + lk;
