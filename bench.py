@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--only-khm", action="store_true", help="time only the K-harmonic kernel (dev aid)")
     return ap.parse_args()
 
@@ -83,12 +84,25 @@ def khm_roofline(dev, N=1 << 20, D=256, K=10, p=4.0):
     ach = nbytes / (ms * 1e-3) / 1e9
     return {"kernel": "khm_kernel+khm_reduce (fused fwd+bwd)", "shape": f"N={N},D={D},K={K}", "bound": "hbm",
             "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "ms": round(ms, 4), "traffic": None}
+            "ms": round(ms, 4), "traffic": _pmc_traffic("khm256_kernel<0, 12, 4>") if N == 1 << 20 else None}
+
+
+def _pmc_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    collected in separate --pmc runs; gfx950 correction 2*FETCH_SIZE; see profiles/r01/hbm_traffic.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "hbm_traffic.json")) as f:
+            return json.load(f)["kernels"][kernel_key]["traffic_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def dominant_kernel_roofline(tr, dev):
-    """conv2d k4s2p1 data-gradient / transposed-conv kernel on the largest layer (tconv5: (B,8,64,64)
-    -> (B,4,128,128)); algorithmic bytes per launch = read input + write output (weights ignored)."""
+    """The largest single convolution launch of the step: the all-parity transposed-conv kernel on
+    tconv5 ((B,8,64,64) -> (B,4,128,128), src/lofar_models.py:57), launched in the closure forward and
+    in the no-grad forward.  Its kernel name maps to exactly this shape, so the rocprofv3 average in
+    profiles/ is directly comparable.  Algorithmic bytes per launch = read input + write output
+    (weights ignored) = 4*(B*8*64*64 + B*4*128*128)."""
     from lshm_amd import _lib as L
     lib = L.load()
     B = tr.B
@@ -99,12 +113,13 @@ def dominant_kernel_roofline(tr, dev):
 
     def run():
         L.check(lib.lshm_conv_fwd(1, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, 8, 4, 64, 64, 0, 0, 0, None, 0, L.stream()))
-    ms = event_time_ms(run, 20)
+    ms = event_time_ms(run, 50, warm=5)
     nbytes = 4.0 * (x.numel() + y.numel())
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "igemm_kernel<Conv2dDgrad> (tconv5 forward)", "bound": "hbm", "achieved": round(ach, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "ms": round(ms, 4),
-            "bytes_per_launch": nbytes, "traffic": None}
+    return {"kernel": "lshm::tconv2d_direct_kernel<8, 4, 4, 64> (tconv5 forward)", "bound": "hbm",
+            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "ms": round(ms, 4), "bytes_per_launch": nbytes,
+            "traffic": _pmc_traffic("tconv2d_direct_kernel<8, 4, 4, 64>") if B == 256 else None}
 
 
 def cpu_baseline(args):
@@ -112,6 +127,9 @@ def cpu_baseline(args):
     loop order for KHM, similarity and augmentation), bounded sample, host cores."""
     from oracle import lshm_oracle as O
     B = args.batch
+    # 16 threads is the measured optimum of this port on the GPU box's 2 x 64-core EPYC 9575F host
+    # (8: 121, 16: 129, 32: 104, 64: 56, 128: 25 patches/s; profiles/cpu_threads_probe.py)
+    torch.set_num_threads(min(args.cpu_threads, os.cpu_count() or 1))
     torch.manual_seed(0)
     cfg = O.StepConfig(K=args.K, bpb=args.bpb, batch_size=B // args.bpb)
     params, M = O.make_params(cfg)

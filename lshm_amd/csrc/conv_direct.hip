@@ -55,33 +55,60 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
       bf[s][j] = ok ? w[(((long)cs * CB + co) * 4 + ky) * 4 + kx] : 0.f;
     }
   }
-  // persistent over tiles: the weight fragments above are loaded once per workgroup
+  // persistent over tiles: the weight fragments above are loaded once per workgroup; the next
+  // tile's patch is fetched into registers while the current tile computes (software pipeline)
   const int tiles_x = Ws / TW, tiles_y = Hs / TH;
+  constexpr int NV4 = (CS * PH * (TW / 4) + 255) / 256, NH = (CS * PH * 2 + 255) / 256;
+  f32x4 rv[NV4];
+  float rh[NH];
+  auto load_tile = [&](int tile) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    const float* sb = small + (long)b * s_bs;
+#pragma unroll
+    for (int q = 0; q < NV4; ++q) {
+      const int i = q * 256 + t;
+      const int rowi = i / (TW / 4), c4 = i - rowi * (TW / 4);
+      const int cs = rowi / PH, py = rowi - cs * PH;
+      const int iy = m0 + py - 1;
+      rv[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CS * PH * (TW / 4) && (unsigned)iy < (unsigned)Hs)
+        rv[q] = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + iy) * Ws + n0 + 4 * c4);
+    }
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+      const int i = q * 256 + t;
+      const int rowi = i >> 1, side = i & 1;
+      const int cs = rowi / PH, py = rowi - cs * PH;
+      const int iy = m0 + py - 1, ix = side ? n0 + TW : n0 - 1;
+      rh[q] = 0.f;
+      if (i < CS * PH * 2 && (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws)
+        rh[q] = sb[((long)cs * Hs + iy) * Ws + ix];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
   const int b = tile / (tiles_x * tiles_y);
   const int tr_ = tile - b * (tiles_x * tiles_y);
   const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
-  const float* sb = small + (long)b * s_bs;
   __syncthreads();  // previous tile's output pass is done with the LDS buffers
-  // ---- stage the input patch (zero outside the image): interior as float4, halo columns as scalars
-  for (int i = t; i < CS * PH * (TW / 4); i += 256) {
-    const int rowi = i / (TW / 4), c4 = i - rowi * (TW / 4);
-    const int cs = rowi / PH, py = rowi - cs * PH;
-    const int iy = m0 + py - 1;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if ((unsigned)iy < (unsigned)Hs) v = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + iy) * Ws + n0 + 4 * c4);
-    float* d = &patch[rowi * PW + 1 + 4 * c4];
-    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+#pragma unroll
+  for (int q = 0; q < NV4; ++q) {
+    const int i = q * 256 + t;
+    if (i < CS * PH * (TW / 4)) {
+      const int rowi = i / (TW / 4), c4 = i - rowi * (TW / 4);
+      float* d = &patch[rowi * PW + 1 + 4 * c4];
+      d[0] = rv[q][0]; d[1] = rv[q][1]; d[2] = rv[q][2]; d[3] = rv[q][3];
+    }
   }
-  for (int i = t; i < CS * PH * 2; i += 256) {
-    const int rowi = i >> 1, side = i & 1;
-    const int cs = rowi / PH, py = rowi - cs * PH;
-    const int iy = m0 + py - 1, ix = side ? n0 + TW : n0 - 1;
-    float v = 0.f;
-    if ((unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws) v = sb[((long)cs * Hs + iy) * Ws + ix];
-    patch[rowi * PW + (side ? PW - 1 : 0)] = v;
+#pragma unroll
+  for (int q = 0; q < NH; ++q) {
+    const int i = q * 256 + t;
+    if (i < CS * PH * 2) patch[(i >> 1) * PW + ((i & 1) ? PW - 1 : 0)] = rh[q];
   }
   __syncthreads();
+  if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
 
   f32x4 acc[MW][NT];
 #pragma unroll
