@@ -276,3 +276,57 @@ def test_fft_features_vs_golden_and_known_answers():
     o[0, 0, 64 + 3, 64 + 5] = 0
     o[0, 0, 64 - 3, 64 - 5] = 0
     assert o.abs().max() < 1e-3
+
+
+def test_full_size_conv_linearity_and_adjointness():
+    """B=256 layer kernels (direct LDS-patch paths) through size-independent properties:
+    linearity in the input and <conv(x), y> == <x, conv^T(y)> (the transposed conv is the adjoint)."""
+    Fh = _F()
+    g = torch.Generator().manual_seed(3)
+    B = 256
+    for cin, cout, hw in ((4, 8, 128), (8, 12, 64)):
+        w = (0.1 * torch.randn(cout, cin, 4, 4, generator=g)).to(DEV)
+        x1 = torch.randn(B, cin, hw, hw, generator=g).to(DEV)
+        x2 = torch.randn(B, cin, hw, hw, generator=g).to(DEV)
+        y = torch.randn(B, cout, hw // 2, hw // 2, generator=g).to(DEV)
+        c1 = Fh.conv_act(x1, w, None, Fh.CONV2D, False)
+        c2 = Fh.conv_act(x2, w, None, Fh.CONV2D, False)
+        c12 = Fh.conv_act(x1 + 2.0 * x2, w, None, Fh.CONV2D, False)
+        assert rel_err(c12, c1 + 2.0 * c2) < 2e-6
+        # ConvTranspose2d with weight (cout, cin, 4, 4) viewed as (Cin_t=cout, Cout_t=cin) is conv^T
+        ty = Fh.conv_act(y, w, None, Fh.TCONV2D, False)
+        lhs = float((c1.double() * y.double()).sum())
+        rhs = float((x1.double() * ty.double()).sum())
+        assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs)) + 1e-3
+    # 1-D pair: conv1d k4 s4 p1 vs transposed k4 s4 p0 are not adjoint (different padding): linearity only
+    w1 = (0.1 * torch.randn(8, 4, 4, generator=g)).to(DEV)
+    a = torch.randn(B, 4, 16384, generator=g).to(DEV)
+    b2 = torch.randn(B, 4, 16384, generator=g).to(DEV)
+    assert rel_err(Fh.conv_act(a - b2, w1, None, Fh.CONV1D, False),
+                   Fh.conv_act(a, w1, None, Fh.CONV1D, False) - Fh.conv_act(b2, w1, None, Fh.CONV1D, False)) < 2e-6
+
+
+def test_full_size_khm_streaming_properties():
+    """N = 2^20 rows (the streaming shape): loss of the concatenation is the mean of the two halves'
+    losses, dM adds, dX rows are independent; K-harmonic loss is invariant to a row permutation."""
+    Fh = _F()
+    g = torch.Generator().manual_seed(9)
+    N, D, K = 1 << 20, 256, 10
+    X = torch.rand(N, D, generator=g).to(DEV)
+    M = torch.rand(K, D, generator=g).to(DEV)
+    Xg, Mg = X.clone().requires_grad_(True), M.clone().requires_grad_(True)
+    loss = Fh.khm_loss(Xg, Mg, 4)
+    loss.backward()
+    halves = []
+    for h in range(2):
+        xh = X[h * (N // 2):(h + 1) * (N // 2)].clone().requires_grad_(True)
+        mh = M.clone().requires_grad_(True)
+        lh = Fh.khm_loss(xh, mh, 4)
+        lh.backward()
+        halves.append((lh.item(), xh.grad, mh.grad))
+    assert abs(loss.item() - 0.5 * (halves[0][0] + halves[1][0])) <= 2e-6 * abs(loss.item())
+    assert rel_err(Mg.grad, 0.5 * (halves[0][2] + halves[1][2])) < 2e-5
+    assert rel_err(Xg.grad[:N // 2], 0.5 * halves[0][1]) < 2e-6
+    perm = torch.randperm(N, generator=g).to(DEV)
+    lp = Fh.khm_loss(X[perm], M, 4)
+    assert abs(lp.item() - loss.item()) <= 2e-6 * abs(loss.item())

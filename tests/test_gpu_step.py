@@ -206,3 +206,95 @@ def test_step_with_k64_clusters():
     assert abs(t["total"] - total.item()) <= 1e-4 * abs(total.item())
     assert abs(t["kdist"] - terms[4].item()) <= 1e-4 * abs(terms[4].item())
     assert rel_err(tr.view("mod.M", tr.grads), grads[-1]) < 2e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size (BASELINE.json configs[1]: B=256, K=10) checks through size-independent properties
+# ---------------------------------------------------------------------------------------------
+def _full_trainer(world=1, batch=256, bs=None):
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    import ctypes as C
+    from lshm_amd import _lib as L
+    tr = KHarmonicTrainer(TrainConfig(Kc=10), batch=batch, batch_per_bline=8,
+                          default_batch=bs if bs is not None else batch // 8, device=DEV)
+    if world != 1:
+        tr._sc.world = world
+        tr.lib.lshm_engine_destroy(tr._h)
+        h = C.c_void_p()
+        L.check(tr.lib.lshm_engine_create(C.byref(tr._sc), C.byref(h)))
+        tr._h = h
+    tr.init_parameters(seed=0)
+    return tr
+
+
+def test_full_size_step_is_bitwise_reproducible_and_finite():
+    """Deterministic reductions everywhere (no float atomics): two runs of 3 iterations at
+    B=256 give bit-identical parameters, multipliers and loss terms."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(256, 4, 128, 128, generator=g)
+    uv = 1000.0 * torch.randn(256, 2, generator=g)
+    outs = []
+    for _ in range(2):
+        tr = _full_trainer()
+        tr.new_minibatch(x.to(DEV), uv.to(DEV))
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize()
+        outs.append((tr.params.clone(), tr.y[2].clone(), tr.terms[:9].clone()))
+        del tr
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][2]).all()
+
+
+def test_full_size_batch_additivity():
+    """Every loss term is a batch mean (or batch independent): the world=2 shares of the two
+    half-batches of a B=256 minibatch sum to the B=256 result (gradients and the 9 terms)."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(256, 4, 128, 128, generator=g)
+    uv = 1000.0 * torch.randn(256, 2, generator=g)
+    y = [0.01 * torch.randn(x.numel(), generator=g) for _ in range(3)]
+    full = _full_trainer()
+    full.new_minibatch(x.to(DEV), uv.to(DEV))
+    for k in range(3):
+        full.y[k].copy_(y[k].to(DEV))
+    full.closure_only()
+    gsum = torch.zeros_like(full.grads)
+    tsum = torch.zeros(9, device=DEV, dtype=torch.float64)
+    for r in range(2):
+        half = _full_trainer(world=2, batch=128, bs=16)
+        half.params.copy_(full.params)
+        sl = slice(r * 128, (r + 1) * 128)
+        half.new_minibatch(x[sl].to(DEV), uv[sl].to(DEV))
+        for k in range(3):
+            half.y[k].copy_(y[k].view(256, -1)[sl].reshape(-1).to(DEV))
+        half.closure_only()
+        gsum += half.grads
+        tsum += half.terms[:9]
+        del half
+    assert rel_err(gsum, full.grads) < 5e-5
+    np.testing.assert_allclose(tsum.cpu().numpy(), full.terms[:9].cpu().numpy(), rtol=5e-6)
+
+
+def test_full_size_directional_derivative():
+    """Gradient check at full size: the loss change along a random direction matches g.d
+    (central difference through the engine's own forward, fp32 -> 2e-2 relative)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(256, 4, 128, 128, generator=g)
+    uv = 1000.0 * torch.randn(256, 2, generator=g)
+    tr = _full_trainer()
+    tr.new_minibatch(x.to(DEV), uv.to(DEV))
+    tr.closure_only()
+    grads = tr.grads.clone()
+    d = torch.randn(tr.nparams, generator=g).to(DEV)
+    d = d * (tr.params.abs() + 1e-3)  # relative perturbation
+    gd = float((grads.double() * d.double()).sum())
+    p0 = tr.params.clone()
+    vals = []
+    for sgn in (1.0, -1.0):
+        tr.params.copy_(p0 + sgn * 2e-3 * d)
+        with torch.no_grad():
+            vals.append(float(tr.lbfgs_closure()))
+    fd = (vals[0] - vals[1]) / (2 * 2e-3)
+    assert abs(fd - gd) <= 2e-2 * abs(gd) + 1e-6, (fd, gd)
