@@ -151,6 +151,16 @@ int lshm_asum_flat(const float* a, long n, double* out, float* workspace, lshm_s
 int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clamp,
                                     lshm_stream_t stream);
 
+/* ---- minibatch patch pipeline (tensor half of get_data_minibatch)      src/lofar_tools.py:113-193
+ * vis (nb, ntime, nfreq, 4 pol, 2) int8, scale (nb, nfreq, 4) fp32  ->  y (px*py*nb, 4, patch, patch),
+ * px = (max(ntime,patch)-patch)/(patch/2)+1, py likewise; patch-major order (:170-173); clamp (:187);
+ * if normalize: (y - mean)/std with torch's unbiased std over the whole minibatch (:190-193).
+ * mean_std[2] (device doubles) always receives the pre-normalisation mean and std. */
+size_t lshm_patches_workspace_floats(void);
+int lshm_patches_from_vis(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int patch,
+                          float clampv, int normalize, float* y, double* mean_std, float* workspace,
+                          lshm_stream_t stream);
+
 /* ---- fused training-step engine (one ADMM iteration)            src/kharmonic_lofar.py:131-202 */
 typedef struct lshm_engine lshm_engine;
 typedef struct lshm_step_config {

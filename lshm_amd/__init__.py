@@ -8,7 +8,10 @@ from . import _lib
 from .lofar_models import AutoEncoder1DCNN, AutoEncoderCNN, AutoEncoderCNN2, Kmeans
 from .kharmonic_lofar import KHarmonicTrainer, TrainConfig
 from .functional import augmented_loss, fft_features
+from .fft_cascade import fft_cascade_forward, fft_cascade_latents
+from .lbfgsnew import LBFGSNew
 
 __all__ = ["AutoEncoderCNN2", "AutoEncoderCNN", "AutoEncoder1DCNN", "Kmeans", "KHarmonicTrainer",
-           "TrainConfig", "augmented_loss", "fft_features"]
+           "TrainConfig", "augmented_loss", "fft_features", "fft_cascade_forward", "fft_cascade_latents",
+           "LBFGSNew"]
 __version__ = "0.1.0"

@@ -79,6 +79,9 @@ _SIGNATURES = {
     "lshm_scale_flat": (c_int, [c_void_p, c_float, c_long, c_void_p]),
     "lshm_dot_flat": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "lshm_asum_flat": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "lshm_patches_workspace_floats": (c_size_t, []),
+    "lshm_patches_from_vis": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
     "lshm_fft2_ortho_shift_cat_clamp": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "lshm_engine_create": (c_int, [C.POINTER(StepConfig), C.POINTER(c_void_p)]),
     "lshm_engine_destroy": (None, [c_void_p]),

@@ -208,6 +208,14 @@ int lshm_asum_flat(const float* a, long n, double* out, float* ws, lshm_stream_t
   return asum_flat(a, n, out, ws, ST(s));
 }
 
+size_t lshm_patches_workspace_floats(void) { return patches_workspace_floats(); }
+int lshm_patches_from_vis(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int patch,
+                          float clampv, int normalize, float* y, double* mean_std, float* ws, lshm_stream_t s) {
+  REQUIRE(vis && scale && y && mean_std && ws && nb > 0 && ntime > 0 && nfreq > 0, "patches_from_vis: bad argument");
+  REQUIRE(patch > 0 && patch % 2 == 0, "patches_from_vis: patch size must be even");
+  return patches_from_vis(vis, scale, nb, ntime, nfreq, patch, clampv, normalize, y, mean_std, ws, ST(s));
+}
+
 int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv, lshm_stream_t s) {
   REQUIRE(x && out && B > 0 && C > 0, "fft2: bad argument");
   return fft2_ortho_shift_cat_clamp(x, out, B, C, clampv, ST(s));

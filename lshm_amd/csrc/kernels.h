@@ -200,6 +200,11 @@ int aug_loss_fwd_bwd(const float* Z, long ldz, int rows, int D, int bpb, int bat
                      float gscale, double* loss, float* dZ, long lddz, int accumulate,
                      hipStream_t st);
 
+// ---- LOFAR minibatch patch pipeline (patches.hip) -----------------------------
+size_t patches_workspace_floats();
+int patches_from_vis(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int P, float clampv,
+                     int normalize, float* y, double* mean_std, float* ws, hipStream_t st);
+
 // ---- batched 2D FFT feature op (fft.hip) ------------------------------------
 int fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv,
                                hipStream_t st);

@@ -208,6 +208,26 @@ def main():
     g["fft/crop"] = yy[:, :, 60:68, 60:68].numpy().copy()
     np.savez_compressed(os.path.join(HERE, "fft.npz"), **g)
 
+    # ---------------- (8) minibatch loader: the reference's get_data_minibatch on a synthetic SAP ----
+    # h5py is absent in the image; the loader only indexes nested groups/datasets, so a stand-in
+    # module whose File() returns dicts of numpy arrays lets the UNMODIFIED reference function run.
+    from tests.h5_fixture import make_sap
+    sap, info = make_sap()
+    fake = types.ModuleType("h5py")
+    fake.File = lambda filename, mode="r": {"measurement": {"saps": {"0": sap}, "info": info}}
+    lt.h5py = fake
+    g8 = {}
+    for normalize in (False, True):
+        np.random.seed(123)
+        px, py, yy8, uv8 = lt.get_data_minibatch(["synthetic.h5"], ["0"], batch_size=3, patch_size=128,
+                                                  normalize_data=normalize, num_channels=4, uvdist=True)
+        tag = "norm" if normalize else "raw"
+        g8[f"{tag}/patchxy"] = np.array([px, py])
+        put(g8, f"{tag}/y", yy8)
+        g8[f"{tag}/y_first"] = yy8[0, :, 60:64, 60:64].numpy().copy()
+        g8[f"{tag}/uv"] = uv8.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "minibatch.npz"), **g8)
+
     # ---------------- (4) full closure + 3 Adam steps ---------------------
     g = {}
     cfg = O.StepConfig(K=4, bpb=4, batch_size=2)

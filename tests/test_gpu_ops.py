@@ -330,3 +330,27 @@ def test_full_size_khm_streaming_properties():
     perm = torch.randperm(N, generator=g).to(DEV)
     lp = Fh.khm_loss(X[perm], M, 4)
     assert abs(lp.item() - loss.item()) <= 2e-6 * abs(loss.item())
+
+
+def test_fft_cascade_matches_oracle_composition():
+    """feature_mode="fft": net -> FFT features of the residual -> 8-channel second-stage AE."""
+    from lshm_amd.fft_cascade import fft_cascade_forward, fft_cascade_latents
+    from lshm_amd.lofar_models import AutoEncoderCNN2
+    hs = torch.tensor(O.DEFAULT_SCALES)
+    sd1 = O.closed_form_state_dict(224, 4, 2, True, "ae2d_rica")
+    sd2 = O.closed_form_state_dict(64, 8, 2, False, "fnet8")
+    net = AutoEncoderCNN2(224, 4, hs, True)
+    fnet = AutoEncoderCNN2(64, 8, hs, False)
+    net.load_state_dict(sd1)
+    fnet.load_state_dict(sd2)
+    net, fnet = net.to(DEV), fnet.to(DEV)
+    net.harmonic_scales = fnet.harmonic_scales = hs.to(DEV)
+    x, uv = O.closed_form_inputs(2, 4)
+    xhat, mu, Fx, Fhat, fmu = fft_cascade_forward(net, fnet, x.to(DEV), uv.to(DEV))
+    xo, muo = O.ae_forward(sd1, x, uv, hs, 2, True)
+    Fo = O.fft_features(x - xo)
+    Fho, fmuo = O.ae_forward(sd2, Fo, uv, hs, 2, False)
+    assert rel_err(xhat, xo) < 1e-5 and rel_err(Fx, Fo) < 1e-5
+    assert rel_err(Fhat, Fho) < 2e-5 and rel_err(fmu, fmuo) < 2e-5
+    Z = fft_cascade_latents(net, fnet, x.to(DEV), uv.to(DEV))
+    assert Z.shape == (2, 224 + 64) and rel_err(Z, torch.cat((muo, fmuo), 1)) < 2e-5
