@@ -183,7 +183,9 @@ def main():
     uv = 1000.0 * torch.randn(B, 2, generator=gen)
     tr.new_minibatch(x.to(dev), uv.to(dev))
 
-    use_graph = not args.no_graph
+    # HIP-graph replay at N=1; with RCCL collectives inside the step the launches stay eager unless
+    # LSHM_DP_GRAPH=1 (capturing the all-reduce is not exercised on the 1-GPU development box)
+    use_graph = not args.no_graph and (world == 1 or os.environ.get("LSHM_DP_GRAPH") == "1")
     if use_graph:
         try:
             tr.capture_graph(warmup=1)
