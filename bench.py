@@ -158,6 +158,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    if os.environ.get("LSHM_SHARE_GPU0") == "1":  # rehearsal of the N>1 path on a one-GPU box
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     pg = None
@@ -165,7 +167,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("LSHM_DIST_BACKEND", "nccl")  # nccl == RCCL over xGMI on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         pg = dist.group.WORLD
 
     if args.only_khm:
