@@ -45,6 +45,11 @@ typedef void* lshm_stream_t; /* hipStream_t */
 
 int lshm_version(void);
 const char* lshm_last_error_string(void);
+/* GEMM-shaped kernels pick their tile configuration per problem shape.  mode 1 (default, or env
+ * LSHM_TUNE=1): the first eager call of a shape times the candidates on the caller's buffers and
+ * caches the winner; mode 0: static heuristic.  force >= 0 pins configuration `force` (0..11) for
+ * every launch (parity tests sweep it); -1 unpins.  Clears the cache. */
+void lshm_set_tuning(int mode, int force);
 
 /* ---- harmonic features: kron(scales, uv) -> cat(sin, cos)   src/lofar_models.py:60-62,145-147
  * uv (B,2), scales (H) -> out (B,4H) */

@@ -37,6 +37,7 @@ class StepConfig(C.Structure):
 _SIGNATURES = {
     "lshm_version": (c_int, []),
     "lshm_last_error_string": (C.c_char_p, []),
+    "lshm_set_tuning": (None, [c_int, c_int]),
     "lshm_uv_harmonics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lshm_conv_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "lshm_conv_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -52,6 +52,7 @@ extern "C" {
 
 int lshm_version(void) { return 100; }
 const char* lshm_last_error_string(void) { return g_err; }
+void lshm_set_tuning(int mode, int force) { igemm_set_tuning(mode, force); }
 
 int lshm_uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, lshm_stream_t s) {
   REQUIRE(uv && scales && out && H > 0 && B >= 0, "uv_harmonics: bad argument");

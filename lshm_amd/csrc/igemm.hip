@@ -13,6 +13,12 @@
 //
 // 64-wide wavefronts: a 256-thread workgroup is 4 waves stacked along M; each
 // wave owns (BM/64) x (BN/16) accumulator tiles.
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include "kernels.h"
 
 namespace lshm {
@@ -600,34 +606,36 @@ struct Strided {
 // Split-K plan: when the output tiling alone cannot fill the chip (deep layers: few output
 // positions, long K; weight gradients: tiny outputs, K = B*H*W), grid.z also splits K and a
 // second kernel combines the slabs.  Needs workspace; without one the launch is unsplit.
-#define IGEMM_BK 16  // K elements staged per main-loop iteration (32 measured 5 % slower end to end)
 struct SplitPlan { int splits, kchunk; };
-static SplitPlan plan_split(long tiles, int K, int M, int N, int zgroups, size_t ws_floats) {
-  SplitPlan sp{1, (K + IGEMM_BK - 1) / IGEMM_BK * IGEMM_BK};
+// target = workgroups the split aims for; 0 disables splitting
+static SplitPlan plan_split(long tiles, int K, int M, int N, int zgroups, size_t ws_floats, int BK, long target) {
+  SplitPlan sp{1, (K + BK - 1) / BK * BK};
   // measured at B=256: with >= ~200 output tiles the second launch costs more than the split gains
-  if (tiles >= 200 || K <= 64 || ws_floats == 0) return sp;
-  long want = (768 + tiles - 1) / tiles;
-  const long maxs = K / 64;  // at least 4 K-steps per split
+  if (target == 0 || tiles >= 200 || K <= 64 || ws_floats == 0) return sp;
+  long want = (target + tiles - 1) / tiles;
+  const long maxs = K / 64;  // at least 64 K elements per split
   if (want > maxs) want = maxs;
   const long Mp = (M + 3) & ~3;
   const long per = Mp * (long)N * zgroups;
   if (per * want > (long)ws_floats) want = (long)ws_floats / per;
   if (want <= 1) return sp;
   int kc = (int)((K + want - 1) / want);
-  kc = (kc + IGEMM_BK - 1) / IGEMM_BK * IGEMM_BK;
+  kc = (kc + BK - 1) / BK * BK;
   sp.kchunk = kc;
   sp.splits = (K + kc - 1) / kc;
-  if (sp.splits <= 1) { sp.splits = 1; sp.kchunk = (K + IGEMM_BK - 1) / IGEMM_BK * IGEMM_BK; }
+  if (sp.splits <= 1) { sp.splits = 1; sp.kchunk = (K + BK - 1) / BK * BK; }
   return sp;
 }
 
+static const long kSplitTargets[3] = {768, 0, 1536};
+
 template <class P, int BM, int BN, int BK>
 static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1, int M, int N, int Z,
-                      float* ws, size_t wsf, hipStream_t st) {
+                      float* ws, size_t wsf, int smode, hipStream_t st) {
   const int G = p1 ? 2 : 1;
   const size_t wsg = ws ? wsf / G : 0;  // split-K scratch per group
   const long tiles = (long)cdiv(M, BM) * cdiv(N, BN) * Z * G;
-  const SplitPlan sp = plan_split(tiles, p0.K, M, N, Z, wsg);
+  const SplitPlan sp = plan_split(tiles, p0.K, M, N, Z, wsg, BK, kSplitTargets[smode]);
   Pair<P> pp;
   pp.p[0] = p0;
   pp.p[1] = p1 ? *p1 : p0;
@@ -648,22 +656,118 @@ static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1
 }
 
 // choose the N tile from the real N so padding waste stays small
-template <class P, int BM>
+template <class P, int BM, int BK>
 static int launch_by_n(const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
-                       float* ws, size_t wsf, hipStream_t st) {
-  if (N <= 16) return launch_cfg<P, BM, 16, IGEMM_BK>(p, p1, M, N, Z, ws, wsf, st);
-  if (N <= 32) return launch_cfg<P, BM, 32, IGEMM_BK>(p, p1, M, N, Z, ws, wsf, st);
-  if (N <= 48 || (N % 48 == 0 && N % 64 != 0)) return launch_cfg<P, BM, 48, IGEMM_BK>(p, p1, M, N, Z, ws, wsf, st);
-  return launch_cfg<P, BM, 64, IGEMM_BK>(p, p1, M, N, Z, ws, wsf, st);
+                       float* ws, size_t wsf, int smode, hipStream_t st) {
+  if (N <= 16) return launch_cfg<P, BM, 16, BK>(p, p1, M, N, Z, ws, wsf, smode, st);
+  if (N <= 32) return launch_cfg<P, BM, 32, BK>(p, p1, M, N, Z, ws, wsf, smode, st);
+  if (N <= 48 || (N % 48 == 0 && N % 64 != 0)) return launch_cfg<P, BM, 48, BK>(p, p1, M, N, Z, ws, wsf, smode, st);
+  return launch_cfg<P, BM, 64, BK>(p, p1, M, N, Z, ws, wsf, smode, st);
+}
+
+// A launch configuration is (M tile 64|128) x (K chunk 16|32) x (split-K mode): index bits 0, 1, 2..3.
+constexpr int kNumConfigs = 12;
+template <class P>
+static int launch_idx(int c, const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
+                      float* ws, size_t wsf, hipStream_t st) {
+  const int smode = c >> 2;
+  switch (c & 3) {
+    case 0: return launch_by_n<P, 64, 16>(p, p1, M, N, Z, ws, wsf, smode, st);
+    case 1: return launch_by_n<P, 128, 16>(p, p1, M, N, Z, ws, wsf, smode, st);
+    case 2: return launch_by_n<P, 64, 32>(p, p1, M, N, Z, ws, wsf, smode, st);
+    default: return launch_by_n<P, 128, 32>(p, p1, M, N, Z, ws, wsf, smode, st);
+  }
+}
+
+// --------------------------------------------------------------------------
+// per-shape autotuning: the first eager call of a (policy, M, N, K, Z, groups) shape times every
+// configuration on the caller's own buffers (outputs are overwritten, so re-running is harmless)
+// and caches the winner for the life of the process.  Calls that accumulate into their output or
+// arrive while the stream is being captured take the static heuristic and leave the cache alone.
+// --------------------------------------------------------------------------
+struct TuneKey {
+  int pol, M, N, K, Z, G;
+  bool operator<(const TuneKey& o) const {
+    return std::tie(pol, M, N, K, Z, G) < std::tie(o.pol, o.M, o.N, o.K, o.Z, o.G);
+  }
+};
+static std::mutex g_tune_mu;
+static std::map<TuneKey, int> g_tuned;
+static int g_tune_mode = -1;   // -1: read LSHM_TUNE on first use; 0 off; 1 on
+static int g_tune_force = -1;  // >= 0: every launch uses this configuration (tests)
+static int g_next_policy = 0;
+template <class P>
+static int policy_id() {
+  static const int id = g_next_policy++;
+  return id;
+}
+template <class T>
+static auto accumulates(const T& p, int) -> decltype(p.accumulate, true) { return p.accumulate != 0; }
+template <class T>
+static bool accumulates(const T&, long) { return false; }
+
+void igemm_set_tuning(int mode, int force) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  g_tune_mode = mode;
+  g_tune_force = force;
+  g_tuned.clear();
 }
 
 template <class P>
 static int launch_auto(const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
                        float* ws, size_t wsf, hipStream_t st) {
-  // small-M problems (deep layers, weight gradients): 64-row tiles give more workgroups
-  if (M <= 64 || (long)cdiv(M, 128) * cdiv(N, 64) * Z < 256)
-    return launch_by_n<P, 64>(p, p1, M, N, Z, ws, wsf, st);
-  return launch_by_n<P, 128>(p, p1, M, N, Z, ws, wsf, st);
+  // static heuristic: small-M problems (deep layers, weight gradients) get 64-row tiles for more workgroups
+  const int heuristic = (M <= 64 || (long)cdiv(M, 128) * cdiv(N, 64) * Z < 256) ? 0 : 1;
+  int mode, force;
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    if (g_tune_mode < 0) {
+      const char* e = getenv("LSHM_TUNE");
+      g_tune_mode = e ? atoi(e) != 0 : 1;
+    }
+    mode = g_tune_mode;
+    force = g_tune_force;
+  }
+  if (force >= 0) return launch_idx<P>(force % kNumConfigs, p, p1, M, N, Z, ws, wsf, st);
+  if (!mode) return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st);
+  const TuneKey key{policy_id<P>(), M, N, p.K, Z, p1 ? 2 : 1};
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) return launch_idx<P>(it->second, p, p1, M, N, Z, ws, wsf, st);
+  }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(st, &cap);
+  if (cap != hipStreamCaptureStatusNone || accumulates(p, 0) || (p1 && accumulates(*p1, 0)))
+    return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st);
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
+    return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st);
+  int best = heuristic;
+  float best_ms = 1e30f;
+  for (int c = 0; c < kNumConfigs; ++c) {
+    if ((c & 1) && M <= 64) continue;
+    int rc = launch_idx<P>(c, p, p1, M, N, Z, ws, wsf, st);  // warm
+    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    (void)hipEventRecord(e0, st);
+    for (int r = 0; r < 3; ++r) launch_idx<P>(c, p, p1, M, N, Z, ws, wsf, st);
+    (void)hipEventRecord(e1, st);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best_ms) { best_ms = ms; best = c; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tuned[key] = best;
+  }
+  if (getenv("LSHM_TUNE_LOG"))
+    fprintf(stderr, "[lshm tune] policy %d M=%d N=%d K=%d Z=%d G=%d -> cfg %d (BM %d BK %d split-mode %d) %.1f us\n",
+            key.pol, M, N, p.K, Z, key.G, best, (best & 1) ? 128 : 64, (best & 2) ? 32 : 16, best >> 2,
+            best_ms * 1000.f / 3);
+  return launch_idx<P>(best, p, p1, M, N, Z, ws, wsf, st);
 }
 
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {
@@ -671,7 +775,7 @@ size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {
   const long Mp = (M + 3) & ~3;
   const long tiles = (long)cdiv(M, 128) * cdiv(N, 64) * zgroups;
   if (tiles >= 200 || K <= 64) return 0;
-  long want = 768;  // upper bound on splits (tiles >= 1)
+  long want = 1536;  // upper bound on splits (tiles >= 1)
   const long maxs = K / 64;
   if (want > maxs) want = maxs;
   return (size_t)(Mp * (long)N * zgroups * want);

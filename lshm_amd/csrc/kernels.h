@@ -75,6 +75,8 @@ int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t 
 int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
                  hipStream_t st, const StridedGemmParams* p1 = nullptr);
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
+// mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
+void igemm_set_tuning(int mode, int force);
 
 // ---- direct LDS-patch kernels for the outer 2-D layers (conv_direct.hip) ----
 bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws);

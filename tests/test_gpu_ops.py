@@ -32,6 +32,27 @@ def test_harmonics():
 @pytest.mark.parametrize("kind", list(KINDS))
 @pytest.mark.parametrize("i", range(6))
 def test_conv_layer_fwd_bwd_vs_golden(kind, i):
+    _check_conv_layer(kind, i)
+
+
+@pytest.mark.parametrize("cfg", range(12))
+def test_every_gemm_tile_configuration(cfg):
+    """The implicit-GEMM launcher autotunes over 12 (M tile, K chunk, split-K) configurations; pin each
+    one in turn so that whichever the tuner picks on a given box has been checked against the goldens."""
+    from lshm_amd import _lib
+    lib = _lib.load()
+    lib.lshm_set_tuning(1, cfg)
+    try:
+        for kind in KINDS:
+            for i in (1, 3, 5):
+                _check_conv_layer(kind, i)
+        test_linear_vs_torch(5, 784, 224, True)
+        test_linear_vs_torch(64, 32, 768, False)
+    finally:
+        lib.lshm_set_tuning(1, -1)
+
+
+def _check_conv_layer(kind, i):
     g = load_golden("convops")
     Fh = _F()
     ch = O.CH
