@@ -305,7 +305,8 @@ bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws) {
 size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)768 * Cs * Cb * 16; }
 
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, int B, int Cs,
-                        int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st) {
+                        int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
+                        GradJobs* defer) {
   if (wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv2d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   int grid;
   if (Cs == 8 && Cb == 4) {
@@ -324,7 +325,12 @@ int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
   }
   int rc = check_launch("conv2d_wgrad_direct");
   if (rc) return rc;
-  return reduce_partials(ws, dw, (long)Cs * Cb * 16, grid, accumulate, st);
+  const int nw = Cs * Cb * 16;
+  if (defer) {
+    defer->sums.push_back(SumJob{ws, dw, nw, nw, grid, 0, 0, 0, 0, accumulate, 0});
+    return LSHM_OK;
+  }
+  return reduce_partials(ws, dw, nw, grid, accumulate, st);
 }
 
 }  // namespace lshm
@@ -579,7 +585,7 @@ size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)768
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
                         size_t wsf, int accumulate, hipStream_t st, const float* small2, const float* big2,
-                        float* dw2, float* db2) {
+                        float* dw2, float* db2, GradJobs* defer) {
   const int G = small2 ? 2 : 1;
   if (wsf < G * conv1d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv1d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   int grid, slab;
@@ -601,6 +607,15 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
   }
   int rc = check_launch("conv1d_wgrad_direct");
   if (rc) return rc;
+  if (defer) {
+    const int nw = Cs * Cb * 4;
+    for (int g = 0; g < G; ++g) {
+      const float* part = g ? ws2 : ws;
+      defer->sums.push_back(SumJob{part, g ? dw2 : dw, slab, nw, grid, 0, 0, 0, 0, accumulate, 0});
+      if (bias_from) defer->sums.push_back(SumJob{part + nw, g ? db2 : db, slab, nbias, grid, 0, 0, 0, 0, accumulate, 0});
+    }
+    return LSHM_OK;
+  }
   // strided reduces over the slabs: weights, then (optionally) the bias entries
   rc = reduce_partials_strided(ws, slab, dw, (long)Cs * Cb * 4, grid, accumulate, st, small2 ? ws2 : nullptr, dw2);
   if (rc || !bias_from) return rc;

@@ -1,0 +1,144 @@
+// Deferred reductions of a backward pass: every split-K combine, per-workgroup partial sum and bias
+// gradient that the weight-gradient launches of one autoencoder leave behind is finished here by
+// two multi-job launches instead of ~60 tiny ones (each of which costs a few microseconds of
+// dispatch whatever its size).  Summation order inside a job is fixed: results are bitwise
+// reproducible and independent of what else runs on the device.
+#include "kernels.h"
+
+namespace lshm {
+
+constexpr int kJobsPerLaunch = 40;  // keeps the by-value tables under the 4 KiB kernel-argument limit
+
+struct ChanTable {
+  ChanJob job[kJobsPerLaunch];
+  int blk0[kJobsPerLaunch + 1];
+  int njobs;
+};
+struct SumTable {
+  SumJob job[kJobsPerLaunch];
+  int blk0[kJobsPerLaunch + 1];
+  int njobs;
+};
+
+template <class T>
+__device__ __forceinline__ int find_job(const T& tab, int blk) {
+  int j = 0;
+  while (j + 1 < tab.njobs && blk >= tab.blk0[j + 1]) ++j;
+  return j;
+}
+
+// stage 1 of the bias gradients: workgroup = (job, channel, chunk)
+__global__ __launch_bounds__(256) void chan_partials_multi_kernel(const ChanTable tab) {
+  __shared__ float red[16];
+  const int jx = find_job(tab, blockIdx.x);
+  const ChanJob& J = tab.job[jx];
+  const int lb = blockIdx.x - tab.blk0[jx];
+  const int c = lb / J.chunks, ch = lb - c * J.chunks;
+  const long total4 = (long)J.B * J.HW / 4;
+  const long len4 = (total4 + J.chunks - 1) / J.chunks;
+  const long beg = ch * len4;
+  const long end = beg + len4 < total4 ? beg + len4 : total4;
+  const float* base = J.dz + (long)c * J.HW;
+  float acc = 0.f;
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    const long e = i * 4;
+    const long b = e / J.HW, pos = e - b * J.HW;
+    const float4 v = *reinterpret_cast<const float4*>(base + b * J.bs + pos);
+    acc += (v.x + v.y) + (v.z + v.w);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) J.partial[(long)ch * J.C + c] = acc;
+}
+
+// stage 2: every remaining sum.  lpo lanes share an output (s strided by lpo), combined by butterflies.
+__global__ __launch_bounds__(256) void sum_jobs_multi_kernel(const SumTable tab) {
+  const int jx = find_job(tab, blockIdx.x);
+  const SumJob& J = tab.job[jx];
+  const int lb = blockIdx.x - tab.blk0[jx];
+  const int lpo = J.lpo;
+  const int opb = 256 / lpo;
+  const int sl = threadIdx.x % lpo;
+  const long j = (long)lb * opb + threadIdx.x / lpo;
+  float acc = 0.f;
+  if (j < J.n) {
+    const float* src = J.src + j;
+    if (lpo == 1) {
+      int s = 0;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+      for (; s + 4 <= J.S; s += 4) {
+        a0 += src[(long)s * J.stride];
+        a1 += src[(long)(s + 1) * J.stride];
+        a2 += src[(long)(s + 2) * J.stride];
+        a3 += src[(long)(s + 3) * J.stride];
+      }
+      for (; s < J.S; ++s) a0 += src[(long)s * J.stride];
+      acc = (a0 + a1) + (a2 + a3);
+    } else {
+      for (int s = sl; s < J.S; s += lpo) acc += src[(long)s * J.stride];
+    }
+  }
+  for (int off = lpo >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (sl == 0 && j < J.n) {
+    long o = j;
+    if (J.Mp) {
+      const int col = (int)(j / J.Mp), row = (int)(j - (long)col * J.Mp);
+      if (row >= J.M) return;
+      o = (long)row * J.rs + (long)col * J.cs;
+    }
+    J.dst[o] = J.accumulate ? J.dst[o] + acc : acc;
+  }
+}
+
+bool GradJobs::add_channel_sum(const float* dz, long bs, int B, int C, long HW, float* db, int accumulate) {
+  if (HW % 4 != 0 || bs % 4 != 0 || (reinterpret_cast<uintptr_t>(dz) & 15)) return false;
+  const long per_channel = (long)B * HW;
+  int chunks = (int)((per_channel + 8191) / 8192);
+  if (chunks < 1) chunks = 1;
+  if (chunks > 256) chunks = 256;
+  float* partial = take((size_t)chunks * C);
+  if (!partial) return false;
+  chan.push_back(ChanJob{dz, partial, bs, HW, B, C, chunks});
+  sums.push_back(SumJob{partial, db, C, C, chunks, 0, 0, 0, 0, accumulate, 0});
+  return true;
+}
+
+int grad_jobs_finish(GradJobs& jobs, hipStream_t st) {
+  for (size_t j0 = 0; j0 < jobs.chan.size(); j0 += kJobsPerLaunch) {
+    ChanTable tab;
+    tab.njobs = (int)std::min<size_t>(kJobsPerLaunch, jobs.chan.size() - j0);
+    int blk = 0;
+    for (int j = 0; j < tab.njobs; ++j) {
+      tab.job[j] = jobs.chan[j0 + j];
+      tab.blk0[j] = blk;
+      blk += tab.job[j].C * tab.job[j].chunks;
+    }
+    tab.blk0[tab.njobs] = blk;
+    if (blk == 0) continue;
+    hipLaunchKernelGGL(chan_partials_multi_kernel, dim3(blk), dim3(256), 0, st, tab);
+    int rc = check_launch("chan_partials_multi");
+    if (rc) return rc;
+  }
+  for (size_t j0 = 0; j0 < jobs.sums.size(); j0 += kJobsPerLaunch) {
+    SumTable tab;
+    tab.njobs = (int)std::min<size_t>(kJobsPerLaunch, jobs.sums.size() - j0);
+    int blk = 0;
+    for (int j = 0; j < tab.njobs; ++j) {
+      SumJob& J = tab.job[j];
+      J = jobs.sums[j0 + j];
+      // plenty of outputs: one lane each (coalesced along j); few outputs: lanes split the S partials
+      J.lpo = (J.n >= 4096 || J.S < 8) ? 1 : (J.S >= 128 ? 64 : 16);
+      tab.blk0[j] = blk;
+      blk += cdiv(J.n, 256 / J.lpo);
+    }
+    tab.blk0[tab.njobs] = blk;
+    if (blk == 0) continue;
+    hipLaunchKernelGGL(sum_jobs_multi_kernel, dim3(blk), dim3(256), 0, st, tab);
+    int rc = check_launch("sum_jobs_multi");
+    if (rc) return rc;
+  }
+  jobs.chan.clear();
+  jobs.sums.clear();
+  return LSHM_OK;
+}
+
+}  // namespace lshm

@@ -67,14 +67,17 @@ struct lshm_engine {
   // shapes) run as pairs inside the same launches, each with its own lane; o_part/o_wpart of a
   // lane are adjacent and together form the split-K scratch of a paired launch.
   struct Lane {
-    size_t o_gA, o_gB, o_dcat1, o_dz1, o_dzmu, o_dcat3, o_dd0, o_part, o_wpart;
+    size_t o_gdec[6], o_genc[6];  // input gradients of decoder / encoder layer i (kept until the deferred sums ran)
+    size_t o_dcat1, o_dz1, o_dzmu, o_dcat3, o_dd0, o_part, o_wpart;
+    size_t o_defer;               // scratch of the backward's deferred reductions (GradJobs)
   } lane[2];
-  // optional side stream: weight-gradient kernels of a layer run beside its data-gradient kernel
+  size_t defer_floats;
+  // optional side stream: netF beside netT (LSHM_FORK=1)
   hipStream_t wstream;
   std::vector<hipEvent_t> events;
   mutable size_t next_event;
   bool side_ok;
-  bool pair_mode;  // LSHM_PAIR=1: netT/netF share launches instead of running on two streams
+  bool pair_mode;  // netT/netF share launches (default) instead of running on two streams (LSHM_FORK=1)
   hipEvent_t take_event() const { return events[next_event++ % events.size()]; }
   size_t part_floats;
   size_t ws_floats;
@@ -230,41 +233,14 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
   return LSHM_OK;
 }
 
-// The weight gradient of a conv layer only needs dz and the saved input, both complete on `st`:
-// fork it onto the side stream (own split-K scratch: lane 1's regions) and join before dz's
-// buffer is reused.  Non-nested fork/join pairs capture fine into a HIP graph on ROCm 7.2.
-static int wgrad_fork(const lshm_engine* e, bool side, int ln, const ConvLayer& L, const ConvWgradIO& io,
-                      const ConvWgradIO* io2, float* ws, hipStream_t st, hipEvent_t* ev_w) {
-  *ev_w = nullptr;
-  if (!side || !e->side_ok)  // in-line, on the lane's own scratch
-    return conv_layer_wgrad(L, io, ws + e->lane[ln].o_part, e->part_floats * (io2 ? 2 : 1), 0, st, io2);
-  float* wpart = ws + e->lane[1].o_part;
-  const size_t wpf = e->part_floats * 2;
-  hipEvent_t ev_dz = e->take_event();
-  hipError_t he;
-  if ((he = hipEventRecord(ev_dz, st)) != hipSuccess || (he = hipStreamWaitEvent(e->wstream, ev_dz, 0)) != hipSuccess) {
-    set_last_error("engine: stream fork failed");
-    return (int)he;
-  }
-  int rc = conv_layer_wgrad(L, io, wpart, wpf, 0, e->wstream, io2);
-  if (rc) return rc;
-  *ev_w = e->take_event();
-  if ((he = hipEventRecord(*ev_w, e->wstream)) != hipSuccess) { set_last_error("engine: event record failed"); return (int)he; }
-  return LSHM_OK;
-}
-static int wgrad_join(const lshm_engine* e, hipEvent_t ev_w, hipStream_t st) {
-  if (!ev_w) return LSHM_OK;
-  hipError_t he = hipStreamWaitEvent(st, ev_w, 0);
-  if (he != hipSuccess) { set_last_error("engine: stream join failed"); return (int)he; }
-  return LSHM_OK;
-}
-
 // Backward of one (G == 1) or two same-shape (G == 2) autoencoders.  dz_out[g]: gradient w.r.t. the
 // AE output (B,C,P*P); gMu (B,D) holds the gradient w.r.t. the latents; dinput[g]: gradient w.r.t.
 // the AE input, or null.  With G == 2, lane 0 holds problem 0's scratch and lane 1 problem 1's.
+// Weight-gradient launches leave their closing sums (split-K slabs, workgroup partials, bias
+// gradients) on a job list that two launches finish at the end; every dz therefore has its own buffer.
 static int ae_backward(const lshm_engine* e, int G, const int* idx, const float* prm, float* grd,
                        const float* const* input, const float* const* dz_out, float* const* dinput, float* ws,
-                       int ln, bool side_wgrad, hipStream_t st) {
+                       int ln, hipStream_t st) {
   const lshm_step_config& c = e->cfg;
   const AEPlan& a0 = e->ae[idx[0]];
   const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
@@ -274,7 +250,9 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   auto A = [&](int g) -> const AEPlan& { return e->ae[idx[g]]; };
   auto LA = [&](int g) -> const lshm_engine::Lane& { return e->lane[ln + g]; };
   int rc;
-  hipEvent_t ev_w = nullptr;
+  GradJobs jobs;
+  jobs.scratch = ws + e->lane[ln].o_defer;
+  jobs.cap = e->defer_floats;
   const float* dz[2];
   for (int g = 0; g < G; ++g) dz[g] = dz_out[g];
   // ---- decoder, last layer first
@@ -284,20 +262,19 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     float* dx[2];
     for (int g = 0; g < G; ++g) {
       const float* xin = (i == 0) ? ws + A(g).d0 : ws + A(g).dact[i - 1];
-      dx[g] = (i == 0) ? ws + LA(g).o_dd0 : ws + ((i & 1) ? LA(g).o_gA : LA(g).o_gB);
+      dx[g] = (i == 0) ? ws + LA(g).o_dd0 : ws + LA(g).o_gdec[i];
       wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).tw[i], grd + A(g).tb[i]};
       // previous activation is an ELU output (except fc3's output feeding tconv0)
       dg[g] = ConvDgradIO{dz[g], prm + A(g).tw[i], dx[g], i == 0 ? nullptr : xin};
     }
-    if ((rc = wgrad_fork(e, side_wgrad, ln, a0.dec[i], wg[0], G > 1 ? &wg[1] : nullptr, ws, st, &ev_w))) return rc;
+    if ((rc = conv_layer_wgrad(a0.dec[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
     if ((rc = conv_layer_dgrad(a0.dec[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
-    if ((rc = wgrad_join(e, ev_w, st))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
   LinWgradIO lw[2];
   LinDgradIO ld[2];
   auto wgrad = [&](long ldx, long lddz, int K, int N) {
-    return linear_wgrad(lw[0], ldx, lddz, B, K, N, part, pf, st, G > 1 ? &lw[1] : nullptr);
+    return linear_wgrad(lw[0], ldx, lddz, B, K, N, nullptr, 0, st, G > 1 ? &lw[1] : nullptr, &jobs);
   };
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr);
@@ -345,20 +322,16 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     float* dx[2];
     for (int g = 0; g < G; ++g) {
       const float* xin = (i == 0) ? input[g] : ws + A(g).act[i - 1];
-      dx[g] = (i == 0) ? dinput[g] : ws + ((i & 1) ? LA(g).o_gA : LA(g).o_gB);
+      dx[g] = (i == 0) ? dinput[g] : ws + LA(g).o_genc[i];
       wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).cw[i], grd + A(g).cb[i]};
       dg[g] = ConvDgradIO{dz[g], prm + A(g).cw[i], dx[g], i == 0 ? nullptr : xin};
     }
-    if ((rc = wgrad_fork(e, side_wgrad, ln, a0.enc[i], wg[0], G > 1 ? &wg[1] : nullptr, ws, st, &ev_w))) return rc;
-    if (i == 0 && !dinput[0]) {
-      if ((rc = wgrad_join(e, ev_w, st))) return rc;
-      break;
-    }
+    if ((rc = conv_layer_wgrad(a0.enc[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
+    if (i == 0 && !dinput[0]) break;
     if ((rc = conv_layer_dgrad(a0.enc[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
-    if ((rc = wgrad_join(e, ev_w, st))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
-  return LSHM_OK;
+  return grad_jobs_finish(jobs, st);
 }
 
 // scal layout (doubles): [0..6] sums7, [7] khm sum, [8] sim, [9..11] rica x3, [12] aug, [13..] aug partials
@@ -397,7 +370,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   const float* in12[2] = {ws + e->o_row, ws + e->o_col};
   if (e->pair_mode || !e->side_ok)  // every launch carries both problems
     return ae_forward(e, 2, i12, prm, in12, ws, 0, st);
-  // or: two streams side by side (measured ~5 % faster than paired launches at B=256)
+  // or: two streams side by side (LSHM_FORK=1; no faster than paired launches since the reductions are deferred)
   hipEvent_t evf = e->take_event();
   if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(e->wstream, evf, 0) != hipSuccess) {
     set_last_error("engine: stream fork failed");
@@ -474,15 +447,15 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     const float* dz12[2] = {ws + e->o_gx2, ws + e->o_gx3c};
     float* di12[2] = {ws + e->o_gT, ws + e->o_gFc};
     if (e->pair_mode || !e->side_ok) {
-      if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, 0, e->pair_mode, st))) return rc;
+      if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, 0, st))) return rc;
     } else {
       hipEvent_t evf = e->take_event();
       if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(e->wstream, evf, 0) != hipSuccess) {
         set_last_error("engine: stream fork failed");
         return LSHM_ERR_ARG;
       }
-      if ((rc = ae_backward(e, 1, i12, prm, grd, in12, dz12, di12, ws, 0, false, st))) return rc;
-      if ((rc = ae_backward(e, 1, i12 + 1, prm, grd, in12 + 1, dz12 + 1, di12 + 1, ws, 1, false, e->wstream))) return rc;
+      if ((rc = ae_backward(e, 1, i12, prm, grd, in12, dz12, di12, ws, 0, st))) return rc;
+      if ((rc = ae_backward(e, 1, i12 + 1, prm, grd, in12 + 1, dz12 + 1, di12 + 1, ws, 1, e->wstream))) return rc;
       hipEvent_t evj = e->take_event();
       if (hipEventRecord(evj, e->wstream) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
         set_last_error("engine: stream join failed");
@@ -496,8 +469,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     const float* in0[1] = {x};
     const float* dz0[1] = {ws + e->o_gx1};
     float* di0[1] = {nullptr};
-    // AE1 runs alone: its weight gradients go beside the data-gradient chain (non-nested fork)
-    if ((rc = ae_backward(e, 1, i0, prm, grd, in0, dz0, di0, ws, 0, true, st))) return rc;
+    if ((rc = ae_backward(e, 1, i0, prm, grd, in0, dz0, di0, ws, 0, st))) return rc;
   }
   return LSHM_OK;
 }
@@ -543,12 +515,27 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->o_gT = take(cur, (size_t)B * img);
   e->o_gFc = take(cur, (size_t)B * img);
   e->o_gx1 = take(cur, (size_t)B * img);
-  const size_t gmax = (size_t)B * 8 * (cfg->P / 2) * (cfg->P / 2);
   const int Lmax = cfg->L > cfg->Lt ? cfg->L : cfg->Lt;
+  // deferred-reduction scratch of one backward: the 2-D autoencoder alone or the two 1-D ones as a pair
+  e->defer_floats = 0;
+  for (int a = 0; a < 2; ++a) {
+    const int G = a == 0 ? 1 : 2;
+    const int La = a == 0 ? cfg->L : cfg->Lt;
+    size_t need = 0;
+    for (int i = 0; i < 6; ++i)
+      need += conv_wgrad_defer_floats(e->ae[a].enc[i], G) + conv_wgrad_defer_floats(e->ae[a].dec[i], G);
+    need += linear_wgrad_defer_floats(B, La + e->hdim, 768, G) + linear_wgrad_defer_floats(B, 768 + e->hdim, La, G) +
+            2 * linear_wgrad_defer_floats(B, e->hdim, e->hdim, G) + 2 * linear_wgrad_defer_floats(B, La, La, G);
+    if (need > e->defer_floats) e->defer_floats = need;
+  }
   for (int ln = 0; ln < 2; ++ln) {
     lshm_engine::Lane& la = e->lane[ln];
-    la.o_gA = take(cur, gmax);
-    la.o_gB = take(cur, gmax);
+    for (int i = 1; i < 6; ++i) {  // same sizes for the 2-D and the 1-D autoencoders
+      la.o_gdec[i] = take(cur, (size_t)B * e->ae[0].dec[i].in_bs);
+      la.o_genc[i] = take(cur, (size_t)B * e->ae[0].enc[i].in_bs);
+    }
+    la.o_gdec[0] = la.o_genc[0] = 0;
+    la.o_defer = take(cur, e->defer_floats);
     la.o_dcat1 = take(cur, (size_t)B * (768 + e->hdim));
     la.o_dz1 = take(cur, (size_t)B * Lmax);
     la.o_dzmu = take(cur, (size_t)B * Lmax);
@@ -583,13 +570,13 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     e->lane[ln].o_part = take(cur, pf);
     e->lane[ln].o_wpart = take(cur, pf);
   }
-  // side stream + events (host objects; absent on a machine without a HIP device or with LSHM_SINGLE_STREAM)
+  // side stream + events, fork mode only (host objects; absent on a machine without a HIP device)
   e->side_ok = false;
   e->next_event = 0;
-  e->pair_mode = getenv("LSHM_PAIR") != nullptr;
+  e->pair_mode = getenv("LSHM_FORK") == nullptr;
   {
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && !getenv("LSHM_SINGLE_STREAM")) {
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && !e->pair_mode) {
       bool ok = hipStreamCreateWithFlags(&e->wstream, hipStreamNonBlocking) == hipSuccess;
       e->events.resize(128);
       for (size_t i = 0; i < e->events.size() && ok; ++i)

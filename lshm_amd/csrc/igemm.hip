@@ -600,6 +600,24 @@ struct Strided {
   }
 };
 
+// Output description of a weight-gradient problem for a deferred split-K combine (see GradJobs);
+// false: this problem's epilogue cannot be expressed as a plain sum and must run in place.
+static bool describe_output(const Conv2dWgradParams& p, SumJob& J) {
+  J.dst = p.dw; J.rs = p.N; J.cs = 1; J.accumulate = p.accumulate;
+  return true;
+}
+static bool describe_output(const Conv1dWgradParams& p, SumJob& J) {
+  J.dst = p.dw; J.rs = p.N; J.cs = 1; J.accumulate = p.accumulate;
+  return true;
+}
+static bool describe_output(const StridedGemmParams& p, SumJob& J) {
+  if (p.bias || p.act || p.add || p.dact) return false;
+  J.dst = p.c; J.rs = (int)p.scm; J.cs = (int)p.scn; J.accumulate = 0;
+  return true;
+}
+template <class T>
+static bool describe_output(const T&, SumJob&) { return false; }
+
 // --------------------------------------------------------------------------
 // launch helpers
 // --------------------------------------------------------------------------
@@ -631,7 +649,7 @@ static const long kSplitTargets[3] = {768, 0, 1536};
 
 template <class P, int BM, int BN, int BK>
 static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1, int M, int N, int Z,
-                      float* ws, size_t wsf, int smode, hipStream_t st) {
+                      float* ws, size_t wsf, int smode, hipStream_t st, GradJobs* defer) {
   const int G = p1 ? 2 : 1;
   const size_t wsg = ws ? wsf / G : 0;  // split-K scratch per group
   const long tiles = (long)cdiv(M, BM) * cdiv(N, BN) * Z * G;
@@ -649,6 +667,19 @@ static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1
   hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK>), grid, dim3(256), 0, st, pp);
   int rc = check_launch("igemm");
   if (rc || sp.splits == 1) return rc;
+  if (defer && Z == 1) {  // leave the slabs where they are; the combine joins the backward's job list
+    SumJob J[2];
+    bool ok = true;
+    for (int g = 0; g < G; ++g) {
+      const long Mp = (M + 3) & ~3;
+      J[g] = SumJob{pp.p[g].sk.partial, nullptr, (long)N * Mp, (int)(N * Mp), sp.splits, (int)Mp, M, 0, 0, 0, 0};
+      ok = ok && describe_output(pp.p[g], J[g]);
+    }
+    if (ok) {
+      for (int g = 0; g < G; ++g) defer->sums.push_back(J[g]);
+      return rc;
+    }
+  }
   const long nout = (long)((M + 3) / 4) * N * Z;
   const int OL = nout >= 16384 ? 64 : 16;
   hipLaunchKernelGGL((splitk_epilogue_kernel<P>), dim3(cdiv(nout, OL), G), dim3(256), 0, st, pp, Z, OL);
@@ -658,24 +689,25 @@ static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1
 // choose the N tile from the real N so padding waste stays small
 template <class P, int BM, int BK>
 static int launch_by_n(const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
-                       float* ws, size_t wsf, int smode, hipStream_t st) {
-  if (N <= 16) return launch_cfg<P, BM, 16, BK>(p, p1, M, N, Z, ws, wsf, smode, st);
-  if (N <= 32) return launch_cfg<P, BM, 32, BK>(p, p1, M, N, Z, ws, wsf, smode, st);
-  if (N <= 48 || (N % 48 == 0 && N % 64 != 0)) return launch_cfg<P, BM, 48, BK>(p, p1, M, N, Z, ws, wsf, smode, st);
-  return launch_cfg<P, BM, 64, BK>(p, p1, M, N, Z, ws, wsf, smode, st);
+                       float* ws, size_t wsf, int smode, hipStream_t st, GradJobs* defer) {
+  if (N <= 16) return launch_cfg<P, BM, 16, BK>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+  if (N <= 32) return launch_cfg<P, BM, 32, BK>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+  if (N <= 48 || (N % 48 == 0 && N % 64 != 0))
+    return launch_cfg<P, BM, 48, BK>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+  return launch_cfg<P, BM, 64, BK>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
 }
 
 // A launch configuration is (M tile 64|128) x (K chunk 16|32) x (split-K mode): index bits 0, 1, 2..3.
 constexpr int kNumConfigs = 12;
 template <class P>
 static int launch_idx(int c, const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
-                      float* ws, size_t wsf, hipStream_t st) {
+                      float* ws, size_t wsf, hipStream_t st, GradJobs* defer = nullptr) {
   const int smode = c >> 2;
   switch (c & 3) {
-    case 0: return launch_by_n<P, 64, 16>(p, p1, M, N, Z, ws, wsf, smode, st);
-    case 1: return launch_by_n<P, 128, 16>(p, p1, M, N, Z, ws, wsf, smode, st);
-    case 2: return launch_by_n<P, 64, 32>(p, p1, M, N, Z, ws, wsf, smode, st);
-    default: return launch_by_n<P, 128, 32>(p, p1, M, N, Z, ws, wsf, smode, st);
+    case 0: return launch_by_n<P, 64, 16>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+    case 1: return launch_by_n<P, 128, 16>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+    case 2: return launch_by_n<P, 64, 32>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+    default: return launch_by_n<P, 128, 32>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
   }
 }
 
@@ -715,7 +747,7 @@ void igemm_set_tuning(int mode, int force) {
 
 template <class P>
 static int launch_auto(const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
-                       float* ws, size_t wsf, hipStream_t st) {
+                       float* ws, size_t wsf, hipStream_t st, GradJobs* defer = nullptr) {
   // static heuristic: small-M problems (deep layers, weight gradients) get 64-row tiles for more workgroups
   const int heuristic = (M <= 64 || (long)cdiv(M, 128) * cdiv(N, 64) * Z < 256) ? 0 : 1;
   int mode, force;
@@ -728,21 +760,21 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
     mode = g_tune_mode;
     force = g_tune_force;
   }
-  if (force >= 0) return launch_idx<P>(force % kNumConfigs, p, p1, M, N, Z, ws, wsf, st);
-  if (!mode) return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st);
+  if (force >= 0) return launch_idx<P>(force % kNumConfigs, p, p1, M, N, Z, ws, wsf, st, defer);
+  if (!mode) return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st, defer);
   const TuneKey key{policy_id<P>(), M, N, p.K, Z, p1 ? 2 : 1};
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
-    if (it != g_tuned.end()) return launch_idx<P>(it->second, p, p1, M, N, Z, ws, wsf, st);
+    if (it != g_tuned.end()) return launch_idx<P>(it->second, p, p1, M, N, Z, ws, wsf, st, defer);
   }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
   if (cap != hipStreamCaptureStatusNone || accumulates(p, 0) || (p1 && accumulates(*p1, 0)))
-    return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st);
+    return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st, defer);
   hipEvent_t e0, e1;
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)
-    return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st);
+    return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st, defer);
   int best = heuristic;
   float best_ms = 1e30f;
   for (int c = 0; c < kNumConfigs; ++c) {
@@ -767,7 +799,7 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
     fprintf(stderr, "[lshm tune] policy %d M=%d N=%d K=%d Z=%d G=%d -> cfg %d (BM %d BK %d split-mode %d) %.1f us\n",
             key.pol, M, N, p.K, Z, key.G, best, (best & 1) ? 128 : 64, (best & 2) ? 32 : 16, best >> 2,
             best_ms * 1000.f / 3);
-  return launch_idx<P>(best, p, p1, M, N, Z, ws, wsf, st);
+  return launch_idx<P>(best, p, p1, M, N, Z, ws, wsf, st, defer);  // candidates ran their combine in place
 }
 
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {
@@ -787,8 +819,9 @@ int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st, 
 int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dDgradParams* p1) {
   return launch_auto<Conv2dDgrad>(p, p1, p.M, p.N, 4, ws, wsf, st);
 }
-int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dWgradParams* p1) {
-  return launch_auto<Conv2dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
+int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dWgradParams* p1,
+                 GradJobs* defer) {
+  return launch_auto<Conv2dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1) {
   return launch_auto<Conv1dFwd>(p, p1, p.M, p.N, 1, ws, wsf, st);
@@ -796,15 +829,16 @@ int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, 
 int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dDgradParams* p1) {
   return launch_auto<Conv1dDgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
-int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1) {
-  return launch_auto<Conv1dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
+int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1,
+                 GradJobs* defer) {
+  return launch_auto<Conv1dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
-                 hipStream_t st, const StridedGemmParams* p1) {
-  if (a_m_fast && b_n_fast) return launch_auto<Strided<true, true>>(p, p1, p.M, p.N, 1, ws, wsf, st);
-  if (a_m_fast) return launch_auto<Strided<true, false>>(p, p1, p.M, p.N, 1, ws, wsf, st);
-  if (b_n_fast) return launch_auto<Strided<false, true>>(p, p1, p.M, p.N, 1, ws, wsf, st);
-  return launch_auto<Strided<false, false>>(p, p1, p.M, p.N, 1, ws, wsf, st);
+                 hipStream_t st, const StridedGemmParams* p1, GradJobs* defer) {
+  if (a_m_fast && b_n_fast) return launch_auto<Strided<true, true>>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
+  if (a_m_fast) return launch_auto<Strided<true, false>>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
+  if (b_n_fast) return launch_auto<Strided<false, true>>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
+  return launch_auto<Strided<false, false>>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 
 }  // namespace lshm

@@ -2,6 +2,7 @@
 // engine (engine.hip).  All pointers are device pointers; every launcher only
 // enqueues work on `st` (no allocation, no synchronisation: graph-capturable).
 #pragma once
+#include <vector>
 #include "common.h"
 
 namespace lshm {
@@ -64,16 +65,56 @@ struct StridedGemmParams {
   const float* add; long sxm; int add_n;
 };
 
+// ---- deferred reductions (deferred.hip) ---------------------------------------------------------
+// The backward pass of an autoencoder ends in ~60 tiny sums (split-K slabs of the weight gradients,
+// per-workgroup partials of the direct kernels, bias gradients).  Instead of one launch each, a
+// backward can park them in a GradJobs list; grad_jobs_finish() runs them all in two launches, in a
+// fixed order (bitwise reproducible).  Everything a job reads must stay untouched until then:
+// scratch comes from the list's own bump allocator, never from shared split-K scratch.
+struct SumJob {     // dst[map(j)] (=|+=) sum_{s<S} src[s*stride + j],  j < n
+  const float* src; float* dst;
+  long stride;      // floats between consecutive partials
+  int n, S;
+  int Mp, M;        // Mp == 0: map(j) = j;  else j = col*Mp + row (split-K slab), rows >= M dropped,
+  int rs, cs;       //          map(j) = row*rs + col*cs
+  int accumulate;
+  int lpo;          // lanes cooperating on one output (1, 16 or 64); chosen by grad_jobs_finish
+};
+struct ChanJob {    // partial[chunk*C + c] = sum over a chunk of {dz[b, c, :]}  (bias gradient, stage 1)
+  const float* dz; float* partial;
+  long bs, HW;      // batch stride and spatial size (HW % 4 == 0)
+  int B, C, chunks;
+};
+struct GradJobs {
+  std::vector<ChanJob> chan;
+  std::vector<SumJob> sums;
+  float* scratch = nullptr;
+  size_t cap = 0, used = 0;
+  float* take(size_t n) {
+    n = (n + 3) & ~(size_t)3;
+    if (used + n > cap) return nullptr;
+    float* p = scratch + used;
+    used += n;
+    return p;
+  }
+  // bias gradient of a conv layer's dz (B, C, HW): stage-1 job + final sum; false if it cannot be deferred
+  bool add_channel_sum(const float* dz, long bs, int B, int C, long HW, float* db, int accumulate);
+};
+int grad_jobs_finish(GradJobs& jobs, hipStream_t st);
+
 // ws / wsf: optional split-K scratch (null: never split)
 // p1 (optional): a second problem of identical shape run in the same launch (ws is split in two)
 int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dFwdParams* p1 = nullptr);
 int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dDgradParams* p1 = nullptr);
-int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dWgradParams* p1 = nullptr);
+int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dWgradParams* p1 = nullptr,
+                 GradJobs* defer = nullptr);
 int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1 = nullptr);
 int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dDgradParams* p1 = nullptr);
-int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1 = nullptr);
+int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1 = nullptr,
+                 GradJobs* defer = nullptr);
+// defer (weight-gradient problems only): a split launch leaves its slabs in ws and queues the combine
 int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
-                 hipStream_t st, const StridedGemmParams* p1 = nullptr);
+                 hipStream_t st, const StridedGemmParams* p1 = nullptr, GradJobs* defer = nullptr);
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
 // mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
 void igemm_set_tuning(int mode, int force);
@@ -90,14 +131,16 @@ int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, 
 bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws);
 size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb);
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, int B, int Cs,
-                        int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st);
+                        int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
+                        GradJobs* defer = nullptr);
 
 bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls);
 size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb);
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
                         size_t wsf, int accumulate, hipStream_t st, const float* small2 = nullptr,
-                        const float* big2 = nullptr, float* dw2 = nullptr, float* db2 = nullptr);
+                        const float* big2 = nullptr, float* dw2 = nullptr, float* db2 = nullptr,
+                        GradJobs* defer = nullptr);
 
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
@@ -123,8 +166,12 @@ int conv_layer_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, float* ws, 
 int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_t wsf, hipStream_t st,
                      const ConvDgradIO* io2 = nullptr);
 // dw, db overwritten (accumulate=0) or accumulated (accumulate=1); ws required
+// defer: scratch is taken from the job list instead of ws and the closing sums are queued on it
 int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_t ws_floats, int accumulate,
-                     hipStream_t st, const ConvWgradIO* io2 = nullptr);
+                     hipStream_t st, const ConvWgradIO* io2 = nullptr, GradJobs* defer = nullptr);
+
+size_t conv_wgrad_defer_floats(const ConvLayer& L, int G);
+size_t linear_wgrad_defer_floats(int B, int K, int N, int G);
 
 struct LinFwdIO { const float* x; const float* w; const float* b; float* y; };
 struct LinDgradIO { const float* dz; const float* w; float* dx; const float* xsaved; const float* add; };
@@ -138,7 +185,7 @@ int linear_dgrad(const LinDgradIO& io, long lddz, long lddx, long ldxs, long lda
 int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols, hipStream_t st);
 // dw[N,K] = dz^T x ; db[N] = colsum(dz)
 int linear_wgrad(const LinWgradIO& io, long ldx, long lddz, int B, int K, int N, float* ws, size_t wsf,
-                 hipStream_t st, const LinWgradIO* io2 = nullptr);
+                 hipStream_t st, const LinWgradIO* io2 = nullptr, GradJobs* defer = nullptr);
 
 // ---- elementwise / reductions (elementwise.hip) -----------------------------
 int uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, hipStream_t st);

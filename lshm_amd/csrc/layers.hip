@@ -78,6 +78,14 @@ size_t conv_workspace_floats(const ConvLayer& L) {
   return a + BIAS_WS_FLOATS + 16;
 }
 
+// scratch a deferred weight-gradient call of this layer takes from its GradJobs list (G problems per launch)
+size_t conv_wgrad_defer_floats(const ConvLayer& L, int G) {
+  return (conv_workspace_floats(L) + 4) * G + (size_t)G * (256 * (size_t)L.Cout + 4);
+}
+size_t linear_wgrad_defer_floats(int B, int K, int N, int G) {
+  return (igemm_workspace_floats(N, K, B, 1) + 16 + 4) * G;
+}
+
 // ---- problem descriptors from pointer bundles ---------------------------------------------
 static Conv2dFwdParams p_conv2d_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, int Ho, int Wo) {
   return Conv2dFwdParams{io.x, io.w, io.b, io.y, nullptr, L.B, L.Cin, L.Hin, L.Win, L.Cout, Ho, Wo,
@@ -189,7 +197,12 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
 }
 
 int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_t ws_floats, int accumulate,
-                     hipStream_t st, const ConvWgradIO* io2) {
+                     hipStream_t st, const ConvWgradIO* io2, GradJobs* defer) {
+  const int G = io2 ? 2 : 1;
+  if (defer) {  // private scratch that survives until grad_jobs_finish
+    ws_floats = conv_workspace_floats(L) * G;
+    ws = defer->take(ws_floats);
+  }
   if (!ws || ws_floats < BIAS_WS_FLOATS + 16) {
     set_last_error("conv wgrad: workspace too small");
     return LSHM_ERR_WORKSPACE;
@@ -207,23 +220,22 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
   float* bias_ws = ws;
   float* gemm_ws = ws + BIAS_WS_FLOATS;
   const size_t gemm_wsf = ws_floats - BIAS_WS_FLOATS;
-  const int G = io2 ? 2 : 1;
   int rc;
   if (L.kind < 2) {
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
     if (!io2 && conv2d_wgrad_direct_supported(Cs, Cb, Hs, Ws) &&
         gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
       rc = conv2d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, L.B, Cs, Cb, Hs, Ws, gemm_ws, gemm_wsf,
-                               accumulate, st);
+                               accumulate, st, defer);
     } else {
       Conv2dWgradParams p{small_of(io), big_of(io), io.dw, L.B, Cs, Hs, Ws, Cb, s_bs, big_bs,
                           g.M, g.N, g.K, accumulate, {}};
       if (io2) {
         Conv2dWgradParams q = p;
         q.s = small_of(*io2); q.big = big_of(*io2); q.dw = io2->dw;
-        rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st, &q);
+        rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st, &q, defer);
       } else {
-        rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st);
+        rc = conv2d_wgrad(p, gemm_ws, gemm_wsf, st, nullptr, defer);
       }
     }
   } else {
@@ -233,25 +245,34 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
       return conv1d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.Cout, L.B, Cs,
                                  Cb, Ls, Lb, tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st,
                                  io2 ? small_of(*io2) : nullptr, io2 ? big_of(*io2) : nullptr,
-                                 io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr);
+                                 io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr, defer);
     Conv1dWgradParams p{small_of(io), big_of(io), io.dw, L.B, Cs, Ls, Cb, Lb, tr ? 0 : 1, s_bs, big_bs,
                         g.M, g.N, g.K, accumulate, {}};
     if (io2) {
       Conv1dWgradParams q = p;
       q.s = small_of(*io2); q.big = big_of(*io2); q.dw = io2->dw;
-      rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st, &q);
+      rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st, &q, defer);
     } else {
-      rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st);
+      rc = conv1d_wgrad(p, gemm_ws, gemm_wsf, st, nullptr, defer);
     }
   }
   if (rc || !io.db) return rc;
   const float* dz2 = io2 ? io2->dz : nullptr;
   float* db2 = io2 ? io2->db : nullptr;
-  if ((long)L.B * Ho * Wo <= 65536)  // small tensor: one workgroup per channel, no second stage
-    return channel_sum_direct(io.dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, io.db, accumulate, st, dz2, db2);
+  const long HW = (long)Ho * Wo;
+  if (defer) {
+    const size_t mark_c = defer->chan.size(), mark_s = defer->sums.size();
+    bool ok = defer->add_channel_sum(io.dz, L.out_bs, L.B, L.Cout, HW, io.db, accumulate);
+    if (ok && io2) ok = defer->add_channel_sum(dz2, L.out_bs, L.B, L.Cout, HW, db2, accumulate);
+    if (ok) return LSHM_OK;
+    defer->chan.resize(mark_c);  // cannot be expressed as jobs: sum in place below
+    defer->sums.resize(mark_s);
+  }
+  if ((long)L.B * HW <= 65536)  // small tensor: one workgroup per channel, no second stage
+    return channel_sum_direct(io.dz, L.out_bs, L.B, L.Cout, HW, io.db, accumulate, st, dz2, db2);
   const int Sb = bias_slices(L);
   float* bias_ws2 = bias_ws + BIAS_WS_FLOATS / 2;
-  rc = channel_sum_partials(io.dz, L.out_bs, L.B, L.Cout, (long)Ho * Wo, bias_ws, Sb, st, dz2, bias_ws2);
+  rc = channel_sum_partials(io.dz, L.out_bs, L.B, L.Cout, HW, bias_ws, Sb, st, dz2, bias_ws2);
   if (rc) return rc;
   return reduce_partials(bias_ws, io.db, L.Cout, Sb, accumulate, st, io2 ? bias_ws2 : nullptr, db2);
 }
@@ -307,18 +328,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   if (part == 0 && n < N) db[n] = (red[nl] + red[64 + nl]) + (red[128 + nl] + red[192 + nl]);
 }
 int linear_wgrad(const LinWgradIO& io, long ldx, long lddz, int B, int K, int N, float* ws, size_t wsf,
-                 hipStream_t st, const LinWgradIO* io2) {
+                 hipStream_t st, const LinWgradIO* io2, GradJobs* defer) {
+  if (defer) {
+    wsf = (igemm_workspace_floats(N, K, B, 1) + 16) * (io2 ? 2 : 1);
+    ws = defer->take(wsf);
+    if (!ws) { set_last_error("linear wgrad: deferred scratch exhausted"); return LSHM_ERR_WORKSPACE; }
+  }
   StridedGemmParams p{io.dz, io.x, nullptr, io.dw, nullptr, 1, lddz, ldx, 1, K, 1, 0, 0, 0, N, K, B, {},
                       nullptr, 0, 0};
   int rc;
   if (io2) {
     StridedGemmParams q = p;
     q.a = io2->dz; q.b = io2->x; q.c = io2->dw;
-    rc = strided_gemm(p, true, true, ws, wsf, st, &q);
+    rc = strided_gemm(p, true, true, ws, wsf, st, &q, defer);
   } else {
-    rc = strided_gemm(p, true, true, ws, wsf, st);
+    rc = strided_gemm(p, true, true, ws, wsf, st, nullptr, defer);
   }
   if (rc || !io.db) return rc;
+  if (defer) {  // column sums of dz: S = B partials of stride lddz
+    defer->sums.push_back(SumJob{io.dz, io.db, lddz, N, B, 0, 0, 0, 0, 0, 0});
+    if (io2) defer->sums.push_back(SumJob{io2->dz, io2->db, lddz, N, B, 0, 0, 0, 0, 0, 0});
+    return LSHM_OK;
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 64), io2 ? 2 : 1), dim3(256), 0, st, io.dz,
                      io2 ? io2->dz : nullptr, lddz, B, N, io.db, io2 ? io2->db : nullptr);
   return check_launch("colsum");
