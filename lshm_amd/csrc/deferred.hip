@@ -50,34 +50,40 @@ __global__ __launch_bounds__(256) void chan_partials_multi_kernel(const ChanTabl
   if (threadIdx.x == 0) J.partial[(long)ch * J.C + c] = acc;
 }
 
-// stage 2: every remaining sum.  lpo lanes share an output (s strided by lpo), combined by butterflies.
+// stage 2: every remaining sum.  A workgroup covers 256/lpo consecutive outputs (lanes of a wave read
+// consecutive addresses); lpo groups of threads split the S partials and are combined through LDS
+// in group order.
 __global__ __launch_bounds__(256) void sum_jobs_multi_kernel(const SumTable tab) {
+  __shared__ float red[256];
   const int jx = find_job(tab, blockIdx.x);
   const SumJob& J = tab.job[jx];
   const int lb = blockIdx.x - tab.blk0[jx];
   const int lpo = J.lpo;
   const int opb = 256 / lpo;
-  const int sl = threadIdx.x % lpo;
-  const long j = (long)lb * opb + threadIdx.x / lpo;
+  const int sl = threadIdx.x / opb, ol = threadIdx.x - sl * opb;
+  const long j = (long)lb * opb + ol;
   float acc = 0.f;
   if (j < J.n) {
     const float* src = J.src + j;
-    if (lpo == 1) {
-      int s = 0;
-      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-      for (; s + 4 <= J.S; s += 4) {
-        a0 += src[(long)s * J.stride];
-        a1 += src[(long)(s + 1) * J.stride];
-        a2 += src[(long)(s + 2) * J.stride];
-        a3 += src[(long)(s + 3) * J.stride];
-      }
-      for (; s < J.S; ++s) a0 += src[(long)s * J.stride];
-      acc = (a0 + a1) + (a2 + a3);
-    } else {
-      for (int s = sl; s < J.S; s += lpo) acc += src[(long)s * J.stride];
+    const long step = (long)lpo * J.stride;
+    int s = sl;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const float* q = src + (long)s * J.stride;
+    for (; s + 3 * lpo < J.S; s += 4 * lpo, q += 4 * step) {
+      a0 += q[0];
+      a1 += q[step];
+      a2 += q[2 * step];
+      a3 += q[3 * step];
     }
+    for (; s < J.S; s += lpo, q += step) a0 += q[0];
+    acc = (a0 + a1) + (a2 + a3);
   }
-  for (int off = lpo >> 1; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if (lpo > 1) {
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (sl == 0)
+      for (int g = 1; g < lpo; ++g) acc += red[g * opb + ol];
+  }
   if (sl == 0 && j < J.n) {
     long o = j;
     if (J.Mp) {
@@ -125,8 +131,10 @@ int grad_jobs_finish(GradJobs& jobs, hipStream_t st) {
     for (int j = 0; j < tab.njobs; ++j) {
       SumJob& J = tab.job[j];
       J = jobs.sums[j0 + j];
-      // plenty of outputs: one lane each (coalesced along j); few outputs: lanes split the S partials
-      J.lpo = (J.n >= 4096 || J.S < 8) ? 1 : (J.S >= 128 ? 64 : 16);
+      // aim for >= 128K threads per job: few outputs -> more thread groups share the S partials
+      int lpo = 1;
+      while (lpo < 64 && (long)J.n * lpo < 131072 && 4 * lpo <= J.S) lpo *= 2;
+      J.lpo = lpo;
       tab.blk0[j] = blk;
       blk += cdiv(J.n, 256 / J.lpo);
     }

@@ -69,10 +69,10 @@ struct TileIdx {
   long row_off[4];  // offsets of (h0+ty+8i, w0+tx) in the row-major plane
   long col_off[4];  // offsets of (w0+ty+8i, h0+tx) in the transposed plane
 };
-__device__ __forceinline__ TileIdx tile_idx(int P) {
+__device__ __forceinline__ TileIdx tile_idx_at(int P, int bx, int by) {
   TileIdx t;
   const long plane = (long)blockIdx.z * P * P;
-  const int h0 = blockIdx.y * TILE, w0 = blockIdx.x * TILE;
+  const int h0 = by * TILE, w0 = bx * TILE;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     t.row_off[i] = plane + (long)(h0 + threadIdx.y + 8 * i) * P + w0 + threadIdx.x;
@@ -80,6 +80,7 @@ __device__ __forceinline__ TileIdx tile_idx(int P) {
   }
   return t;
 }
+__device__ __forceinline__ TileIdx tile_idx(int P) { return tile_idx_at(P, blockIdx.x, blockIdx.y); }
 
 __global__ __launch_bounds__(256) void residual_split_kernel(const float* __restrict__ x,
                                                              const float* __restrict__ x1,
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void recon_kernel(
     const float* __restrict__ y3, float rho, float inv_n, int P, double* __restrict__ partials,
     float* __restrict__ gx1p, float* __restrict__ gx2, float* __restrict__ gx3c) {
   __shared__ float tile[TILE][TILE + 1];
-  __shared__ double red[16];
+  __shared__ float red[4][8];
   const TileIdx t = tile_idx(P);
 #pragma unroll
   for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = x3c[t.col_off[i]];
@@ -244,21 +245,20 @@ __global__ __launch_bounds__(256) void recon_kernel(
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = g3[i];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; ++i) gx3c[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
-  const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  // flatten thread index for block_sum
+  // per-wavefront sums in fp32 (256 terms each), combined across the 4 waves and all tiles in fp64
   const int tid = threadIdx.y * TILE + threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
   for (int q = 0; q < 7; ++q) {
-    double v = wave_sum_d((double)s[q]);
-    if (lane == 0) red[w] = v;
-    __syncthreads();
-    if (tid == 0) partials[blk * 7 + q] = red[0] + red[1] + red[2] + red[3];
-    __syncthreads();
+    const float v = wave_sum(s[q]);
+    if (lane == 0) red[w][q] = v;
   }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) gx3c[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
+  const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  if (tid < 7)
+    partials[blk * 7 + tid] = ((double)red[0][tid] + (double)red[1][tid]) + ((double)red[2][tid] + (double)red[3][tid]);
 }
 __global__ __launch_bounds__(1024) void sum7_kernel(const double* __restrict__ partials, long nblk,
                                                     double* __restrict__ sums7) {
