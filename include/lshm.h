@@ -65,6 +65,13 @@ size_t lshm_conv_workspace_floats(int kind, int B, int Cin, int Cout, int Hin, i
 int lshm_conv_fwd(int kind, const float* x, const float* w, const float* bias, float* y, int B,
                   int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, int act,
                   float* workspace, size_t workspace_floats, lshm_stream_t stream);
+/* Two independent problems of identical shape in one launch: the row- and the column-vectorised 1-D
+ * autoencoder (src/kharmonic_lofar.py:142-147) run every layer this way.  A workspace, if given, is
+ * split in two: pass twice lshm_conv_workspace_floats(). */
+int lshm_conv_fwd_pair(int kind, const float* x0, const float* w0, const float* bias0, float* y0,
+                       const float* x1, const float* w1, const float* bias1, float* y1, int B, int Cin,
+                       int Cout, int Hin, int Win, long in_bs, long out_bs, int act, float* workspace,
+                       size_t workspace_floats, lshm_stream_t stream);
 /* data gradient: dx = op^T(dz, w); if y_in_saved != NULL the result is multiplied by ELU'(y_in_saved)
  * (the saved *output* of the previous layer), i.e. it is already the pre-activation gradient. */
 int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved,

@@ -42,6 +42,9 @@ _SIGNATURES = {
     "lshm_conv_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "lshm_conv_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                               c_int, c_long, c_long, c_int, c_void_p, c_size_t, c_void_p]),
+    "lshm_conv_fwd_pair": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_int, c_void_p,
+                                   c_size_t, c_void_p]),
     "lshm_conv_dgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                 c_int, c_long, c_long, c_void_p, c_size_t, c_void_p]),
     "lshm_conv_wgrad": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

@@ -74,6 +74,16 @@ int lshm_conv_fwd(int kind, const float* x, const float* w, const float* bias, f
   if (rc) return rc;
   return conv_layer_fwd(L, ConvFwdIO{x, w, bias, y}, act, ws, ws ? wsf : 0, ST(s));
 }
+int lshm_conv_fwd_pair(int kind, const float* x0, const float* w0, const float* bias0, float* y0,
+                       const float* x1, const float* w1, const float* bias1, float* y1, int B, int Cin, int Cout,
+                       int Hin, int Win, long in_bs, long out_bs, int act, float* ws, size_t wsf, lshm_stream_t s) {
+  REQUIRE(x0 && w0 && y0 && x1 && w1 && y1, "conv_fwd_pair: null pointer");
+  ConvLayer L;
+  int rc = make_layer(kind, B, Cin, Cout, Hin, Win, in_bs, out_bs, &L);
+  if (rc) return rc;
+  const ConvFwdIO io1{x1, w1, bias1, y1};
+  return conv_layer_fwd(L, ConvFwdIO{x0, w0, bias0, y0}, act, ws, ws ? wsf : 0, ST(s), &io1);
+}
 int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved, int B,
                     int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, float* ws, size_t wsf,
                     lshm_stream_t s) {

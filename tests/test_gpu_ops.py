@@ -327,6 +327,39 @@ def test_full_size_conv_linearity_and_adjointness():
                    Fh.conv_act(a, w1, None, Fh.CONV1D, False) - Fh.conv_act(b2, w1, None, Fh.CONV1D, False)) < 2e-6
 
 
+def test_conv_fwd_pair_matches_two_single_launches():
+    """lshm_conv_fwd_pair (netT and netF share every launch) must be bitwise the two single-problem results."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(11)
+    B = 16
+    for kind, cin, cout, win in ((2, 4, 8, 16384), (2, 24, 48, 256), (3, 48, 24, 16), (3, 8, 4, 4096)):
+        xs = [torch.randn(B, cin, win, generator=g).to(DEV) for _ in range(2)]
+        wshape = (cout, cin, 4) if kind == 2 else (cin, cout, 4)
+        ws_ = [(0.2 * torch.randn(*wshape, generator=g)).to(DEV) for _ in range(2)]
+        bs = [torch.randn(cout, generator=g).to(DEV) for _ in range(2)]
+        wo = (win - 2) // 4 + 1 if kind == 2 else win * 4
+        nws = lib.lshm_conv_workspace_floats(kind, B, cin, cout, 1, win)
+        wk = torch.empty(2 * nws + 16, device=DEV)
+        single = [torch.empty(B, cout, wo, device=DEV) for _ in range(2)]
+        pair = [torch.empty(B, cout, wo, device=DEV) for _ in range(2)]
+        for i in range(2):
+            L.check(lib.lshm_conv_fwd(kind, L.ptr(xs[i]), L.ptr(ws_[i]), L.ptr(bs[i]), L.ptr(single[i]), B, cin, cout,
+                                      1, win, 0, 0, 1, L.ptr(wk), nws, L.stream()))
+        L.check(lib.lshm_conv_fwd_pair(kind, L.ptr(xs[0]), L.ptr(ws_[0]), L.ptr(bs[0]), L.ptr(pair[0]),
+                                       L.ptr(xs[1]), L.ptr(ws_[1]), L.ptr(bs[1]), L.ptr(pair[1]), B, cin, cout,
+                                       1, win, 0, 0, 1, L.ptr(wk), 2 * nws, L.stream()))
+        torch.cuda.synchronize()
+        for i in range(2):
+            ref = torch.nn.functional.elu(
+                torch.nn.functional.conv1d(xs[i].double().cpu(), ws_[i].double().cpu(), bs[i].double().cpu(), stride=4, padding=1)
+                if kind == 2 else
+                torch.nn.functional.conv_transpose1d(xs[i].double().cpu(), ws_[i].double().cpu(), bs[i].double().cpu(), stride=4))
+            assert rel_err(pair[i], ref.float()) < 2e-6
+            # the tile configuration is chosen per (shape, group count): same values up to summation order
+            assert rel_err(pair[i], single[i]) < 1e-6
+
+
 def test_full_size_khm_streaming_properties():
     """N = 2^20 rows (the streaming shape): loss of the concatenation is the mean of the two halves'
     losses, dM adds, dX rows are independent; K-harmonic loss is invariant to a row permutation."""
