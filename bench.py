@@ -38,7 +38,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="patches per GPU")
     ap.add_argument("--K", type=int, default=10)
     ap.add_argument("--bpb", type=int, default=8)
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a HIP graph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step from a HIP graph (slower: the graph executor serialises the two-stream backward)")
+    ap.add_argument("--no-graph", action="store_true", help="(default) launch eagerly")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--roofline-cold", action="store_true",
@@ -202,9 +204,10 @@ def main():
     uv = 1000.0 * torch.randn(B, 2, generator=gen)
     tr.new_minibatch(x.to(dev), uv.to(dev))
 
-    # HIP-graph replay at N=1; with RCCL collectives inside the step the launches stay eager unless
-    # LSHM_DP_GRAPH=1 (capturing the all-reduce is not exercised on the 1-GPU development box)
-    use_graph = not args.no_graph and (world == 1 or os.environ.get("LSHM_DP_GRAPH") == "1")
+    # eager by default: the engine enqueues a whole forward+backward per C call (the host stays ~3x ahead
+    # of the device), and the weight-gradient chain runs on its own stream beside the data-gradient chain
+    # (--graph: HIP-graph replay at N=1; with RCCL collectives inside the step only with LSHM_DP_GRAPH=1)
+    use_graph = args.graph and not args.no_graph and (world == 1 or os.environ.get("LSHM_DP_GRAPH") == "1")
     if use_graph:
         try:
             tr.capture_graph(warmup=1)

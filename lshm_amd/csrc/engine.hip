@@ -70,7 +70,7 @@ struct lshm_engine {
     size_t o_gdec[6], o_genc[6];  // input gradients of decoder / encoder layer i (kept until the deferred sums ran)
     size_t o_dcat1, o_dz1, o_dzmu, o_dcat3, o_dd0, o_part, o_wpart;
     size_t o_defer;               // scratch of the backward's deferred reductions (GradJobs)
-  } lane[2];
+  } lane[3];  // 0, 1: netT, netF; 2: the 2-D autoencoder (its backward may start while 0/1 are still being read)
   size_t defer_floats;
   // optional side stream: netF beside netT (LSHM_FORK=1)
   hipStream_t wstream;
@@ -78,6 +78,7 @@ struct lshm_engine {
   mutable size_t next_event;
   bool side_ok;
   bool pair_mode;  // netT/netF share launches (default) instead of running on two streams (LSHM_FORK=1)
+  bool side_wgrad; // weight-gradient chain on the side stream (default; LSHM_WGRAD_INLINE=1 turns it off)
   hipEvent_t take_event() const { return events[next_event++ % events.size()]; }
   size_t part_floats;
   size_t ws_floats;
@@ -240,7 +241,7 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
 // gradients) on a job list that two launches finish at the end; every dz therefore has its own buffer.
 static int ae_backward(const lshm_engine* e, int G, const int* idx, const float* prm, float* grd,
                        const float* const* input, const float* const* dz_out, float* const* dinput, float* ws,
-                       int ln, hipStream_t st) {
+                       int ln, hipStream_t st, hipStream_t wgrad_stream) {
   const lshm_step_config& c = e->cfg;
   const AEPlan& a0 = e->ae[idx[0]];
   const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
@@ -253,6 +254,21 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   GradJobs jobs;
   jobs.scratch = ws + e->lane[ln].o_defer;
   jobs.cap = e->defer_floats;
+  // Weight gradients need only dz and the saved input of their layer, and nothing waits for them
+  // before the optimizer: with a side stream they form a second chain beside the data-gradient
+  // chain, each link waiting for "dz is ready" on `st`; `st` itself never waits (the caller joins
+  // once, after all backward passes).
+  const bool side = wgrad_stream != nullptr && wgrad_stream != st;
+  hipStream_t wst = side ? wgrad_stream : st;
+  auto dz_ready = [&]() -> int {
+    if (!side) return LSHM_OK;
+    hipEvent_t ev = e->take_event();
+    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(wst, ev, 0) != hipSuccess) {
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
+    return LSHM_OK;
+  };
   const float* dz[2];
   for (int g = 0; g < G; ++g) dz[g] = dz_out[g];
   // ---- decoder, last layer first
@@ -267,14 +283,16 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       // previous activation is an ELU output (except fc3's output feeding tconv0)
       dg[g] = ConvDgradIO{dz[g], prm + A(g).tw[i], dx[g], i == 0 ? nullptr : xin};
     }
-    if ((rc = conv_layer_wgrad(a0.dec[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
+    if ((rc = dz_ready())) return rc;
+    if ((rc = conv_layer_wgrad(a0.dec[i], wg[0], nullptr, 0, 0, wst, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
     if ((rc = conv_layer_dgrad(a0.dec[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
   LinWgradIO lw[2];
   LinDgradIO ld[2];
   auto wgrad = [&](long ldx, long lddz, int K, int N) {
-    return linear_wgrad(lw[0], ldx, lddz, B, K, N, nullptr, 0, st, G > 1 ? &lw[1] : nullptr, &jobs);
+    int r = dz_ready();
+    return r ? r : linear_wgrad(lw[0], ldx, lddz, B, K, N, nullptr, 0, wst, G > 1 ? &lw[1] : nullptr, &jobs);
   };
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr);
@@ -326,12 +344,13 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).cw[i], grd + A(g).cb[i]};
       dg[g] = ConvDgradIO{dz[g], prm + A(g).cw[i], dx[g], i == 0 ? nullptr : xin};
     }
-    if ((rc = conv_layer_wgrad(a0.enc[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
+    if ((rc = dz_ready())) return rc;
+    if ((rc = conv_layer_wgrad(a0.enc[i], wg[0], nullptr, 0, 0, wst, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
     if (i == 0 && !dinput[0]) break;
     if ((rc = conv_layer_dgrad(a0.enc[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
-  return grad_jobs_finish(jobs, st);
+  return grad_jobs_finish(jobs, wst);
 }
 
 // scal layout (doubles): [0..6] sums7, [7] khm sum, [8] sim, [9..11] rica x3, [12] aug, [13..] aug partials
@@ -441,21 +460,22 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   if ((rc = check_launch("finalize_terms"))) return rc;
   if (!grd) return LSHM_OK;
   // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
+  hipStream_t wgs = (e->pair_mode && e->side_ok && e->side_wgrad) ? e->wstream : nullptr;
   {
     const int i12[2] = {1, 2};
     const float* in12[2] = {ws + e->o_row, ws + e->o_col};
     const float* dz12[2] = {ws + e->o_gx2, ws + e->o_gx3c};
     float* di12[2] = {ws + e->o_gT, ws + e->o_gFc};
     if (e->pair_mode || !e->side_ok) {
-      if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, 0, st))) return rc;
+      if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, 0, st, wgs))) return rc;
     } else {
       hipEvent_t evf = e->take_event();
       if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(e->wstream, evf, 0) != hipSuccess) {
         set_last_error("engine: stream fork failed");
         return LSHM_ERR_ARG;
       }
-      if ((rc = ae_backward(e, 1, i12, prm, grd, in12, dz12, di12, ws, 0, st))) return rc;
-      if ((rc = ae_backward(e, 1, i12 + 1, prm, grd, in12 + 1, dz12 + 1, di12 + 1, ws, 1, e->wstream))) return rc;
+      if ((rc = ae_backward(e, 1, i12, prm, grd, in12, dz12, di12, ws, 0, st, nullptr))) return rc;
+      if ((rc = ae_backward(e, 1, i12 + 1, prm, grd, in12 + 1, dz12 + 1, di12 + 1, ws, 1, e->wstream, nullptr))) return rc;
       hipEvent_t evj = e->take_event();
       if (hipEventRecord(evj, e->wstream) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
         set_last_error("engine: stream join failed");
@@ -469,7 +489,14 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     const float* in0[1] = {x};
     const float* dz0[1] = {ws + e->o_gx1};
     float* di0[1] = {nullptr};
-    if ((rc = ae_backward(e, 1, i0, prm, grd, in0, dz0, di0, ws, 0, st))) return rc;
+    if ((rc = ae_backward(e, 1, i0, prm, grd, in0, dz0, di0, ws, 2, st, wgs))) return rc;
+  }
+  if (wgs) {  // the weight-gradient chain joins here, before anything consumes the gradients
+    hipEvent_t evj = e->take_event();
+    if (hipEventRecord(evj, wgs) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
+      set_last_error("engine: stream join failed");
+      return LSHM_ERR_ARG;
+    }
   }
   return LSHM_OK;
 }
@@ -528,7 +555,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
             2 * linear_wgrad_defer_floats(B, e->hdim, e->hdim, G) + 2 * linear_wgrad_defer_floats(B, La, La, G);
     if (need > e->defer_floats) e->defer_floats = need;
   }
-  for (int ln = 0; ln < 2; ++ln) {
+  for (int ln = 0; ln < 3; ++ln) {
     lshm_engine::Lane& la = e->lane[ln];
     for (int i = 1; i < 6; ++i) {  // same sizes for the 2-D and the 1-D autoencoders
       la.o_gdec[i] = take(cur, (size_t)B * e->ae[0].dec[i].in_bs);
@@ -566,7 +593,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     if (w > pf) pf = w;
   }
   e->part_floats = pf;
-  for (int ln = 0; ln < 2; ++ln) {
+  for (int ln = 0; ln < 3; ++ln) {
     e->lane[ln].o_part = take(cur, pf);
     e->lane[ln].o_wpart = take(cur, pf);
   }
@@ -576,7 +603,8 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->pair_mode = getenv("LSHM_FORK") == nullptr;
   {
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && !e->pair_mode) {
+    e->side_wgrad = getenv("LSHM_WGRAD_INLINE") == nullptr;
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && (!e->pair_mode || e->side_wgrad)) {
       bool ok = hipStreamCreateWithFlags(&e->wstream, hipStreamNonBlocking) == hipSuccess;
       e->events.resize(128);
       for (size_t i = 0; i < e->events.size() && ok; ++i)
