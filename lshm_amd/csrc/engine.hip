@@ -19,6 +19,7 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -76,6 +77,8 @@ struct lshm_engine {
   hipStream_t wstream;
   std::vector<hipEvent_t> events;
   mutable size_t next_event;
+  hipEvent_t latent_event;  // set while the latent-space terms of the current forward are in flight
+  size_t o_latent_ws, latent_ws_floats;
   bool side_ok;
   bool pair_mode;  // netT/netF share launches (default) instead of running on two streams (LSHM_FORK=1)
   bool side_wgrad; // weight-gradient chain on the side stream (default; LSHM_WGRAD_INLINE=1 turns it off)
@@ -177,7 +180,8 @@ static void plan_ae(lshm_engine* e, int idx, const char* prefix, int ndim, int L
 // Forward of one autoencoder (G == 1) or of two autoencoders of identical shape that share every
 // launch (G == 2: netT and netF).  idx[] = AE indices, input[] = their input tensors.
 static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* prm, const float* const* input,
-                      float* ws, int ln, hipStream_t st) {  // ln: scratch lane of problem 0
+                      float* ws, int ln, hipStream_t st,  // ln: scratch lane of problem 0
+                      const std::function<int()>* after_latent = nullptr) {  // called once the latents are enqueued
   const lshm_step_config& c = e->cfg;
   const AEPlan& a0 = e->ae[idx[0]];
   const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
@@ -217,6 +221,7 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
     for (int g = 0; g < G; ++g)
       if ((rc = copy2d(ws + e->o_Mu + A(g).mu_col, D, ws + A(g).cat3, L + hd, B, L, st))) return rc;
   }
+  if (after_latent && (rc = (*after_latent)())) return rc;
   for (int g = 0; g < G; ++g) l[g] = LinFwdIO{uvh, prm + A(g).fcuv3w, prm + A(g).fcuv3b, ws + A(g).cat3 + L};
   if ((rc = lin(hd, L + hd, hd, hd, 1))) return rc;
   for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat3, prm + A(g).fc3w, prm + A(g).fc3b, ws + A(g).d0};
@@ -374,7 +379,7 @@ __global__ void finalize_terms_kernel(const double* __restrict__ scal, double* _
 }
 
 static int three_forward(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws,
-                         hipStream_t st) {
+                         hipStream_t st, const std::function<int()>* after_latents = nullptr) {
   const lshm_step_config& c = e->cfg;
   int rc;
   if ((rc = uv_harmonics_host_scales(uv, c.scales, c.H, c.B, ws + e->o_uvh, st))) return rc;
@@ -388,7 +393,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   const int i12[2] = {1, 2};
   const float* in12[2] = {ws + e->o_row, ws + e->o_col};
   if (e->pair_mode || !e->side_ok)  // every launch carries both problems
-    return ae_forward(e, 2, i12, prm, in12, ws, 0, st);
+    return ae_forward(e, 2, i12, prm, in12, ws, 0, st, after_latents);
   // or: two streams side by side (LSHM_FORK=1; no faster than paired launches since the reductions are deferred)
   hipEvent_t evf = e->take_event();
   if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(e->wstream, evf, 0) != hipSuccess) {
@@ -402,10 +407,72 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
     set_last_error("engine: stream join failed");
     return LSHM_ERR_ARG;
   }
+  return after_latents ? (*after_latents)() : LSHM_OK;
+}
+
+// Latent-space terms (src/kharmonic_lofar.py:160-172): they need only the three latent codes, so
+// they can run on a side stream while the decoders and the reconstruction kernel run on the main one.
+//   gMu = d/dMu (alpha*khm + gamma*aug + lambda*rica),  dM = alpha*khm' + beta*sim'
+static int latent_losses(lshm_engine* e, const float* prm, float* grd, float* ws, hipStream_t st) {
+  const lshm_step_config& c = e->cfg;
+  const int B = c.B, D = e->D;
+  const double world = c.world > 0 ? c.world : 1;
+  double* scal = reinterpret_cast<double*>(ws + e->o_scal);
+  float* gMu = ws + e->o_gMu;
+  float* Mu = ws + e->o_Mu;
+  float* dM = grd ? grd + e->Moff : ws + e->o_dMscratch;
+  const float* M = prm + e->Moff;
+  int rc;
+  const double inv_count = 1.0 / (world * (double)B * c.K * D);
+  if ((rc = khm_fwd_bwd(Mu, D, M, B, D, c.K, c.p, 1e-9f, inv_count, c.alpha, scal + 7, gMu, D, dM, 0,
+                        ws + e->o_latent_ws, e->latent_ws_floats, st))) return rc;
+  if ((rc = cluster_sim_fwd_bwd(M, c.K, D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 1, st))) return rc;
+  const int bs_global = (int)(c.batch_size * world);
+  {
+    // augmented loss: local groups, global normalisation.  aug_loss_fwd_bwd normalises by
+    // batch_size*bpb*bpb of the value passed: pass the global batch size, but only the local rows take part
+    const int used = c.batch_size * c.bpb < B ? c.batch_size * c.bpb : B;
+    if ((rc = aug_loss_fwd_bwd(Mu, D, used, D, c.bpb, bs_global, c.gamma, scal + 12, gMu, D, 1, st))) return rc;
+  }
+  if (c.rica) {
+    double* rica_part = scal + 16 + (B + c.bpb - 1) / c.bpb;  // [LOGCOSH3_BLOCKS][3]
+    const AEPlan* a = e->ae;
+    int cols[3];
+    float sc3[3];
+    for (int i = 0; i < 3; ++i) {
+      cols[i] = a[i].L;
+      sc3[i] = (float)(c.rica_lambda / (world * (double)B * a[i].L));
+    }
+    if ((rc = logcosh3_fwd_bwd(Mu, D, B, cols, sc3, rica_part, LOGCOSH3_BLOCKS, gMu, D, st))) return rc;
+  }
   return LSHM_OK;
 }
 
-// losses (and, when grd != null, every gradient) after three_forward
+// forward of the three autoencoders with the latent-space terms overlapped (side stream if there is one)
+static int forward_with_latent_losses(lshm_engine* e, const float* prm, float* grd, const float* x, const float* uv,
+                                      float* ws, hipStream_t st) {
+  const bool side = e->side_ok && e->side_wgrad;
+  e->latent_event = nullptr;
+  const std::function<int()> hook = [&]() -> int {
+    if (!side) return latent_losses(e, prm, grd, ws, st);
+    hipEvent_t ev = e->take_event();
+    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->wstream, ev, 0) != hipSuccess) {
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
+    int rc = latent_losses(e, prm, grd, ws, e->wstream);
+    if (rc) return rc;
+    e->latent_event = e->take_event();
+    if (hipEventRecord(e->latent_event, e->wstream) != hipSuccess) {
+      set_last_error("engine: event record failed");
+      return LSHM_ERR_ARG;
+    }
+    return LSHM_OK;
+  };
+  return three_forward(e, prm, x, uv, ws, st, &hook);
+}
+
+// reconstruction losses, loss terms and (when grd != null) every gradient, after forward_with_latent_losses
 static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, const float* x,
                                const float* y1, const float* y2, const float* y3, double* terms,
                                float* ws, hipStream_t st) {
@@ -414,10 +481,6 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   const double world = c.world > 0 ? c.world : 1;
   const double n_global = world * (double)B * c.C * c.P * c.P;
   double* scal = reinterpret_cast<double*>(ws + e->o_scal);
-  float* gMu = ws + e->o_gMu;
-  float* Mu = ws + e->o_Mu;
-  float* dM = grd ? grd + e->Moff : ws + e->o_dMscratch;
-  const float* M = prm + e->Moff;
   int rc;
   // reconstruction terms; the kernel's 1/n uses the local element count, rescale for world > 1 below
   if ((rc = recon_losses_fwd_bwd(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3,
@@ -430,30 +493,14 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     if ((rc = scale_flat(ws + e->o_gx2, s, n, st))) return rc;
     if ((rc = scale_flat(ws + e->o_gx3c, s, n, st))) return rc;
   }
-  // latent-space terms: gMu = d/dMu (alpha*khm + gamma*aug + lambda*rica), dM = alpha*khm' + beta*sim'
   const double inv_count = 1.0 / (world * (double)B * c.K * D);
-  if ((rc = khm_fwd_bwd(Mu, D, M, B, D, c.K, c.p, 1e-9f, inv_count, c.alpha, scal + 7, gMu, D, dM, 0,
-                        ws + e->lane[0].o_part, e->part_floats, st))) return rc;
-  if ((rc = cluster_sim_fwd_bwd(M, c.K, D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 1, st))) return rc;
-  const int bs_global = (int)(c.batch_size * world);
-  // augmented loss: local groups, global normalisation
-  {
-    const int used = c.batch_size * c.bpb < B ? c.batch_size * c.bpb : B;
-    const float coef_scale = c.gamma;
-    // aug_loss_fwd_bwd normalises by batch_size*bpb*bpb of the value passed: pass the global batch size,
-    // but only the local rows take part
-    if ((rc = aug_loss_fwd_bwd(Mu, D, used, D, c.bpb, bs_global, coef_scale, scal + 12, gMu, D, 1, st))) return rc;
-  }
   double* rica_part = scal + 16 + (B + c.bpb - 1) / c.bpb;  // [LOGCOSH3_BLOCKS][3]
-  if (c.rica) {
-    const AEPlan* a = e->ae;
-    int cols[3];
-    float sc3[3];
-    for (int i = 0; i < 3; ++i) {
-      cols[i] = a[i].L;
-      sc3[i] = (float)(c.rica_lambda / (world * (double)B * a[i].L));
+  if (e->latent_event) {  // the latent-space terms ran beside the decoders
+    if (hipStreamWaitEvent(st, e->latent_event, 0) != hipSuccess) {
+      set_last_error("engine: stream join failed");
+      return LSHM_ERR_ARG;
     }
-    if ((rc = logcosh3_fwd_bwd(Mu, D, B, cols, sc3, rica_part, LOGCOSH3_BLOCKS, gMu, D, st))) return rc;
+    e->latent_event = nullptr;
   }
   hipLaunchKernelGGL(finalize_terms_kernel, dim3(1), dim3(64), 0, st, scal, terms, n_global, (double)c.rho,
                      (double)c.alpha * inv_count, c.rica, rica_part, LOGCOSH3_BLOCKS * 3);
@@ -570,6 +617,9 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     la.o_dd0 = take(cur, (size_t)B * 768);
   }
   e->o_dMscratch = take(cur, (size_t)cfg->K * e->D);
+  e->latent_ws_floats = khm_workspace_floats(B, e->D, cfg->K);
+  e->o_latent_ws = take(cur, e->latent_ws_floats);
+  e->latent_event = nullptr;
   // split-K / reduction scratch: the largest consumer among wgrads, KHM and the recon partials
   size_t pf = khm_workspace_floats(B, e->D, cfg->K);
   const size_t rp = recon_partials_floats(B * cfg->C, cfg->P);
@@ -675,7 +725,7 @@ int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* gra
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   e->next_event = 0;
-  int rc = three_forward(e, params, x, uv, ws, st);
+  int rc = forward_with_latent_losses(e, params, grads, x, uv, ws, st);
   if (rc) return rc;
   return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st);
 }
@@ -687,7 +737,7 @@ int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   e->next_event = 0;
-  int rc = three_forward(e, params, x, uv, ws, st);
+  int rc = forward_with_latent_losses(e, params, nullptr, x, uv, ws, st);
   if (rc) return rc;
   return losses_and_backward(e, params, nullptr, x, y1, y2, y3, terms, ws, st);
 }
