@@ -47,6 +47,8 @@ def parse():
                     help="also time the roofline kernel on rotating buffers (every byte from HBM); adds roofline_cold")
     ap.add_argument("--cpu-steps", type=int, default=6)
     ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--save-tuning", default=None, metavar="PATH",
+                    help="write the implicit-GEMM tile configurations measured in this run (lshm_amd/tuned_gfx950.txt)")
     ap.add_argument("--only-khm", action="store_true", help="time only the K-harmonic kernel (dev aid)")
     return ap.parse_args()
 
@@ -102,12 +104,13 @@ def _pmc_traffic(kernel_key):
 
 
 def dominant_kernel_roofline(tr, dev, cold=False):
-    """The kernel with the largest share of the step (6 launches, ~6 % of the time): the implicit-GEMM
-    conv1d forward of the outermost 1-D layer, netT and netF sharing the launch -- conv0 of
-    AutoEncoder1DCNN ((B,4,16384) -> (B,8,4096), src/lofar_models.py:115,158) in both forwards and, with the
-    same GEMM shape, the data gradient of tconv5 (:142,183).  All six map to the same kernel name and
-    problem size, so the rocprofv3 average in profiles/ is directly comparable.  Algorithmic bytes per
-    launch = read inputs + write outputs of both problems (weights ignored) = 2*4*(B*4*16384 + B*8*4096)."""
+    """The kernel shape with the largest share of the step (3 launches, ~5 % of the time): the
+    implicit-GEMM k4 s4 transposed conv1d of the outermost 1-D decoder layer, netT and netF sharing the
+    launch -- tconv5 of AutoEncoder1DCNN ((B,8,4096) -> (B,4,16384), src/lofar_models.py:142,183) in both
+    forwards and, as the same GEMM, the data gradient of conv0 (:115).  With the committed tile table
+    (lshm_amd/tuned_gfx950.txt) this shape and only this shape runs as igemm_kernel<Conv1dDgrad,128,16,16>,
+    so the rocprofv3 average in profiles/ is directly comparable.  Algorithmic bytes per launch = read inputs +
+    write outputs of both problems (weights ignored) = 2*4*(B*8*4096 + B*4*16384)."""
     from lshm_amd import _lib as L
     lib = L.load()
     B = tr.B
@@ -115,26 +118,26 @@ def dominant_kernel_roofline(tr, dev, cold=False):
     # Infinity Cache; re-launching on one buffer set reproduces that (and matches the rocprofv3 in-step
     # average).  --roofline-cold rotates three sets (0.6 GB) so that every byte comes from HBM.
     nsets = 3 if cold else 1
-    xs = [torch.randn(B, 4, 16384, device=dev) for _ in range(2 * nsets)]
+    xs = [torch.randn(B, 8, 4096, device=dev) for _ in range(2 * nsets)]
     ws_ = [torch.randn(8, 4, 4, device=dev) * 0.1 for _ in range(2)]
-    bs = [torch.zeros(8, device=dev) for _ in range(2)]
-    ys = [torch.empty(B, 8, 4096, device=dev) for _ in range(2 * nsets)]
+    bs = [torch.zeros(4, device=dev) for _ in range(2)]
+    ys = [torch.empty(B, 4, 16384, device=dev) for _ in range(2 * nsets)]
     turn = [0]
 
     def run():
         i = 2 * (turn[0] % nsets)
         turn[0] += 1
-        L.check(lib.lshm_conv_fwd_pair(2, L.ptr(xs[i]), L.ptr(ws_[0]), L.ptr(bs[0]), L.ptr(ys[i]), L.ptr(xs[i + 1]),
-                                       L.ptr(ws_[1]), L.ptr(bs[1]), L.ptr(ys[i + 1]), B, 4, 8, 1, 16384, 0, 0, 1, None,
+        L.check(lib.lshm_conv_fwd_pair(3, L.ptr(xs[i]), L.ptr(ws_[0]), L.ptr(bs[0]), L.ptr(ys[i]), L.ptr(xs[i + 1]),
+                                       L.ptr(ws_[1]), L.ptr(bs[1]), L.ptr(ys[i + 1]), B, 8, 4, 1, 4096, 0, 0, 0, None,
                                        0, L.stream()))
     ms = event_time_ms(run, 48, warm=6)
     nbytes = 2 * 4.0 * (xs[0].numel() + ys[0].numel())
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "lshm::igemm_kernel<lshm::Conv1dFwd, 128, 16, 16> (1-D conv0 forward, netT+netF in one launch)",
+    return {"kernel": "lshm::igemm_kernel<lshm::Conv1dDgrad, 128, 16, 16> (1-D tconv5 forward, netT+netF in one launch)",
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "ms": round(ms, 4), "bytes_per_launch": nbytes,
             "buffers": "rotating, HBM-cold" if cold else "re-used, cache-warm as in the step",
-            "traffic": _pmc_traffic("igemm_kernel<Conv1dFwd, 128, 16, 16>") if B == 256 and not cold else None}
+            "traffic": _pmc_traffic("igemm_kernel<Conv1dDgrad, 128, 16, 16>") if B == 256 and not cold else None}
 
 
 def cpu_baseline(args):
@@ -264,6 +267,9 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0 and args.save_tuning:
+        from lshm_amd import _lib as L
+        print(f"[bench] {L.save_tuning(args.save_tuning)} tuned shapes -> {args.save_tuning}", file=sys.stderr)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)

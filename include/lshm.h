@@ -50,6 +50,12 @@ const char* lshm_last_error_string(void);
  * caches the winner; mode 0: static heuristic.  force >= 0 pins configuration `force` (0..11) for
  * every launch (parity tests sweep it); -1 unpins.  Clears the cache. */
 void lshm_set_tuning(int mode, int force);
+/* The cache as text ("policy M N K Z groups config" per line).  export returns the buffer size needed
+ * (terminating 0 included) and fills buf up to cap; import merges entries and returns how many it read.
+ * Importing the table measured on the target GPU makes runs start without timing launches and
+ * reproduce each other bit for bit. */
+size_t lshm_tuning_export(char* buf, size_t cap);
+int lshm_tuning_import(const char* text);
 
 /* ---- harmonic features: kron(scales, uv) -> cat(sin, cos)   src/lofar_models.py:60-62,145-147
  * uv (B,2), scales (H) -> out (B,4H) */

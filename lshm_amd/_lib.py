@@ -14,6 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # LSHM_LIB lets a developer A/B two builds of the same C ABI in one process launch
 LIB_PATH = os.environ.get("LSHM_LIB") or os.path.join(_HERE, "lib", "liblshm_hip.so")
+TUNE_FILE = os.path.join(_HERE, "tuned_gfx950.txt")
 
 _lib = None
 
@@ -38,6 +39,8 @@ _SIGNATURES = {
     "lshm_version": (c_int, []),
     "lshm_last_error_string": (C.c_char_p, []),
     "lshm_set_tuning": (None, [c_int, c_int]),
+    "lshm_tuning_export": (c_size_t, [c_void_p, c_size_t]),
+    "lshm_tuning_import": (c_int, [C.c_char_p]),
     "lshm_uv_harmonics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lshm_conv_workspace_floats": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "lshm_conv_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
@@ -118,7 +121,25 @@ def load():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    # tile configurations measured on the target GPU (bench.py --save-tuning): no timing launches, and
+    # every run picks the same kernels.  LSHM_TUNE_FILE overrides the path; empty disables.
+    path = os.environ.get("LSHM_TUNE_FILE", TUNE_FILE)
+    if path and os.path.exists(path):
+        with open(path, "rb") as f:
+            lib.lshm_tuning_import(f.read())
     return lib
+
+
+def save_tuning(path: str) -> int:
+    """Write the tile-configuration cache of this process to `path` (merged with what was imported)."""
+    lib = load()
+    n = lib.lshm_tuning_export(None, 0)
+    buf = C.create_string_buffer(n)
+    lib.lshm_tuning_export(buf, n)
+    lines = sorted(set(buf.value.decode().splitlines()), key=lambda l: [int(v) for v in l.split()])
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return len(lines)
 
 
 def check(rc: int, what: str = ""):

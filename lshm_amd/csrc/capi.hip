@@ -53,6 +53,8 @@ extern "C" {
 int lshm_version(void) { return 100; }
 const char* lshm_last_error_string(void) { return g_err; }
 void lshm_set_tuning(int mode, int force) { igemm_set_tuning(mode, force); }
+size_t lshm_tuning_export(char* buf, size_t cap) { return igemm_tuning_export(buf, cap); }
+int lshm_tuning_import(const char* text) { return igemm_tuning_import(text); }
 
 int lshm_uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, lshm_stream_t s) {
   REQUIRE(uv && scales && out && H > 0 && B >= 0, "uv_harmonics: bad argument");

@@ -13,8 +13,11 @@
 //
 // 64-wide wavefronts: a 256-thread workgroup is 4 waves stacked along M; each
 // wave owns (BM/64) x (BN/16) accumulator tiles.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <string>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -254,6 +257,7 @@ __device__ __forceinline__ float epi(float v, float bias, int act) {
 // --------------------------------------------------------------------------
 struct Conv2dFwd {
   static constexpr bool A_M_FAST = true, B_N_FAST = false;
+  static constexpr int ID = 0;  // stable key of the tuning cache
   using Params = Conv2dFwdParams;
   struct FastA { const float* base; int iy0, ix0; };
   struct FastB { int k; };
@@ -311,6 +315,7 @@ struct Conv2dFwd {
 // --------------------------------------------------------------------------
 struct Conv2dDgrad {
   static constexpr bool A_M_FAST = true, B_N_FAST = true;
+  static constexpr int ID = 1;  // stable key of the tuning cache
   using Params = Conv2dDgradParams;
   struct FastA { const float* base; int mm, nn; };
   struct FastB { int n; };
@@ -377,6 +382,7 @@ struct Conv2dDgrad {
 // --------------------------------------------------------------------------
 struct Conv2dWgrad {
   static constexpr bool A_M_FAST = false, B_N_FAST = false;
+  static constexpr int ID = 2;  // stable key of the tuning cache
   using Params = Conv2dWgradParams;
   struct FastA { const float* base; };
   struct FastB { const float* base; int iy0, ix0; };
@@ -419,6 +425,7 @@ struct Conv2dWgrad {
 // --------------------------------------------------------------------------
 struct Conv1dFwd {
   static constexpr bool A_M_FAST = true, B_N_FAST = false;
+  static constexpr int ID = 3;  // stable key of the tuning cache
   using Params = Conv1dFwdParams;
   struct FastA { const float* base; int j0; };
   struct FastB { int k; };
@@ -468,6 +475,7 @@ struct Conv1dFwd {
 // --------------------------------------------------------------------------
 struct Conv1dDgrad {
   static constexpr bool A_M_FAST = true, B_N_FAST = true;
+  static constexpr int ID = 4;  // stable key of the tuning cache
   using Params = Conv1dDgradParams;
   struct FastA { const float* base; };
   struct FastB { int n; };
@@ -523,6 +531,7 @@ struct Conv1dDgrad {
 // --------------------------------------------------------------------------
 struct Conv1dWgrad {
   static constexpr bool A_M_FAST = false, B_N_FAST = false;
+  static constexpr int ID = 5;  // stable key of the tuning cache
   using Params = Conv1dWgradParams;
   struct FastA { const float* base; };
   struct FastB { const float* base; int pos0; };
@@ -560,6 +569,7 @@ struct Conv1dWgrad {
 template <bool AMF, bool BNF>
 struct Strided {
   static constexpr bool A_M_FAST = AMF, B_N_FAST = BNF;
+  static constexpr int ID = 6 + 2 * (AMF ? 1 : 0) + (BNF ? 1 : 0);
   using Params = StridedGemmParams;
   struct FastA { int i; };
   struct FastB { int i; };
@@ -727,16 +737,50 @@ static std::mutex g_tune_mu;
 static std::map<TuneKey, int> g_tuned;
 static int g_tune_mode = -1;   // -1: read LSHM_TUNE on first use; 0 off; 1 on
 static int g_tune_force = -1;  // >= 0: every launch uses this configuration (tests)
-static int g_next_policy = 0;
 template <class P>
-static int policy_id() {
-  static const int id = g_next_policy++;
-  return id;
-}
+static int policy_id() { return P::ID; }
 template <class T>
 static auto accumulates(const T& p, int) -> decltype(p.accumulate, true) { return p.accumulate != 0; }
 template <class T>
 static bool accumulates(const T&, long) { return false; }
+
+// Cache <-> text, one "policy M N K Z groups config" line per shape: lets a process start with the
+// configurations measured earlier (same results bit for bit from run to run, no timing launches).
+size_t igemm_tuning_export(char* buf, size_t cap) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  std::string out;
+  char line[96];
+  for (const auto& kv : g_tuned) {
+    const TuneKey& k = kv.first;
+    snprintf(line, sizeof line, "%d %d %d %d %d %d %d\n", k.pol, k.M, k.N, k.K, k.Z, k.G, kv.second);
+    out += line;
+  }
+  if (buf && cap > 0) {
+    const size_t n = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), n);
+    buf[n] = 0;
+  }
+  return out.size() + 1;
+}
+int igemm_tuning_import(const char* text) {
+  if (!text) return 0;
+  std::lock_guard<std::mutex> lk(g_tune_mu);
+  int n = 0;
+  const char* p = text;
+  while (*p) {
+    TuneKey k;
+    int cfg = 0, used = 0;
+    if (sscanf(p, "%d %d %d %d %d %d %d%n", &k.pol, &k.M, &k.N, &k.K, &k.Z, &k.G, &cfg, &used) == 7 && cfg >= 0 &&
+        cfg < kNumConfigs) {
+      g_tuned[k] = cfg;
+      ++n;
+      p += used;
+    }
+    while (*p && *p != '\n') ++p;
+    if (*p == '\n') ++p;
+  }
+  return n;
+}
 
 void igemm_set_tuning(int mode, int force) {
   std::lock_guard<std::mutex> lk(g_tune_mu);
@@ -777,12 +821,13 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
     return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st, defer);
   int best = heuristic;
   float best_ms = 1e30f;
+  static const int reps = getenv("LSHM_TUNE_REPS") ? std::max(1, atoi(getenv("LSHM_TUNE_REPS"))) : 3;
   for (int c = 0; c < kNumConfigs; ++c) {
     if ((c & 1) && M <= 64) continue;
     int rc = launch_idx<P>(c, p, p1, M, N, Z, ws, wsf, st);  // warm
     if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     (void)hipEventRecord(e0, st);
-    for (int r = 0; r < 3; ++r) launch_idx<P>(c, p, p1, M, N, Z, ws, wsf, st);
+    for (int r = 0; r < reps; ++r) launch_idx<P>(c, p, p1, M, N, Z, ws, wsf, st);
     (void)hipEventRecord(e1, st);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -798,7 +843,7 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
   if (getenv("LSHM_TUNE_LOG"))
     fprintf(stderr, "[lshm tune] policy %d M=%d N=%d K=%d Z=%d G=%d -> cfg %d (BM %d BK %d split-mode %d) %.1f us\n",
             key.pol, M, N, p.K, Z, key.G, best, (best & 1) ? 128 : 64, (best & 2) ? 32 : 16, best >> 2,
-            best_ms * 1000.f / 3);
+            best_ms * 1000.f / reps);
   return launch_idx<P>(best, p, p1, M, N, Z, ws, wsf, st, defer);  // candidates ran their combine in place
 }
 

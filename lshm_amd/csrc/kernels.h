@@ -118,6 +118,8 @@ int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
 // mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
 void igemm_set_tuning(int mode, int force);
+size_t igemm_tuning_export(char* buf, size_t cap);  // returns the bytes needed (with the terminating 0)
+int igemm_tuning_import(const char* text);          // returns the entries read
 
 // ---- direct LDS-patch kernels for the outer 2-D layers (conv_direct.hip) ----
 bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws);
