@@ -104,13 +104,12 @@ def _pmc_traffic(kernel_key):
 
 
 def dominant_kernel_roofline(tr, dev, cold=False):
-    """The kernel shape with the largest share of the step (3 launches, ~5 % of the time): the
-    implicit-GEMM k4 s4 transposed conv1d of the outermost 1-D decoder layer, netT and netF sharing the
-    launch -- tconv5 of AutoEncoder1DCNN ((B,8,4096) -> (B,4,16384), src/lofar_models.py:142,183) in both
-    forwards and, as the same GEMM, the data gradient of conv0 (:115).  With the committed tile table
-    (lshm_amd/tuned_gfx950.txt) this shape and only this shape runs as igemm_kernel<Conv1dDgrad,128,16,16>,
-    so the rocprofv3 average in profiles/ is directly comparable.  Algorithmic bytes per launch = read inputs +
-    write outputs of both problems (weights ignored) = 2*4*(B*8*4096 + B*4*16384)."""
+    """The largest convolution launch of the 1-D autoencoders: the k4 s4 transposed conv1d of the
+    outermost decoder layer, netT and netF sharing the launch -- tconv5 of AutoEncoder1DCNN ((B,8,4096) ->
+    (B,4,16384), src/lofar_models.py:142,183), run in the closure forward and in the no-grad forward.  Its
+    kernel name (tconv1d_stream_kernel<8,4,false>) maps to exactly this shape, so the rocprofv3 average in
+    profiles/ is directly comparable.  Algorithmic bytes per launch = read inputs + write outputs of both
+    problems (weights ignored) = 2*4*(B*8*4096 + B*4*16384)."""
     from lshm_amd import _lib as L
     lib = L.load()
     B = tr.B
@@ -133,11 +132,11 @@ def dominant_kernel_roofline(tr, dev, cold=False):
     ms = event_time_ms(run, 48, warm=6)
     nbytes = 2 * 4.0 * (xs[0].numel() + ys[0].numel())
     ach = nbytes / (ms * 1e-3) / 1e9
-    return {"kernel": "lshm::igemm_kernel<lshm::Conv1dDgrad, 128, 16, 16> (1-D tconv5 forward, netT+netF in one launch)",
+    return {"kernel": "lshm::tconv1d_stream_kernel<8, 4, false> (1-D tconv5 forward, netT+netF in one launch)",
             "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(ach / HBM_PEAK_GBS, 4), "ms": round(ms, 4), "bytes_per_launch": nbytes,
             "buffers": "rotating, HBM-cold" if cold else "re-used, cache-warm as in the step",
-            "traffic": _pmc_traffic("igemm_kernel<Conv1dDgrad, 128, 16, 16>") if B == 256 and not cold else None}
+            "traffic": _pmc_traffic("tconv1d_stream_kernel<8, 4, false>") if B == 256 and not cold else None}
 
 
 def cpu_baseline(args):

@@ -869,9 +869,11 @@ int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t 
   return launch_auto<Conv2dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1) {
+  if (g_tune_force < 0 && conv1d_stream_supported(p) && (!p1 || conv1d_stream_supported(*p1))) return conv1d_stream(p, p1, st);
   return launch_auto<Conv1dFwd>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dDgradParams* p1) {
+  if (g_tune_force < 0 && tconv1d_stream_supported(p) && (!p1 || tconv1d_stream_supported(*p1))) return tconv1d_stream(p, p1, st);
   return launch_auto<Conv1dDgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1,

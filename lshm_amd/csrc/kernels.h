@@ -116,6 +116,11 @@ int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t 
 int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
                  hipStream_t st, const StridedGemmParams* p1 = nullptr, GradJobs* defer = nullptr);
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
+// streaming kernels for the outer 1-D layers (conv1d_stream.hip); conv1d_fwd / conv1d_dgrad use them when they apply
+bool conv1d_stream_supported(const Conv1dFwdParams& p);
+int conv1d_stream(const Conv1dFwdParams& p, const Conv1dFwdParams* p1, hipStream_t st);
+bool tconv1d_stream_supported(const Conv1dDgradParams& p);
+int tconv1d_stream(const Conv1dDgradParams& p, const Conv1dDgradParams* p1, hipStream_t st);
 // mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
 void igemm_set_tuning(int mode, int force);
 size_t igemm_tuning_export(char* buf, size_t cap);  // returns the bytes needed (with the terminating 0)

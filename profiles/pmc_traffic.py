@@ -19,7 +19,8 @@ def collect(d, counter):
 
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 ALGO = {  # algorithmic bytes per launch at B=256
-    "igemm_kernel<Conv1dDgrad, 128, 16, 16>": 201326592,
+    "tconv1d_stream_kernel<8, 4, false>": 201326592,
+    "conv1d_stream_kernel<4, 8, true>": 201326592,
     "tconv2d_direct_kernel<8, 4, 4, 64>": 100663296,
     "conv2d_direct_kernel<4, 8, 4, 64>": 100663296,
     "conv2d_wgrad_direct_kernel<8, 4, 4, 64>": 100663296,
