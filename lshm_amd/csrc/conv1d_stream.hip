@@ -104,6 +104,161 @@ __global__ __launch_bounds__(256) void conv1d_stream_kernel(const Conv1dFwdParam
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// k4 s4 weight gradient of the same layers, bias gradient fused, no LDS staging:
+//   dW[cs, cb, t] = sum_{b,j} small[b,cs,j] * big[b,cb,4j-pad+t]
+// v_mfma_f32_4x4x1_16b_f32 runs 16 independent 4x4 outer products per instruction (measured layout:
+// D[lane l][reg r] += A[lane 4*(l/4)+r] * B[lane l]).  Slot b = l/4 carries one position, the A quad
+// of a slot 4 small channels, the B quad 4 big channels at one tap: every lane of every instruction is
+// useful for 8/12 and 4/8 channels, where the 16x16 tile would be half empty.  A wavefront walks tiles
+// of 64 positions: a lane loads one float4 of `small` (4 positions of its channel -> 4 MFMA steps) and
+// four float4 of `big` (the 16 taps of those positions) straight from global memory into registers,
+// the next tile's loads in flight while the current tile's MFMAs run.  Each slot accumulates its own
+// positions; slots, wavefronts and workgroups are combined at the end in a fixed order.
+// ----------------------------------------------------------------------------------------------
+template <int CS, int CB>
+__global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* __restrict__ small0,
+                                                                  const float* __restrict__ small1, long s_bs,
+                                                                  const float* __restrict__ big0,
+                                                                  const float* __restrict__ big1, long big_bs,
+                                                                  float* __restrict__ partial0,
+                                                                  float* __restrict__ partial1, int Ls, int Lb,
+                                                                  int pad, int bias_from, int ntiles) {
+  const float* small = blockIdx.y ? small1 : small0;
+  const float* big = blockIdx.y ? big1 : big0;
+  float* partial = blockIdx.y ? partial1 : partial0;
+  constexpr int GA = CS / 4, GB = CB / 4;
+  constexpr int NW = CS * CB * 4, SLAB = NW + 16;
+  __shared__ float comb[4][SLAB];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int slot = lane >> 2, q = lane & 3;
+  f32x4 acc[GA][GB][4];
+#pragma unroll
+  for (int a = 0; a < GA; ++a)
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) acc[a][g][tp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bsum[GA > GB ? GA : GB];
+#pragma unroll
+  for (int i = 0; i < (GA > GB ? GA : GB); ++i) bsum[i] = 0.f;
+
+  const int tiles_per = Ls / 64;
+  const int nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+  f32x4 ra[GA], rb[GB][4];
+  auto load_tile = [&](int tile) {
+    const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * 64;
+    const float* sb = small + (long)b * s_bs + j0 + 4 * slot;
+    const float* bb = big + (long)b * big_bs + 4L * (j0 + 4 * slot) - pad;
+#pragma unroll
+    for (int a = 0; a < GA; ++a) ra[a] = *reinterpret_cast<const f32x4*>(sb + (long)(4 * a + q) * Ls);
+    if (pad && j0 == 0 && slot == 0) {  // the window of position 0 starts one element before the row
+#pragma unroll
+      for (int g = 0; g < GB; ++g) {
+        const float* row = bb + pad + (long)(4 * g + q) * Lb;
+        float e[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * i);
+          e[4 * i] = v[0]; e[4 * i + 1] = v[1]; e[4 * i + 2] = v[2]; e[4 * i + 3] = v[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          rb[g][i] = (f32x4){i == 0 ? 0.f : e[4 * i - 1], e[4 * i], e[4 * i + 1], e[4 * i + 2]};
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[g][i] = *reinterpret_cast<const f32x4*>(bb + (long)(4 * g + q) * Lb + 4 * i);
+    }
+  };
+  if (w0 < ntiles) load_tile(w0);
+  for (int tile = w0; tile < ntiles; tile += nwaves) {
+    f32x4 ca[GA], cb_[GB][4];
+#pragma unroll
+    for (int a = 0; a < GA; ++a) ca[a] = ra[a];
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cb_[g][i] = rb[g][i];
+    if (tile + nwaves < ntiles) load_tile(tile + nwaves);
+    if (bias_from == 1) {
+#pragma unroll
+      for (int a = 0; a < GA; ++a) bsum[a] += (ca[a][0] + ca[a][1]) + (ca[a][2] + ca[a][3]);
+    } else if (bias_from == 2) {
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bsum[g] += (cb_[g][i][0] + cb_[g][i][1]) + (cb_[g][i][2] + cb_[g][i][3]);
+    }
+#pragma unroll
+    for (int st = 0; st < 4; ++st)      // position 4*slot + st of the tile
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp)    // tap
+#pragma unroll
+        for (int a = 0; a < GA; ++a)
+#pragma unroll
+          for (int g = 0; g < GB; ++g)
+            acc[a][g][tp] = __builtin_amdgcn_mfma_f32_4x4x1f32(ca[a][st], cb_[g][st][tp], acc[a][g][tp], 0, 0, 0);
+  }
+  // ---- 16 slots -> lane q of slot 0 (butterflies over lane bits 2..5), then the 4 waves through LDS
+#pragma unroll
+  for (int a = 0; a < GA; ++a)
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[a][g][tp][r];
+          v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+          // lane (slot 0, q): dW[cs = 4a + r][cb = 4g + q][tap tp]
+          if (slot == 0) comb[wave][((4 * a + r) * CB + 4 * g + q) * 4 + tp] = v;
+        }
+#pragma unroll
+  for (int i = 0; i < (GA > GB ? GA : GB); ++i) {
+    float v = bsum[i];
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (slot == 0) comb[wave][NW + 4 * i + q] = v;  // channel 4i + q of small (bias_from 1) or big (2)
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * SLAB;
+  for (int i = t; i < SLAB; i += 256) {
+    const bool live = i < NW || (bias_from == 1 && i - NW < CS) || (bias_from == 2 && i - NW < CB);
+    out[i] = live ? (comb[0][i] + comb[1][i]) + (comb[2][i] + comb[3][i]) : 0.f;
+  }
+}
+
+bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
+                                   const float* small, const float* big) {
+  const bool shape = (Cs == 8 && Cb == 4) || (Cs == 12 && Cb == 8);
+  return shape && Ls % 64 == 0 && Lb == 4 * Ls && (pad == 0 || pad == 1) && !(bias_from == 2 && pad != 0) &&
+         s_bs % 4 == 0 && big_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(small) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(big) & 15) == 0;
+}
+// one slab of Cs*Cb*4 + 16 floats per workgroup at ws (and ws2 for the second problem); returns the grid size
+int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
+                        long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
+                        int bias_from, int max_blocks, hipStream_t st, int* grid_out) {
+  const int ntiles = (Ls / 64) * B;
+  // measured at B=256: 4..8 tiles per wavefront and at most 512 workgroups per problem (more workgroups
+  // only add closing butterflies and partial slabs)
+  int grid = ntiles / 16;
+  if (grid > 512) grid = 512;
+  if (grid < 1) grid = 1;
+  if (grid > max_blocks) grid = max_blocks;
+  *grid_out = grid;
+  const dim3 g(grid, small2 ? 2 : 1);
+  if (Cs == 8)
+    hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<8, 4>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs,
+                       ws, ws2, Ls, Lb, pad, bias_from, ntiles);
+  else
+    hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<12, 8>), g, dim3(256), 0, st, small, small2, s_bs, big, big2,
+                       big_bs, ws, ws2, Ls, Lb, pad, bias_from, ntiles);
+  return check_launch("conv1d_wgrad_stream");
+}
+
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 bool tconv1d_stream_supported(const Conv1dDgradParams& p) {

@@ -579,7 +579,7 @@ bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls) {
   if (Cs == 12 && Cb == 8) return Ls % 256 == 0;
   return false;
 }
-size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)768 * (Cs * Cb * 4 + 16); }
+size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)2048 * (Cs * Cb * 4 + 16); }
 
 // second problem (small2, big2, dw2, db2) optional: both run in one launch
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
@@ -593,7 +593,14 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
   float* ws2 = ws + conv1d_wgrad_direct_workspace_floats(Cs, Cb);
   const int ntiles = (Ls / 256) * B;
   grid = ntiles < 768 / G ? ntiles : 768 / G;
-  if (Cs == 8 && Cb == 4) {
+  static const bool use_stream = getenv("LSHM_WGRAD1D_LDS") == nullptr;
+  if (use_stream && conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, pad, bias_from, s_bs, big_bs, small, big) &&
+      (!small2 || conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, pad, bias_from, s_bs, big_bs, small2, big2))) {
+    slab = Cs * Cb * 4 + 16;
+    int rc0 = conv1d_wgrad_stream(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, bias_from,
+                                  2048 / G, st, &grid);
+    if (rc0) return rc0;
+  } else if (Cs == 8 && Cb == 4) {
     slab = 8 * 4 * 4 + 16;
     hipLaunchKernelGGL((conv1d_wgrad_direct_kernel<8, 4, 256>), dim3(grid, G), dim3(256), 0, st, small, small2, s_bs,
                        big, big2, big_bs, ws, ws2, Ls, Lb, pad, bias_from, ntiles);

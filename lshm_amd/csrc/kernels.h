@@ -119,6 +119,11 @@ size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
 // streaming kernels for the outer 1-D layers (conv1d_stream.hip); conv1d_fwd / conv1d_dgrad use them when they apply
 bool conv1d_stream_supported(const Conv1dFwdParams& p);
 int conv1d_stream(const Conv1dFwdParams& p, const Conv1dFwdParams* p1, hipStream_t st);
+bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
+                                   const float* small, const float* big);
+int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
+                        long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
+                        int bias_from, int max_blocks, hipStream_t st, int* grid_out);
 bool tconv1d_stream_supported(const Conv1dDgradParams& p);
 int tconv1d_stream(const Conv1dDgradParams& p, const Conv1dDgradParams* p1, hipStream_t st);
 // mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
