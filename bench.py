@@ -139,6 +139,43 @@ def dominant_kernel_roofline(tr, dev, cold=False):
             "traffic": _pmc_traffic("tconv1d_stream_kernel<8, 4, false>") if B == 256 and not cold else None}
 
 
+def other_kernel_rooflines(tr, dev):
+    """Two more launches timed live, each alone on the stream as it runs in the forward part of the step:
+    the largest single kernel of the step (the fused reconstruction-loss pass, src/kharmonic_lofar.py:
+    137-158,175: reads x, x1, x2, x3, y1..y3 and writes the three output gradients = 10 image-sized arrays)
+    and the largest convolution of the 2-D autoencoder (conv0, (B,4,128,128) -> (B,8,64,64))."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    B = tr.B
+    out = []
+    img = [torch.randn(B, 4, 128, 128, device=dev) for _ in range(10)]
+    sums = torch.zeros(8, device=dev, dtype=torch.float64)
+    nws = lib.lshm_recon_workspace_floats(B * 4, 128)
+    ws = torch.empty(nws, device=dev)
+
+    def recon():
+        L.check(lib.lshm_recon_losses_fwd_bwd(*[L.ptr(t) for t in img[:7]], 1.0, B * 4, 128, L.ptr(sums), L.ptr(img[7]),
+                                              L.ptr(img[8]), L.ptr(img[9]), L.ptr(ws), L.stream()))
+    ms = event_time_ms(recon, 20, warm=3)
+    nbytes = 10 * 4.0 * img[0].numel()
+    out.append({"kernel": "lshm::recon_kernel (+ sum7_kernel)", "bound": "hbm", "bytes_per_launch": nbytes,
+                "ms": round(ms, 4), "achieved": round(nbytes / ms / 1e6, 1), "unit": "GB/s",
+                "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)})
+    x = img[0]
+    w = torch.randn(8, 4, 4, 4, device=dev) * 0.1
+    b = torch.zeros(8, device=dev)
+    y = torch.empty(B, 8, 64, 64, device=dev)
+
+    def conv0():
+        L.check(lib.lshm_conv_fwd(0, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, 4, 8, 128, 128, 0, 0, 1, None, 0, L.stream()))
+    ms = event_time_ms(conv0, 50, warm=5)
+    nbytes = 4.0 * (x.numel() + y.numel())
+    out.append({"kernel": "lshm::conv2d_direct_kernel<4, 8, 4, 64> (2-D conv0 forward)", "bound": "hbm",
+                "bytes_per_launch": nbytes, "ms": round(ms, 4), "achieved": round(nbytes / ms / 1e6, 1),
+                "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)})
+    return out
+
+
 def cpu_baseline(args):
     """Oracle port of the same step (torch CPU ops, the reference's per-sample / per-centroid
     loop order for KHM, similarity and augmentation), bounded sample, host cores."""
@@ -262,6 +299,7 @@ def main():
         if args.roofline_cold:
             out["roofline_cold"] = dominant_kernel_roofline(tr, dev, cold=True)
         out["khm_roofline"] = khm_roofline(dev)
+        out["other_kernels"] = other_kernel_rooflines(tr, dev)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -4,15 +4,15 @@ timeline of the last step.  Usage: tools_prof.py DIR NSTEPS [min_us]"""
 import csv, glob, sys
 d, nsteps = sys.argv[1], int(sys.argv[2])
 min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 30.0
-st = glob.glob(d + "/*/*kernel_stats.csv")[0]
+st = (glob.glob(d + "/*kernel_stats.csv") + glob.glob(d + "/*/*kernel_stats.csv"))[0]
 rows = list(csv.DictReader(open(st)))
 tot = sum(int(r['TotalDurationNs']) for r in rows)
 print(f"total kernel time per step: {tot/nsteps/1e6:.3f} ms")
-for r in rows[:28]:
+for r in rows[:40]:
     n = r['Name'].replace('lshm::', '').replace('void ', '')[:84]
     print(f"{n:86s} calls/step={int(r['Calls'])/nsteps:6.1f} ms/step={int(r['TotalDurationNs'])/nsteps/1e6:7.3f} avg={float(r['AverageNs'])/1e3:8.1f}us {float(r['Percentage']):5.1f}%")
 if min_us >= 0:
-    tr = glob.glob(d + "/*/*kernel_trace.csv")[0]
+    tr = (glob.glob(d + "/*kernel_trace.csv") + glob.glob(d + "/*/*kernel_trace.csv"))[0]
     rows = list(csv.DictReader(open(tr)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     per = len(rows) // nsteps
