@@ -216,7 +216,11 @@ template <int CS, int CB, int TH, int TW>
 __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* __restrict__ small, long s_bs,
                                                                   const float* __restrict__ big, long big_bs,
                                                                   float* __restrict__ partial, int Hs, int Ws,
-                                                                  int ntiles) {
+                                                                  int ntiles, int bias_from) {
+  // bias_from: 0 none, 1 bias gradient = sum of `small` (conv layer), 2 = sum of `big` (transposed conv);
+  // every element passes through this thread's registers on its way to LDS, and a thread always stages
+  // the same channel, so the sums cost one add per float4
+  constexpr int SLAB = CS * CB * 16 + 16;
   constexpr int TP = TH * TW;             // positions per tile
   constexpr int LDS_S = TP + 2;           // small-tile row stride: == 2 (mod 32) -> conflict-free A reads
   constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
@@ -230,6 +234,13 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
   f32x4 acc[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NQS = (CS * TH * (TW / 4) + 255) / 256;      // float4 of the small tile per thread
+  constexpr int NQB = (CB * PH * (2 * TW / 4) + 255) / 256;  // float4 of the big patch per thread
+  float bs_small[NQS], bs_big[NQB];
+#pragma unroll
+  for (int qq = 0; qq < NQS; ++qq) bs_small[qq] = 0.f;
+#pragma unroll
+  for (int qq = 0; qq < NQB; ++qq) bs_big[qq] = 0.f;
 
   const int tiles_x = Ws / TW, tiles_y = Hs / TH;
   const int Hb = 2 * Hs, Wb = 2 * Ws;
@@ -242,22 +253,33 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
     const float* bb = big + (long)b * big_bs;
     __syncthreads();
     // small tile: [cs][TH*TW] as float4 rows of TW
-    for (int i = t; i < CS * TH * (TW / 4); i += 256) {
-      const int c4 = i % (TW / 4), rr = i / (TW / 4);
-      const int row = rr % TH, cs = rr / TH;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + m0 + row) * Ws + n0 + 4 * c4);
-      float* d = &stile[cs * LDS_S + row * TW + 4 * c4];
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+#pragma unroll
+    for (int qq = 0; qq < NQS; ++qq) {
+      const int i = t + 256 * qq;
+      if (i < CS * TH * (TW / 4)) {
+        const int c4 = i % (TW / 4), rr = i / (TW / 4);
+        const int row = rr % TH, cs = rr / TH;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + m0 + row) * Ws + n0 + 4 * c4);
+        float* d = &stile[cs * LDS_S + row * TW + 4 * c4];
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        bs_small[qq] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
     }
     // big patch: rows 2*m0-1 .. 2*m0+2*TH, cols 2*n0-1 .. 2*n0+2*TW (zero outside the image)
-    for (int i = t; i < CB * PH * (2 * TW / 4); i += 256) {
-      const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
-      const int prow = rr % PH, cb = rr / PH;
-      const int iy = 2 * m0 - 1 + prow;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)iy < (unsigned)Hb) v = *reinterpret_cast<const f32x4*>(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
-      float* d = &patch[(cb * PH + prow) * PW + 1 + 4 * c4];
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+#pragma unroll
+    for (int qq = 0; qq < NQB; ++qq) {
+      const int i = t + 256 * qq;
+      if (i < CB * PH * (2 * TW / 4)) {
+        const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+        const int prow = rr % PH, cb = rr / PH;
+        const int iy = 2 * m0 - 1 + prow;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)iy < (unsigned)Hb) v = *reinterpret_cast<const f32x4*>(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
+        float* d = &patch[(cb * PH + prow) * PW + 1 + 4 * c4];
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        // halo rows belong to the neighbouring tiles: only the 2*TH interior rows count towards the bias sum
+        if (prow >= 1 && prow <= 2 * TH) bs_big[qq] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
     }
     for (int i = t; i < CB * PH * 2; i += 256) {
       const int side = i & 1, rr = i >> 1;
@@ -290,10 +312,39 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
 #pragma unroll
     for (int r = 0; r < 4; ++r) comb[wave][4 * lk + r][16 * j + lm] = acc[j][r];
   __syncthreads();
-  float* out = partial + (size_t)blockIdx.x * CS * CB * 16;
+  float* out = partial + (size_t)blockIdx.x * SLAB;
   for (int i = t; i < CS * CB * 16; i += 256) {
     const int m = i / (CB * 16), n = i - m * (CB * 16);
     out[i] = (comb[0][m][n] + comb[1][m][n]) + (comb[2][m][n] + comb[3][m][n]);
+  }
+  // ---- bias partials: per-thread sums -> per-channel workgroup sums (fixed order), slab[CS*CB*16 + c]
+  __syncthreads();
+  float* bred = patch;  // [16 channels][4 waves]
+  if (bias_from) {
+    const int nch = bias_from == 1 ? CS : CB;
+    for (int c = 0; c < nch; ++c) {
+      float v = 0.f;
+      if (bias_from == 1) {
+#pragma unroll
+        for (int qq = 0; qq < NQS; ++qq) {
+          const int i = t + 256 * qq;
+          if (i < CS * TH * (TW / 4) && (i / (TW / 4)) / TH == c) v += bs_small[qq];
+        }
+      } else {
+#pragma unroll
+        for (int qq = 0; qq < NQB; ++qq) {
+          const int i = t + 256 * qq;
+          if (i < CB * PH * (2 * TW / 4) && (i / (2 * TW / 4)) / PH == c) v += bs_big[qq];
+        }
+      }
+      v = wave_sum(v);
+      if (lane == 0) bred[c * 4 + wave] = v;
+    }
+  }
+  __syncthreads();
+  if (t < 16) {
+    const int nch = bias_from == 1 ? CS : bias_from == 2 ? CB : 0;
+    out[CS * CB * 16 + t] = t < nch ? (bred[t * 4] + bred[t * 4 + 1]) + (bred[t * 4 + 2] + bred[t * 4 + 3]) : 0.f;
   }
 }
 
@@ -302,35 +353,40 @@ bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws) {
   if (Cs == 12 && Cb == 8) return Hs % 8 == 0 && Ws % 32 == 0;
   return false;
 }
-size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)768 * Cs * Cb * 16; }
+size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)768 * (Cs * Cb * 16 + 16); }
 
-int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, int B, int Cs,
-                        int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
-                        GradJobs* defer) {
+int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
+                        int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
+                        hipStream_t st, GradJobs* defer) {
+  if (!db) bias_from = 0;
   if (wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv2d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   int grid;
   if (Cs == 8 && Cb == 4) {
     const int ntiles = (Ws / 64) * (Hs / 4) * B;
     grid = ntiles < 768 ? ntiles : 768;
     hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<8, 4, 4, 64>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
-                       big_bs, ws, Hs, Ws, ntiles);
+                       big_bs, ws, Hs, Ws, ntiles, bias_from);
   } else if (Cs == 12 && Cb == 8) {
     const int ntiles = (Ws / 32) * (Hs / 8) * B;
     grid = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<12, 8, 8, 32>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
-                       big_bs, ws, Hs, Ws, ntiles);
+                       big_bs, ws, Hs, Ws, ntiles, bias_from);
   } else {
     set_last_error("conv2d_wgrad_direct: unsupported shape");
     return LSHM_ERR_UNSUPPORTED;
   }
   int rc = check_launch("conv2d_wgrad_direct");
   if (rc) return rc;
-  const int nw = Cs * Cb * 16;
+  const int nw = Cs * Cb * 16, slab = nw + 16;
+  const int nbias = bias_from == 1 ? Cs : Cb;
   if (defer) {
-    defer->sums.push_back(SumJob{ws, dw, nw, nw, grid, 0, 0, 0, 0, accumulate, 0});
+    defer->sums.push_back(SumJob{ws, dw, slab, nw, grid, 0, 0, 0, 0, accumulate, 0});
+    if (bias_from) defer->sums.push_back(SumJob{ws + nw, db, slab, nbias, grid, 0, 0, 0, 0, accumulate, 0});
     return LSHM_OK;
   }
-  return reduce_partials(ws, dw, nw, grid, accumulate, st);
+  rc = reduce_partials_strided(ws, slab, dw, nw, grid, accumulate, st);
+  if (rc || !bias_from) return rc;
+  return reduce_partials_strided(ws + nw, slab, db, nbias, grid, accumulate, st);
 }
 
 }  // namespace lshm

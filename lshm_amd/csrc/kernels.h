@@ -142,9 +142,10 @@ int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, 
                   const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st);
 bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws);
 size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb);
-int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, int B, int Cs,
-                        int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
-                        GradJobs* defer = nullptr);
+// db (optional): bias gradient fused; bias_from 1: dz is `small` (conv), 2: dz is `big` (transposed conv)
+int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
+                        int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
+                        hipStream_t st, GradJobs* defer = nullptr);
 
 bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls);
 size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb);

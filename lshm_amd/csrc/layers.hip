@@ -225,8 +225,9 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
     if (!io2 && conv2d_wgrad_direct_supported(Cs, Cb, Hs, Ws) &&
         gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
-      rc = conv2d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, L.B, Cs, Cb, Hs, Ws, gemm_ws, gemm_wsf,
-                               accumulate, st, defer);
+      // weight and bias gradient in one pass (dz is `big` for the transposed conv, `small` otherwise)
+      return conv2d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.B, Cs, Cb, Hs,
+                                 Ws, gemm_ws, gemm_wsf, accumulate, st, defer);
     } else {
       Conv2dWgradParams p{small_of(io), big_of(io), io.dw, L.B, Cs, Hs, Ws, Cb, s_bs, big_bs,
                           g.M, g.N, g.K, accumulate, {}};
