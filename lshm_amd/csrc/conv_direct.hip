@@ -484,6 +484,164 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restr
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Same op on v_mfma_f32_4x4x1_16b_f32 for conv0 (4 -> 8 channels; as a data gradient: tconv5).  The
+// 4x4x1 form runs 16 independent 4x4 outer products per instruction, D[lane l][r] += A[lane 4*(l/4)+r]
+// * B[lane l], at the same FLOP/clk as 16x16x4 - so 8 output channels are two full instructions instead
+// of one half-empty 16-wide tile, and no lane idles in the ELU epilogue.
+//   lane l <-> output column ox = l of one output row;  A = input value under tap (ci,ky,kx) at that
+//   column, read straight from the LDS patch (two taps per ds_read_b64);  B = w[4h + l%4][ci][ky][kx];
+//   D = 4 consecutive ox of channel 4h + l%4 -> float4 stores.
+// Wavefront w takes input channel ci = w for all TH rows of the tile (its 16 taps x 2 channel groups =
+// 32 weight registers stay resident for the whole launch); the four per-channel partial tiles meet in
+// LDS and are added in channel order (fixed order: bitwise reproducible) by the wavefront that owns the row.
+// ----------------------------------------------------------------------------------------------
+template <int COUT, int TH>
+__global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restrict__ x, long x_bs,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        long y_bs, const float* __restrict__ dact, int Ho, int Wo,
+                                                        int act, int ntiles) {
+  constexpr int CIN = 4, TW = 64;
+  constexpr int NH = COUT / 4;
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;  // even row stride keeps the ds_read_b64 at column 2*ox aligned
+  static_assert(COUT % 4 == 0 && TH == 4, "one output row per wavefront in the combine");
+  __shared__ __attribute__((aligned(16))) float patch[CIN * PH * PW];
+  __shared__ f32x4 red[CIN][TH - 1][NH][64];  // partial rows of the other wavefronts (the own row stays in registers)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int q = lane & 3;
+  // B fragments of this wavefront's input channel: bw[ky][h] = taps kx 0..3 of w[4h+q][wave][ky][:]
+  f32x4 bw[4][NH];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      bw[ky][h] = *reinterpret_cast<const f32x4*>(w + (((long)(4 * h + q) * CIN + wave) * 4 + ky) * 4);
+  float bv[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) bv[h] = bias ? bias[4 * h + q] : 0.f;
+
+  const int tiles_x = Wo / TW, tiles_y = Ho / TH;
+  const int H = 2 * Ho, W = 2 * Wo;
+  // software pipeline: the next tile's patch is fetched into registers while this one computes
+  constexpr int NV4 = (CIN * PH * (2 * TW / 4) + 255) / 256, NHL = (CIN * PH * 2 + 255) / 256;
+  f32x4 rv[NV4];
+  float rh[NHL];
+  auto load_tile = [&](int tile) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    const float* xb = x + (long)b * x_bs;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int i = k * 256 + t;
+      const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+      const int prow = rr % PH, ci = rr / PH;
+      const int iy = 2 * m0 - 1 + prow;
+      rv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CIN * PH * (2 * TW / 4) && (unsigned)iy < (unsigned)H)
+        rv[k] = *reinterpret_cast<const f32x4*>(xb + ((long)ci * H + iy) * W + 2 * n0 + 4 * c4);
+    }
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int i = k * 256 + t;
+      const int side = i & 1, rr = i >> 1;
+      const int prow = rr % PH, ci = rr / PH;
+      const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
+      rh[k] = 0.f;
+      if (i < CIN * PH * 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) rh[k] = xb[((long)ci * H + iy) * W + ix];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    __syncthreads();  // the previous tile's A reads and combine reads are done
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int i = k * 256 + t;
+      if (i < CIN * PH * (2 * TW / 4)) {
+        const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+        float* d = &patch[rr * PW + 1 + 4 * c4];  // odd offset: b32 + b64 + b32
+        d[0] = rv[k][0];
+        *reinterpret_cast<float2*>(d + 1) = make_float2(rv[k][1], rv[k][2]);
+        d[3] = rv[k][3];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int i = k * 256 + t;
+      if (i < CIN * PH * 2) patch[(i >> 1) * PW + ((i & 1) ? PW - 1 : 0)] = rh[k];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+
+    // ---- this wavefront's input channel, all rows: TH*NH independent accumulator chains
+    f32x4 acc[TH][NH];
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) acc[r][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      float2 a01[TH], a23[TH];
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const float* pr = &patch[(wave * PH + 2 * r + ky) * PW + 2 * lane];
+        a01[r] = *reinterpret_cast<const float2*>(pr);
+        a23[r] = *reinterpret_cast<const float2*>(pr + 2);
+      }
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a01[r].x, bw[ky][h][0], acc[r][h], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a01[r].y, bw[ky][h][1], acc[r][h], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a23[r].x, bw[ky][h][2], acc[r][h], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a23[r].y, bw[ky][h][3], acc[r][h], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+      if (r != wave) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) red[wave][r < wave ? r : r - 1][h][lane] = acc[r][h];
+      }
+    __syncthreads();
+    // ---- row `wave`: add the four channel partials in order, epilogue, float4 stores
+    // lane (slot, q): 4 consecutive ox = 4*slot .. 4*slot+3 of channel 4h + q
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const f32x4 own = wave == 0 ? acc[0][h] : wave == 1 ? acc[1][h] : wave == 2 ? acc[2][h] : acc[3][h];
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)  // channel order 0..3 whichever wavefront adds
+        s4 += (c == wave) ? own : red[c][wave < c ? wave : wave - 1][h][lane];
+      const long g = (long)b * y_bs + ((long)(4 * h + q) * Ho + m0 + wave) * Wo + n0 + 4 * (lane >> 2);
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = s4[r] + bv[h];
+        o[r] = act ? elu(v) : v;
+      }
+      if (dact) {
+        const f32x4 sv = *reinterpret_cast<const f32x4*>(dact + g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] *= elu_grad_from_out(sv[r]);
+      }
+      *reinterpret_cast<f32x4*>(y + g) = o;
+    }
+  }
+}
+
 bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo) {
   if (Cin == 4 && Cout == 8) return Ho % 4 == 0 && Wo % 64 == 0;
   if (Cin == 8 && Cout == 12) return Ho % 8 == 0 && Wo % 32 == 0;
@@ -492,7 +650,12 @@ bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo) {
 
 int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
                   const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st) {
-  if (Cin == 4 && Cout == 8) {
+  static const bool use_q4 = getenv("LSHM_CONV2D_16x16") == nullptr;
+  if (Cin == 4 && Cout == 8 && use_q4) {
+    const int ntiles = (Wo / 64) * (Ho / 4) * B;
+    hipLaunchKernelGGL((conv2d_q4_kernel<8, 4>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x, x_bs, w,
+                       bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+  } else if (Cin == 4 && Cout == 8) {
     const int ntiles = (Wo / 64) * (Ho / 4) * B;
     hipLaunchKernelGGL((conv2d_direct_kernel<4, 8, 4, 64>), dim3(ntiles < 1280 ? ntiles : 1280), dim3(256), 0, st, x,
                        x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
