@@ -170,7 +170,7 @@ def other_kernel_rooflines(tr, dev):
         L.check(lib.lshm_conv_fwd(0, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, 4, 8, 128, 128, 0, 0, 1, None, 0, L.stream()))
     ms = event_time_ms(conv0, 50, warm=5)
     nbytes = 4.0 * (x.numel() + y.numel())
-    out.append({"kernel": "lshm::conv2d_direct_kernel<4, 8, 4, 64> (2-D conv0 forward)", "bound": "hbm",
+    out.append({"kernel": "lshm::conv2d_q4_kernel<8, 4> (2-D conv0 forward)", "bound": "hbm",
                 "bytes_per_launch": nbytes, "ms": round(ms, 4), "achieved": round(nbytes / ms / 1e6, 1),
                 "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)})
     return out

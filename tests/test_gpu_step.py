@@ -83,6 +83,29 @@ def test_step_vs_oracle_full_gradients(rica):
         assert e < 2e-4, (n, e)
 
 
+@pytest.mark.parametrize("B,K,bpb,bs", [(1, 1, 1, 1), (3, 3, 3, 1), (9, 10, 9, 1), (5, 4, 2, 3), (7, 64, 4, 2)])
+def test_step_vs_oracle_odd_shapes(B, K, bpb, bs):
+    """Ragged / minimal configurations: one patch, one cluster, the loader's 9 patches per baseline
+    (src/lofar_tools.py:157-158), a last group cut short by the batch, batch sizes that are not multiples
+    of any tile.  Loss terms and every gradient element against oracle autograd."""
+    tr, ocfg, params, M, x, uv = _trainer(B, K, bpb, bs)
+    y = [0.01 * O.closed_form((x.numel(),), f"y{k}", 1.0, 0.123 + 0.1 * k) for k in range(3)]
+    for k in range(3):
+        tr.y[k].copy_(y[k].to(DEV))
+    tr.closure_only()
+    leaves = O.flat_leaves(params, M)
+    for l in leaves:
+        l.requires_grad_(True)
+    total, terms = O.closure_losses(params, M, x, uv, y, ocfg)
+    grads = torch.autograd.grad(total, leaves)
+    t = tr.read_terms()
+    assert abs(t["total"] - total.item()) <= 1e-4 * abs(total.item())
+    names = [f"{g}.{k}" for g in O.GROUPS for k in params[g]] + ["mod.M"]
+    for n, gr in zip(names, grads):
+        e = rel_err(tr.view(n, tr.grads), gr)
+        assert e < 3e-4, (n, e)
+
+
 def test_train_groups_freeze():
     tr, ocfg, params, M, x, uv = _trainer(4, 4, 2, 2, groups=("net",))
     before = {n: tr.view(n).clone() for n in tr.layout}
