@@ -175,6 +175,163 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
   }  // tile loop
 }
 
+// ----------------------------------------------------------------------------------------------
+// The same transposed conv for tconv5 (8 -> 4 channels; as a data gradient: conv0) on
+// v_mfma_f32_4x4x1_16b_f32, one output parity at a time with only the four taps that parity uses:
+// no structurally-zero taps (the all-parity 16x16 formulation spends 9/4 of the useful MACs) and no
+// padded channel tile.   lane l <-> small column n = l of one small row;  A = small[cs][m+dy][n+dx]
+// from the LDS patch (one ds_read_b32, shared by every parity that uses that neighbour);  B =
+// w[cs][q][ky][kx] for q = l%4;  D[py][px] = 4 consecutive n of channel q.  The two px parities of
+// a lane interleave into 8 consecutive output columns -> two float4 stores per output row.
+// Wavefront (rp, ch) takes small rows {2rp, 2rp+1} and input channels 4ch..4ch+3 (64 weight
+// registers, resident); the two channel halves of a row meet in LDS and are added half 0 + half 1.
+// ----------------------------------------------------------------------------------------------
+template <int TH>
+__global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restrict__ small, long s_bs,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias,
+                                                            float* __restrict__ big, long big_bs,
+                                                            const float* __restrict__ dact, int Hs, int Ws,
+                                                            int act, int ntiles) {
+  constexpr int CS = 8, CB = 4, TW = 64;
+  constexpr int PH = TH + 2, PW = TW + 2;
+  static_assert(TH == 4, "two small rows per wavefront pair");
+  __shared__ float patch[CS * PH * PW];
+  __shared__ f32x4 red[4][2][2][64];  // [wave][py][px][lane]: the row this wavefront does not finish
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int q = lane & 3, rp = wave & 1, ch = wave >> 1;
+  // B fragments: bw[c][ky] = taps kx 0..3 of w[4ch + c][q][ky][:]
+  f32x4 bw[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky)
+      bw[c][ky] = *reinterpret_cast<const f32x4*>(w + (((long)(4 * ch + c) * CB + q) * 4 + ky) * 4);
+  const float bv = bias ? bias[q] : 0.f;
+
+  const int tiles_x = Ws / TW, tiles_y = Hs / TH;
+  constexpr int NV4 = (CS * PH * (TW / 4) + 255) / 256, NHL = (CS * PH * 2 + 255) / 256;
+  f32x4 rv[NV4];
+  float rh[NHL];
+  auto load_tile = [&](int tile) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    const float* sb = small + (long)b * s_bs;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int i = k * 256 + t;
+      const int rowi = i / (TW / 4), c4 = i - rowi * (TW / 4);
+      const int cs = rowi / PH, py = rowi - cs * PH;
+      const int iy = m0 + py - 1;
+      rv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CS * PH * (TW / 4) && (unsigned)iy < (unsigned)Hs)
+        rv[k] = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + iy) * Ws + n0 + 4 * c4);
+    }
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int i = k * 256 + t;
+      const int rowi = i >> 1, side = i & 1;
+      const int cs = rowi / PH, py = rowi - cs * PH;
+      const int iy = m0 + py - 1, ix = side ? n0 + TW : n0 - 1;
+      rh[k] = 0.f;
+      if (i < CS * PH * 2 && (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws)
+        rh[k] = sb[((long)cs * Hs + iy) * Ws + ix];
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    __syncthreads();  // the previous tile's reads of patch / red are done
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int i = k * 256 + t;
+      if (i < CS * PH * (TW / 4)) {
+        const int rowi = i / (TW / 4), c4 = i - rowi * (TW / 4);
+        float* d = &patch[rowi * PW + 1 + 4 * c4];
+        d[0] = rv[k][0]; d[1] = rv[k][1]; d[2] = rv[k][2]; d[3] = rv[k][3];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int i = k * 256 + t;
+      if (i < CS * PH * 2) patch[(i >> 1) * PW + ((i & 1) ? PW - 1 : 0)] = rh[k];
+    }
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+
+    // acc[rr][py][px]: small row 2rp + rr, output parity (py, px)
+    f32x4 acc[2][2][2];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+      for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) acc[rr][py][px] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      // neighbourhood of both rows: patch rows 2rp .. 2rp+3 (= small rows 2rp-1 .. 2rp+2), columns n-1, n, n+1
+      float a[4][3];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        const float* prow = &patch[((4 * ch + c) * PH + 2 * rp + pr) * PW + lane];
+        a[pr][0] = prow[0]; a[pr][1] = prow[1]; a[pr][2] = prow[2];
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+          for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int dyi = 0; dyi < 2; ++dyi)
+#pragma unroll
+              for (int dxi = 0; dxi < 2; ++dxi) {
+                const int dy = py - 1 + dyi, dx = px - 1 + dxi;  // dy in {py-1, py}, dx in {px-1, px}
+                const int ky = py - 2 * dy + 1, kx = px - 2 * dx + 1;
+                acc[rr][py][px] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rr + dy + 1][dx + 1], bw[c][ky][kx],
+                                                                    acc[rr][py][px], 0, 0, 0);
+              }
+    }
+    // ---- exchange: this wavefront finishes small row 2rp + ch, its partner (other ch) the other one
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) red[wave][py][px][lane] = ch == 0 ? acc[1][py][px] : acc[0][py][px];
+    __syncthreads();
+    const int partner = wave ^ 2;
+    const int m = m0 + 2 * rp + ch;
+    const int Hb = 2 * Hs, Wb = 2 * Ws;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      f32x4 s0 = ch == 0 ? acc[0][py][0] : red[partner][py][0][lane];  // channel half 0
+      f32x4 s1 = ch == 0 ? acc[0][py][1] : red[partner][py][1][lane];
+      const f32x4 h0 = ch == 0 ? red[partner][py][0][lane] : acc[1][py][0];  // channel half 1
+      const f32x4 h1 = ch == 0 ? red[partner][py][1][lane] : acc[1][py][1];
+      s0 += h0;
+      s1 += h1;
+      // lane (slot, q): output row 2m+py, columns 2*(n0 + 4 slot) .. +7 of channel q: o[2r + px] = D[py][px][r]
+      const long g = (long)b * big_bs + ((long)q * Hb + 2 * m + py) * Wb + 2 * (n0 + 4 * (lane >> 2));
+      f32x4 o0 = {s0[0] + bv, s1[0] + bv, s0[1] + bv, s1[1] + bv};
+      f32x4 o1 = {s0[2] + bv, s1[2] + bv, s0[3] + bv, s1[3] + bv};
+      if (act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o0[r] = elu(o0[r]); o1[r] = elu(o1[r]); }
+      }
+      if (dact) {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(dact + g);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(dact + g + 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o0[r] *= elu_grad_from_out(v0[r]); o1[r] *= elu_grad_from_out(v1[r]); }
+      }
+      *reinterpret_cast<f32x4*>(big + g) = o0;
+      *reinterpret_cast<f32x4*>(big + g + 4) = o1;
+    }
+  }
+}
+
 bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws) {
   if (Cs == 8 && Cb == 4) return Hs % 4 == 0 && Ws % 64 == 0;
   if (Cs == 12 && Cb == 8) return Hs % 8 == 0 && Ws % 32 == 0;
@@ -184,7 +341,12 @@ bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws) {
 int tconv2d_direct(const float* small, long s_bs, const float* w, const float* bias, float* big,
                    long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
                    hipStream_t st) {
-  if (Cs == 8 && Cb == 4) {
+  static const bool use_q4 = getenv("LSHM_CONV2D_16x16") == nullptr;
+  if (Cs == 8 && Cb == 4 && use_q4) {
+    const int ntiles = (Ws / 64) * (Hs / 4) * B;
+    hipLaunchKernelGGL((tconv2d_q4_kernel<4>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, small, s_bs, w,
+                       bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+  } else if (Cs == 8 && Cb == 4) {
     const int ntiles = (Ws / 64) * (Hs / 4) * B;
     hipLaunchKernelGGL((tconv2d_direct_kernel<8, 4, 4, 64>), dim3(ntiles < 1280 ? ntiles : 1280), dim3(256), 0, st,
                        small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
