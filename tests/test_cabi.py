@@ -105,3 +105,23 @@ def test_default_init_matches_torch_layer_defaults():
     torch.manual_seed(3)
     first = nn.Conv2d(4, 8, 4, stride=2, padding=1)
     assert torch.equal(net.conv0.weight, first.weight) and torch.equal(net.conv0.bias, first.bias)
+
+
+def test_tuning_table_roundtrip_without_device():
+    """lshm_tuning_import / lshm_tuning_export are host-side: text in, same text out (sorted by key), and the
+    committed table for gfx950 parses completely."""
+    import ctypes as C
+    import os
+    from lshm_amd import _lib
+    lib = _lib.load()
+    lib.lshm_set_tuning(1, -1)  # clears the cache
+    text = b"0 16384 48 384 1 1 10\n3 262144 12 32 1 2 9\nnot a line\n6 16 784 256 1 1 8\n"
+    assert lib.lshm_tuning_import(text) == 3
+    n = lib.lshm_tuning_export(None, 0)
+    buf = C.create_string_buffer(n)
+    lib.lshm_tuning_export(buf, n)
+    assert buf.value.decode().splitlines() == ["0 16384 48 384 1 1 10", "3 262144 12 32 1 2 9", "6 16 784 256 1 1 8"]
+    lib.lshm_set_tuning(1, -1)
+    with open(_lib.TUNE_FILE, "rb") as f:
+        table = f.read()
+    assert lib.lshm_tuning_import(table) == len(table.decode().strip().splitlines())
