@@ -139,6 +139,24 @@ def dominant_kernel_roofline(tr, dev, cold=False):
             "traffic": _pmc_traffic("tconv1d_stream_kernel<8, 4, false>") if B == 256 and not cold else None}
 
 
+def fft_roofline(tr, dev):
+    """Batched 2-D FFT feature step (Demo.ipynb:169-175): fftn(ortho) + fftshift + cat(Re,Im) + clamp on
+    (B,4,128,128).  Algorithmic bytes per image = read 64 KiB + write 128 KiB = 196,608 B."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    B = tr.B
+    x = torch.randn(B, 4, 128, 128, device=dev)
+    out = torch.empty(B, 8, 128, 128, device=dev)
+
+    def run():
+        L.check(lib.lshm_fft2_ortho_shift_cat_clamp(L.ptr(x), L.ptr(out), B, 4, 10.0, L.stream()))
+    ms = event_time_ms(run, 30, warm=3)
+    nbytes = 196608.0 * B * 4
+    return {"kernel": "lshm::fft2_feature_kernel", "shape": f"({B},4,128,128)", "bound": "hbm",
+            "bytes_per_launch": nbytes, "ms": round(ms, 4), "achieved": round(nbytes / ms / 1e6, 1), "unit": "GB/s",
+            "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+
 def other_kernel_rooflines(tr, dev):
     """Two more launches timed live, each alone on the stream as it runs in the forward part of the step:
     the largest single kernel of the step (the fused reconstruction-loss pass, src/kharmonic_lofar.py:
@@ -300,6 +318,7 @@ def main():
             out["roofline_cold"] = dominant_kernel_roofline(tr, dev, cold=True)
         out["khm_roofline"] = khm_roofline(dev)
         out["other_kernels"] = other_kernel_rooflines(tr, dev)
+        out["fft_roofline"] = fft_roofline(tr, dev)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
