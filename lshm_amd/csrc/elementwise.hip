@@ -275,13 +275,13 @@ size_t recon_partials_floats(int planes, int P) {
 int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
                          const float* y1, const float* y2, const float* y3, float rho, int planes,
                          int P, double* sums7, float* gx1p, float* gx2, float* gx3c,
-                         float* block_partials, hipStream_t st) {
+                         float* block_partials, hipStream_t st, float grad_scale) {
   if (P % TILE) { set_last_error("recon_losses: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
   const double n = (double)planes * P * P;
   double* part = reinterpret_cast<double*>(block_partials);
   dim3 grid(P / TILE, P / TILE, planes);
   hipLaunchKernelGGL(recon_kernel, grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
-                     (float)(1.0 / n), P, part, gx1p, gx2, gx3c);
+                     (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
   int rc = check_launch("recon_losses");
   if (rc) return rc;
   hipLaunchKernelGGL(sum7_kernel, dim3(7), dim3(1024), 0, st, part,

@@ -225,7 +225,8 @@ int logcosh3_fwd_bwd(const float* z, long ldz, int rows, const int* seg_cols, co
 int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
                          const float* y1, const float* y2, const float* y3, float rho, int planes,
                          int P, double* sums7, float* gx1p, float* gx2, float* gx3c,
-                         float* block_partials, hipStream_t st);
+                         float* block_partials, hipStream_t st,
+                         float grad_scale = 1.f)  /* gradients (not the sums) are multiplied by grad_scale */;
 size_t recon_partials_floats(int planes, int P);
 int combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes,
                 int P, hipStream_t st);
