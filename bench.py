@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--save-tuning", default=None, metavar="PATH",
                     help="write the implicit-GEMM tile configurations measured in this run (lshm_amd/tuned_gfx950.txt)")
+    ap.add_argument("--no-reuse-mode", action="store_true", help="skip the extra reuse_forward timing")
     ap.add_argument("--only-khm", action="store_true", help="time only the K-harmonic kernel (dev aid)")
     return ap.parse_args()
 
@@ -297,6 +298,30 @@ def main():
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
 
+    # Not the headline: the same iterations with TrainConfig.reuse_forward (iteration k+1 starts from the
+    # activations of iteration k's no-grad forward; bit-for-bit the same trajectory, tests/test_gpu_step.py::
+    # test_reuse_forward_is_bitwise_the_same_trajectory).  Reported next to `value`, which always recomputes.
+    reuse = None
+    if not use_graph and not args.no_reuse_mode:
+        tr.cfg.reuse_forward = True
+        tr.invalidate_forward()
+        for _ in range(max(2, args.warmup)):
+            tr.step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step()
+        barrier()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            tt = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt2 = tt.item()
+        tr.cfg.reuse_forward = False
+        reuse = {"value": round(world * B * args.steps / dt2, 1), "unit": "patches/s",
+                 "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                 "note": "TrainConfig.reuse_forward=True: one forward per ADMM iteration instead of two, identical results"}
+
     out = {"metric": "spectrogram-patches/sec per training step (AE+FFT+k-harmonic), 1/2/4/8 GPU",
            "value": round(value, 1), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
@@ -312,6 +337,8 @@ def main():
                              "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(STEP_BYTES_PER_PATCH * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "note": "whole step, algorithmic 15.04 MB/patch (SURVEY 8d), per GPU"}}
+    if reuse is not None:
+        out["reuse_forward_mode"] = reuse
     if rank == 0 and not args.no_roofline:
         out["roofline"] = dominant_kernel_roofline(tr, dev)
         if args.roofline_cold:

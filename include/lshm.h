@@ -209,6 +209,16 @@ int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* gra
                                  const float* uv, const float* y1, const float* y2, const float* y3,
                                  double* terms, float* workspace, size_t workspace_floats,
                                  lshm_stream_t stream);
+/* The same closure on the activations a previous forward left in `workspace`.  Inside the ADMM loop
+ * (src/kharmonic_lofar.py:131-202) the no-grad forward of iteration k (lshm_engine_multiplier_update,
+ * after the optimizer step) and the closure forward of iteration k+1 evaluate the same networks on the
+ * same minibatch with the same parameters - only the multipliers y differ, and they enter after the
+ * forward - so iteration k+1 may start from the saved activations: losses, gradients and terms are
+ * bit-for-bit those of lshm_engine_forward_backward.  The caller guarantees that the last engine call on
+ * this workspace was a forward with these params / x / uv. */
+int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads, const float* x,
+                               const float* y1, const float* y2, const float* y3, double* terms,
+                               float* workspace, size_t workspace_floats, lshm_stream_t stream);
 /* closure forward only (line-search evaluations of LBFGS): terms as above */
 int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x, const float* uv,
                              const float* y1, const float* y2, const float* y3, double* terms,

@@ -449,26 +449,27 @@ static int latent_losses(lshm_engine* e, const float* prm, float* grd, float* ws
 }
 
 // forward of the three autoencoders with the latent-space terms overlapped (side stream if there is one)
+// latent-space terms on the side stream if there is one (joined in losses_and_backward), else in line
+static int start_latent_losses(lshm_engine* e, const float* prm, float* grd, float* ws, hipStream_t st) {
+  e->latent_event = nullptr;
+  if (!(e->side_ok && e->side_wgrad)) return latent_losses(e, prm, grd, ws, st);
+  hipEvent_t ev = e->take_event();
+  if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->wstream, ev, 0) != hipSuccess) {
+    set_last_error("engine: stream fork failed");
+    return LSHM_ERR_ARG;
+  }
+  int rc = latent_losses(e, prm, grd, ws, e->wstream);
+  if (rc) return rc;
+  e->latent_event = e->take_event();
+  if (hipEventRecord(e->latent_event, e->wstream) != hipSuccess) {
+    set_last_error("engine: event record failed");
+    return LSHM_ERR_ARG;
+  }
+  return LSHM_OK;
+}
 static int forward_with_latent_losses(lshm_engine* e, const float* prm, float* grd, const float* x, const float* uv,
                                       float* ws, hipStream_t st) {
-  const bool side = e->side_ok && e->side_wgrad;
-  e->latent_event = nullptr;
-  const std::function<int()> hook = [&]() -> int {
-    if (!side) return latent_losses(e, prm, grd, ws, st);
-    hipEvent_t ev = e->take_event();
-    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->wstream, ev, 0) != hipSuccess) {
-      set_last_error("engine: stream fork failed");
-      return LSHM_ERR_ARG;
-    }
-    int rc = latent_losses(e, prm, grd, ws, e->wstream);
-    if (rc) return rc;
-    e->latent_event = e->take_event();
-    if (hipEventRecord(e->latent_event, e->wstream) != hipSuccess) {
-      set_last_error("engine: event record failed");
-      return LSHM_ERR_ARG;
-    }
-    return LSHM_OK;
-  };
+  const std::function<int()> hook = [&]() -> int { return start_latent_losses(e, prm, grd, ws, st); };
   return three_forward(e, prm, x, uv, ws, st, &hook);
 }
 
@@ -720,6 +721,18 @@ int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* gra
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   e->next_event = 0;
   int rc = forward_with_latent_losses(e, params, grads, x, uv, ws, st);
+  if (rc) return rc;
+  return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st);
+}
+
+int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads, const float* x, const float* y1,
+                               const float* y2, const float* y3, double* terms, float* ws, size_t wsf,
+                               lshm_stream_t s) {
+  ENGINE_CHECK(e && params && grads && x && y1 && y2 && y3 && terms && ws, "engine_backward_saved: null pointer");
+  if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  e->next_event = 0;
+  int rc = start_latent_losses(e, params, grads, ws, st);
   if (rc) return rc;
   return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st);
 }

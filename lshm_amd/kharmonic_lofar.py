@@ -51,6 +51,12 @@ class TrainConfig:
     # which parameter groups the optimiser updates; upstream ships {"net"} (:86-90) and asks the
     # user to alternate by hand (README.md:27-30); the benchmark trains all four
     train_groups: Tuple[str, ...] = GROUPS
+    # Inside the ADMM loop the no-grad forward that ends iteration k (after the optimiser step) and the
+    # closure forward that opens iteration k+1 are the same computation (same parameters, same minibatch;
+    # the multipliers enter after the forward).  True: iteration k+1 starts from the saved activations -
+    # bit-for-bit the same trajectory, one forward per iteration instead of two.  Only valid while
+    # parameters and inputs change through this trainer's own methods (see invalidate_forward).
+    reuse_forward: bool = False
 
 
 class KHarmonicTrainer:
@@ -111,6 +117,7 @@ class KHarmonicTrainer:
         self.uv = torch.zeros((self.B, 2), device=dev)
         self.y = [torch.zeros(self.x.numel(), device=dev) for _ in range(3)]
         self._graph = None
+        self._saved_forward = False  # the workspace holds the forward of the current params / x / uv
 
     def __del__(self):
         try:
@@ -145,6 +152,7 @@ class KHarmonicTrainer:
 
     def load_state_dicts(self, net=None, netT=None, netF=None, mod=None):
         """Accepts the reference's four state_dicts (keys 'conv0.weight' ... / 'M')."""
+        self._saved_forward = False
         with torch.no_grad():
             for prefix, sd in (("net", net), ("netT", netT), ("netF", netF), ("mod", mod)):
                 if sd is None:
@@ -195,13 +203,25 @@ class KHarmonicTrainer:
         self.uv.copy_(uv)
         for t in self.y:
             t.zero_()
+        self._saved_forward = False
+
+    def invalidate_forward(self):
+        """Call after changing parameters or inputs behind the trainer's back (e.g. through ``view``) when
+        ``reuse_forward`` is on: the next iteration recomputes its closure forward."""
+        self._saved_forward = False
 
     # ------------------------------------------------------------------ one iteration
     def _closure_fwd_bwd(self):
         P = L.ptr
-        L.check(self.lib.lshm_engine_forward_backward(
-            self._h, P(self.params), P(self.grads), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]),
-            P(self.y[2]), P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_forward_backward")
+        if self.cfg.reuse_forward and self._saved_forward and self._graph is None:
+            L.check(self.lib.lshm_engine_backward_saved(
+                self._h, P(self.params), P(self.grads), P(self.x), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+                P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_backward_saved")
+        else:
+            L.check(self.lib.lshm_engine_forward_backward(
+                self._h, P(self.params), P(self.grads), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]),
+                P(self.y[2]), P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_forward_backward")
+        self._saved_forward = False  # whatever follows (optimiser, line search) moves the parameters
         if self.world > 1:
             from .dist import allreduce_closure
             allreduce_closure(self.grads, self.terms, self.pg)
@@ -221,6 +241,7 @@ class KHarmonicTrainer:
         L.check(self.lib.lshm_engine_multiplier_update(
             self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
             P(self.ws), self.ws_floats, L.stream()), "engine_multiplier_update")
+        self._saved_forward = True  # forward of the parameters the next closure will see
 
     def _step_impl(self):
         self._closure_fwd_bwd()
@@ -228,7 +249,9 @@ class KHarmonicTrainer:
         self._multipliers()
 
     def capture_graph(self, warmup: int = 2):
-        """Capture one iteration in a HIP graph (state is restored afterwards)."""
+        """Capture one iteration in a HIP graph (state is restored afterwards; a replayed iteration
+        always recomputes its closure forward)."""
+        self._saved_forward = False
         snap = [t.clone() for t in (self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -266,6 +289,7 @@ class KHarmonicTrainer:
         if torch.is_grad_enabled():
             self._closure_fwd_bwd()
         else:
+            self._saved_forward = False  # trial point of the line search
             P = L.ptr
             L.check(self.lib.lshm_engine_forward_loss(
                 self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
@@ -300,6 +324,7 @@ class KHarmonicTrainer:
     # ------------------------------------------------------------------ inference helper
     def encode(self, want_recon: bool = False):
         """Latents Mu = [mu | muT | muF] (B, L+2Lt) for the current x, uv (no grad)."""
+        self._saved_forward = False  # conservative: the encode pass re-uses the activation workspace
         c = self.cfg
         Mu = torch.empty((self.B, c.L + 2 * c.Lt), device=self.device)
         outs = [torch.empty_like(self.x) for _ in range(3)] if want_recon else [None] * 3

@@ -321,3 +321,31 @@ def test_full_size_directional_derivative():
             vals.append(float(tr.lbfgs_closure()))
     fd = (vals[0] - vals[1]) / (2 * 2e-3)
     assert abs(fd - gd) <= 2e-2 * abs(gd) + 1e-6, (fd, gd)
+
+
+def test_reuse_forward_is_bitwise_the_same_trajectory():
+    """TrainConfig.reuse_forward: iteration k+1 starts from the activations of iteration k's no-grad
+    forward.  Parameters, multipliers, Adam moments and loss terms must be bit-for-bit those of the
+    default (recomputing) trainer over several iterations, including across a new minibatch."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    out = []
+    for reuse in (False, True):
+        cfg = TrainConfig(Kc=5, reuse_forward=reuse)
+        tr = KHarmonicTrainer(cfg, batch=4, batch_per_bline=2, default_batch=2, device=DEV)
+        tr.init_parameters(seed=3)
+        x, uv = O.closed_form_inputs(4, 4)
+        tr.new_minibatch(x.to(DEV), uv.to(DEV))
+        terms = []
+        for it in range(4):
+            tr.step()
+            terms.append(tr.terms[:9].clone())
+        tr.new_minibatch((0.5 * x).to(DEV), uv.to(DEV))
+        for it in range(3):
+            tr.step()
+            terms.append(tr.terms[:9].clone())
+        out.append((tr.params.clone(), [t.clone() for t in tr.y], tr.exp_avg.clone(), torch.stack(terms)))
+    a, b = out
+    assert torch.equal(a[0], b[0])
+    assert all(torch.equal(p, q) for p, q in zip(a[1], b[1]))
+    assert torch.equal(a[2], b[2])
+    assert torch.equal(a[3], b[3])
