@@ -219,6 +219,12 @@ int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* gra
 int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads, const float* x,
                                const float* y1, const float* y2, const float* y3, double* terms,
                                float* workspace, size_t workspace_floats, lshm_stream_t stream);
+/* lshm_engine_multiplier_update that also leaves the reconstruction terms of the *next* closure in the
+ * workspace (they read the same seven image-sized arrays as the multiplier update: one pass instead of two).
+ * A following lshm_engine_backward_saved picks them up; any other forward discards them. */
+int lshm_engine_multiplier_update_next(lshm_engine* e, const float* params, const float* x, const float* uv,
+                                       float* y1, float* y2, float* y3, float* workspace,
+                                       size_t workspace_floats, lshm_stream_t stream);
 /* closure forward only (line-search evaluations of LBFGS): terms as above */
 int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x, const float* uv,
                              const float* y1, const float* y2, const float* y3, double* terms,

@@ -101,6 +101,7 @@ _SIGNATURES = {
     "lshm_engine_forward_loss": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_backward_saved": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_multiplier_update": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "lshm_engine_multiplier_update_next": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_encode": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
 }
 

@@ -212,11 +212,15 @@ int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* d
 //   gx2  = (2e - y2 - rho r2)/n           gx3c = ((2e - y3 - rho r3)/n)^T
 //   gx1p = (2e - y1 - rho r1)/n - (y2 + rho r2 + y3 + rho r3)/(2n)
 // --------------------------------------------------------------------------
+// UPD: first advance the multipliers, y_k += rho r_k (src/kharmonic_lofar.py:200-202), write them back, and
+// evaluate everything else with the new values: the multiplier update of one ADMM iteration and the
+// reconstruction terms of the next one read the same seven arrays, so they can share one pass.
+template <bool UPD>
 __global__ __launch_bounds__(256) void recon_kernel(
     const float* __restrict__ x, const float* __restrict__ x1, const float* __restrict__ x2,
-    const float* __restrict__ x3c, const float* __restrict__ y1, const float* __restrict__ y2,
-    const float* __restrict__ y3, float rho, float inv_n, int P, double* __restrict__ partials,
-    float* __restrict__ gx1p, float* __restrict__ gx2, float* __restrict__ gx3c) {
+    const float* __restrict__ x3c, float* y1, float* y2, float* y3, float rho, float inv_n, int P,
+    double* __restrict__ partials, float* __restrict__ gx1p, float* __restrict__ gx2,
+    float* __restrict__ gx3c) {
   __shared__ float tile[TILE][TILE + 1];
   __shared__ float red[4][8];
   const TileIdx t = tile_idx(P);
@@ -232,7 +236,11 @@ __global__ __launch_bounds__(256) void recon_kernel(
     const float a3 = tile[threadIdx.x][threadIdx.y + 8 * i];
     const float r1 = xv - a1, h = 0.5f * r1, r2 = h - a2, r3 = h - a3;
     const float e = a1 + a2 + a3 - xv;
-    const float m1 = y1[o], m2 = y2[o], m3 = y3[o];
+    float m1 = y1[o], m2 = y2[o], m3 = y3[o];
+    if (UPD) {
+      m1 = fmaf(rho, r1, m1); m2 = fmaf(rho, r2, m2); m3 = fmaf(rho, r3, m3);
+      y1[o] = m1; y2[o] = m2; y3[o] = m3;
+    }
     s[0] += e * e;
     s[1] += m1 * r1; s[2] += r1 * r1;
     s[3] += m2 * r2; s[4] += r2 * r2;
@@ -272,21 +280,38 @@ __global__ __launch_bounds__(1024) void sum7_kernel(const double* __restrict__ p
 size_t recon_partials_floats(int planes, int P) {
   return (size_t)planes * (P / TILE) * (P / TILE) * 7 * 2;
 }
-int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
-                         const float* y1, const float* y2, const float* y3, float rho, int planes,
-                         int P, double* sums7, float* gx1p, float* gx2, float* gx3c,
-                         float* block_partials, hipStream_t st, float grad_scale) {
+static int recon_launch(bool upd, const float* x, const float* x1, const float* x2, const float* x3c, float* y1,
+                        float* y2, float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
+                        float* gx3c, float* block_partials, hipStream_t st, float grad_scale) {
   if (P % TILE) { set_last_error("recon_losses: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
   const double n = (double)planes * P * P;
   double* part = reinterpret_cast<double*>(block_partials);
   dim3 grid(P / TILE, P / TILE, planes);
-  hipLaunchKernelGGL(recon_kernel, grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
-                     (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
+  if (upd)
+    hipLaunchKernelGGL(recon_kernel<true>, grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
+                       (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
+  else
+    hipLaunchKernelGGL(recon_kernel<false>, grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
+                       (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
   int rc = check_launch("recon_losses");
   if (rc) return rc;
   hipLaunchKernelGGL(sum7_kernel, dim3(7), dim3(1024), 0, st, part,
                      (long)grid.x * grid.y * grid.z, sums7);
   return check_launch("recon_sum7");
+}
+int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
+                         const float* y1, const float* y2, const float* y3, float rho, int planes,
+                         int P, double* sums7, float* gx1p, float* gx2, float* gx3c,
+                         float* block_partials, hipStream_t st, float grad_scale) {
+  return recon_launch(false, x, x1, x2, x3c, const_cast<float*>(y1), const_cast<float*>(y2), const_cast<float*>(y3),
+                      rho, planes, P, sums7, gx1p, gx2, gx3c, block_partials, st, grad_scale);
+}
+// y_k += rho r_k, then the reconstruction terms of the next closure with the updated multipliers
+int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
+                            float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
+                            float* gx3c, float* block_partials, hipStream_t st, float grad_scale) {
+  return recon_launch(true, x, x1, x2, x3c, y1, y2, y3, rho, planes, P, sums7, gx1p, gx2, gx3c, block_partials, st,
+                      grad_scale);
 }
 
 // gx1 = gx1p - 0.5*(gT + gFc^T)
@@ -326,9 +351,9 @@ __global__ __launch_bounds__(256) void multiplier_update_kernel(
   for (int i = 0; i < 4; ++i) {
     const long o = t.row_off[i];
     const float r1 = x[o] - x1[o], h = 0.5f * r1;
-    y1[o] += rho * r1;
-    y2[o] += rho * (h - x2[o]);
-    y3[o] += rho * (h - tile[threadIdx.x][threadIdx.y + 8 * i]);
+    y1[o] = fmaf(rho, r1, y1[o]);
+    y2[o] = fmaf(rho, h - x2[o], y2[o]);
+    y3[o] = fmaf(rho, h - tile[threadIdx.x][threadIdx.y + 8 * i], y3[o]);
   }
 }
 int multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c, float* y1,

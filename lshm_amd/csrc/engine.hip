@@ -78,6 +78,7 @@ struct lshm_engine {
   std::vector<hipEvent_t> events;
   mutable size_t next_event;
   hipEvent_t latent_event;  // set while the latent-space terms of the current forward are in flight
+  bool recon_ready;         // the workspace already holds the reconstruction terms of the next closure
   size_t o_latent_ws, latent_ws_floats;
   bool side_ok;
   bool pair_mode;  // netT/netF share launches (default) instead of running on two streams (LSHM_FORK=1)
@@ -382,6 +383,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
                          hipStream_t st, const std::function<int()>* after_latents = nullptr) {
   const lshm_step_config& c = e->cfg;
   int rc;
+  e->recon_ready = false;  // a new forward: whatever reconstruction terms the workspace held are stale
   if ((rc = uv_harmonics_host_scales(uv, c.scales, c.H, c.B, ws + e->o_uvh, st))) return rc;
   {
     const int i0[1] = {0};
@@ -476,7 +478,7 @@ static int forward_with_latent_losses(lshm_engine* e, const float* prm, float* g
 // reconstruction losses, loss terms and (when grd != null) every gradient, after forward_with_latent_losses
 static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, const float* x,
                                const float* y1, const float* y2, const float* y3, double* terms,
-                               float* ws, hipStream_t st) {
+                               float* ws, hipStream_t st, bool recon_done = false) {
   const lshm_step_config& c = e->cfg;
   const int B = c.B, D = e->D, planes = c.B * c.C;
   const double world = c.world > 0 ? c.world : 1;
@@ -485,7 +487,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   int rc;
   // reconstruction terms; the kernel's 1/n uses the local element count, rescale for world > 1 below
   // gradients carry this rank's share of the global mean (1/world folded into the kernel's 1/n)
-  if ((rc = recon_losses_fwd_bwd(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3,
+  if (!recon_done && (rc = recon_losses_fwd_bwd(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3,
                                  c.rho, planes, c.P, scal, ws + e->o_gx1p, ws + e->o_gx2,
                                  ws + e->o_gx3c, ws + e->lane[0].o_part, st, (float)(1.0 / world)))) return rc;
   const double inv_count = 1.0 / (world * (double)B * c.K * D);
@@ -615,6 +617,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->latent_ws_floats = khm_workspace_floats(B, e->D, cfg->K);
   e->o_latent_ws = take(cur, e->latent_ws_floats);
   e->latent_event = nullptr;
+  e->recon_ready = false;
   // split-K / reduction scratch: the largest consumer among wgrads, KHM and the recon partials
   size_t pf = khm_workspace_floats(B, e->D, cfg->K);
   const size_t rp = recon_partials_floats(B * cfg->C, cfg->P);
@@ -732,9 +735,30 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
   e->next_event = 0;
+  const bool recon_done = e->recon_ready;
+  e->recon_ready = false;
   int rc = start_latent_losses(e, params, grads, ws, st);
   if (rc) return rc;
-  return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st);
+  return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st, recon_done);
+}
+
+int lshm_engine_multiplier_update_next(lshm_engine* e, const float* params, const float* x, const float* uv,
+                                       float* y1, float* y2, float* y3, float* ws, size_t wsf, lshm_stream_t s) {
+  ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update_next: null pointer");
+  if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  e->next_event = 0;
+  e->recon_ready = false;
+  int rc = three_forward(e, params, x, uv, ws, st);
+  if (rc) return rc;
+  const lshm_step_config& c = e->cfg;
+  const double world = c.world > 0 ? c.world : 1;
+  rc = multiplier_update_recon(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3, c.rho,
+                               c.B * c.C, c.P, reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
+                               ws + e->o_gx2, ws + e->o_gx3c, ws + e->lane[0].o_part, st, (float)(1.0 / world));
+  if (rc) return rc;
+  e->recon_ready = true;
+  return LSHM_OK;
 }
 
 int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x, const float* uv,

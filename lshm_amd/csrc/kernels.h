@@ -228,6 +228,9 @@ int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const
                          float* block_partials, hipStream_t st,
                          float grad_scale = 1.f)  /* gradients (not the sums) are multiplied by grad_scale */;
 size_t recon_partials_floats(int planes, int P);
+int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
+                            float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
+                            float* gx3c, float* block_partials, hipStream_t st, float grad_scale = 1.f);
 int combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes,
                 int P, hipStream_t st);
 int multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c,

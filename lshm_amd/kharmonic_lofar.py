@@ -238,9 +238,11 @@ class KHarmonicTrainer:
 
     def _multipliers(self):
         P = L.ptr
-        L.check(self.lib.lshm_engine_multiplier_update(
-            self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
-            P(self.ws), self.ws_floats, L.stream()), "engine_multiplier_update")
+        # with reuse_forward the same pass also prepares the reconstruction terms of the next closure
+        fn = (self.lib.lshm_engine_multiplier_update_next if self.cfg.reuse_forward and self._graph is None
+              else self.lib.lshm_engine_multiplier_update)
+        L.check(fn(self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+                   P(self.ws), self.ws_floats, L.stream()), "engine_multiplier_update")
         self._saved_forward = True  # forward of the parameters the next closure will see
 
     def _step_impl(self):
