@@ -338,6 +338,9 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   if ((rc = dgrad(ld_dzfc1, 768 + hd, 768 + hd, 0, 0, 768 + hd, L))) return rc;
   for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{uvh, ws + LA(g).o_dcat1 + 768, grd + A(g).fcuv1w, grd + A(g).fcuv1b};
   if ((rc = wgrad(hd, 768 + hd, hd, hd))) return rc;
+  // the decoder's and the dense layers' closing sums go now (side stream, behind their producers): the
+  // tail after the last weight gradient then only has the encoder's
+  if (side && (rc = grad_jobs_finish(jobs, wst))) return rc;
   // ---- encoder
   for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_dcat1;
   for (int i = 5; i >= 0; --i) {
