@@ -341,15 +341,10 @@ bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws) {
 int tconv2d_direct(const float* small, long s_bs, const float* w, const float* bias, float* big,
                    long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
                    hipStream_t st) {
-  static const bool use_q4 = getenv("LSHM_CONV2D_16x16") == nullptr;
-  if (Cs == 8 && Cb == 4 && use_q4) {
+  if (Cs == 8 && Cb == 4) {
     const int ntiles = (Ws / 64) * (Hs / 4) * B;
     hipLaunchKernelGGL((tconv2d_q4_kernel<4>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, small, s_bs, w,
                        bias, big, big_bs, dact, Hs, Ws, act, ntiles);
-  } else if (Cs == 8 && Cb == 4) {
-    const int ntiles = (Ws / 64) * (Hs / 4) * B;
-    hipLaunchKernelGGL((tconv2d_direct_kernel<8, 4, 4, 64>), dim3(ntiles < 1280 ? ntiles : 1280), dim3(256), 0, st,
-                       small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
   } else if (Cs == 12 && Cb == 8) {
     const int ntiles = (Ws / 32) * (Hs / 8) * B;
     hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st,
@@ -812,15 +807,10 @@ bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo) {
 
 int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
                   const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st) {
-  static const bool use_q4 = getenv("LSHM_CONV2D_16x16") == nullptr;
-  if (Cin == 4 && Cout == 8 && use_q4) {
+  if (Cin == 4 && Cout == 8) {
     const int ntiles = (Wo / 64) * (Ho / 4) * B;
     hipLaunchKernelGGL((conv2d_q4_kernel<8, 4>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x, x_bs, w,
                        bias, y, y_bs, dact, Ho, Wo, act, ntiles);
-  } else if (Cin == 4 && Cout == 8) {
-    const int ntiles = (Wo / 64) * (Ho / 4) * B;
-    hipLaunchKernelGGL((conv2d_direct_kernel<4, 8, 4, 64>), dim3(ntiles < 1280 ? ntiles : 1280), dim3(256), 0, st, x,
-                       x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
   } else if (Cin == 8 && Cout == 12) {
     const int ntiles = (Wo / 32) * (Ho / 8) * B;
     hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x,
@@ -838,127 +828,11 @@ namespace lshm {
 
 // ----------------------------------------------------------------------------------------------
 // k4 s4 1-D weight gradient for the outer layers of the 1-D autoencoders (src/lofar_models.py:115-117,
-// :141-142), with the bias gradient fused:
-//   dW[cs, cb, t] = sum_{b,j} small[b,cs,j] big[b,cb,4j-pad+t]
-//   db = sum of dz over batch and positions, dz being `small` (conv) or `big` (transposed conv)
-// M = Cs (<= 16), N = Cb*4, K = all positions.  Persistent workgroups walk tiles of TL small
-// positions; the small tile and the 4*TL-long big segment are staged in LDS (big rows padded to a
-// stride == 8 (mod 32): the (channel, tap, position) lanes of a B fragment hit 32 distinct banks).
+// :141-142), bias gradient fused: launcher around conv1d_wgrad_stream_kernel (conv1d_stream.hip); one
+// slab of Cs*Cb*4 + 16 floats per workgroup, summed here or queued on the backward's job list.
 // ----------------------------------------------------------------------------------------------
-template <int CS, int CB, int TL>
-__global__ __launch_bounds__(256) void conv1d_wgrad_direct_kernel(const float* __restrict__ small0,
-                                                                  const float* __restrict__ small1, long s_bs,
-                                                                  const float* __restrict__ big0,
-                                                                  const float* __restrict__ big1, long big_bs,
-                                                                  float* __restrict__ partial0,
-                                                                  float* __restrict__ partial1, int Ls, int Lb,
-                                                                  int pad, int bias_from, int ntiles) {
-  // blockIdx.y selects one of two independent problems of the same shape (netT / netF)
-  const float* small = blockIdx.y ? small1 : small0;
-  const float* big = blockIdx.y ? big1 : big0;
-  float* partial = blockIdx.y ? partial1 : partial0;
-  constexpr int LDS_S = TL + 2;
-  constexpr int BL = 4 * TL + 8;  // == 8 (mod 32)
-  constexpr int NT = CB / 4;      // 16 columns = 4 big channels x 4 taps
-  constexpr int SLAB = CS * CB * 4 + 16;
-  static_assert(TL % 256 == 0 && CB % 4 == 0 && CS <= 16, "shape limits");
-  __shared__ float stile[CS * LDS_S];
-  __shared__ float btile[CB * BL];
-  __shared__ float comb[4][16][CB * 4 + 1];
-  __shared__ float bred[4][16];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int lm = lane & 15, lk = lane >> 4;
-  f32x4 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bsum[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) bsum[i] = 0.f;
-
-  const int tiles_per = Ls / TL;
-  // software pipeline over tiles: the next tile is loaded into registers while the MFMAs of the
-  // current one run out of LDS
-  constexpr int NS = CS * (TL / 256), NBG = CB * (4 * TL / 256);
-  float rs[NS], rbg[NBG];
-  auto load_tile = [&](int tile) {
-    const int b = tile / tiles_per, l0 = (tile - b * tiles_per) * TL;
-    const float* sb = small + (long)b * s_bs;
-    const float* bb = big + (long)b * big_bs;
-#pragma unroll
-    for (int cs = 0; cs < CS; ++cs)
-#pragma unroll
-      for (int q = 0; q < TL / 256; ++q) rs[cs * (TL / 256) + q] = sb[(long)cs * Ls + l0 + q * 256 + t];
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-      for (int q = 0; q < 4 * TL / 256; ++q) {
-        const long g = 4L * l0 - pad + q * 256 + t;
-        rbg[cb * (4 * TL / 256) + q] = (g >= 0 && g < Lb) ? bb[(long)cb * Lb + g] : 0.f;
-      }
-  };
-  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    __syncthreads();  // previous tile's MFMAs are done with the LDS buffers
-#pragma unroll
-    for (int cs = 0; cs < CS; ++cs)
-#pragma unroll
-      for (int q = 0; q < TL / 256; ++q) {
-        const float v = rs[cs * (TL / 256) + q];
-        stile[cs * LDS_S + q * 256 + t] = v;
-        if (bias_from == 1) bsum[cs] += v;
-      }
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
-#pragma unroll
-      for (int q = 0; q < 4 * TL / 256; ++q) {
-        const float v = rbg[cb * (4 * TL / 256) + q];
-        btile[cb * BL + q * 256 + t] = v;
-        if (bias_from == 2) bsum[cb] += v;
-      }
-    __syncthreads();
-    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
-#pragma unroll 4
-    for (int s = wave; s < TL / 4; s += 4) {
-      const int p = 4 * s + lk;
-      const float a = lm < CS ? stile[lm * LDS_S + p] : 0.f;
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, btile[(4 * j + (lm >> 2)) * BL + 4 * p + (lm & 3)], acc[j], 0, 0, 0);
-    }
-  }
-  // positions of `big` past the last window (4*Ls-pad .. Lb-1) belong to no tile: add them to the bias sum
-  if (bias_from == 2 && blockIdx.x == 0) {
-    for (int cb = 0; cb < CB; ++cb)
-      for (long i = (long)t; i < (long)ntiles / tiles_per * (Lb - (4L * Ls - pad)); i += 256) {
-        const long tail = Lb - (4L * Ls - pad);
-        const long bi = i / tail, r = i - bi * tail;
-        bsum[cb] += big[bi * big_bs + (long)cb * Lb + 4L * Ls - pad + r];
-      }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) comb[wave][4 * lk + r][16 * j + lm] = acc[j][r];
-  // bias: wave reduction, then the 4 waves through LDS
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const float v = wave_sum(bsum[i]);
-    if (lane == 0) bred[wave][i] = v;
-  }
-  __syncthreads();
-  float* out = partial + (size_t)blockIdx.x * SLAB;
-  for (int i = t; i < CS * CB * 4; i += 256) {
-    const int m = i / (CB * 4), n = i - m * (CB * 4);
-    out[i] = (comb[0][m][n] + comb[1][m][n]) + (comb[2][m][n] + comb[3][m][n]);
-  }
-  if (t < 16) out[CS * CB * 4 + t] = (bred[0][t] + bred[1][t]) + (bred[2][t] + bred[3][t]);
-}
-
 bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls) {
-  if (Cs == 8 && Cb == 4) return Ls % 256 == 0;
-  if (Cs == 12 && Cb == 8) return Ls % 256 == 0;
-  return false;
+  return ((Cs == 8 && Cb == 4) || (Cs == 12 && Cb == 8)) && Ls % 64 == 0;
 }
 size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)2048 * (Cs * Cb * 4 + 16); }
 
@@ -969,31 +843,18 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
                         float* dw2, float* db2, GradJobs* defer) {
   const int G = small2 ? 2 : 1;
   if (wsf < G * conv1d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv1d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
-  int grid, slab;
   if (!db) bias_from = 0;
-  float* ws2 = ws + conv1d_wgrad_direct_workspace_floats(Cs, Cb);
-  const int ntiles = (Ls / 256) * B;
-  grid = ntiles < 768 / G ? ntiles : 768 / G;
-  static const bool use_stream = getenv("LSHM_WGRAD1D_LDS") == nullptr;
-  if (use_stream && conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, pad, bias_from, s_bs, big_bs, small, big) &&
-      (!small2 || conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, pad, bias_from, s_bs, big_bs, small2, big2))) {
-    slab = Cs * Cb * 4 + 16;
-    int rc0 = conv1d_wgrad_stream(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, bias_from,
-                                  2048 / G, st, &grid);
-    if (rc0) return rc0;
-  } else if (Cs == 8 && Cb == 4) {
-    slab = 8 * 4 * 4 + 16;
-    hipLaunchKernelGGL((conv1d_wgrad_direct_kernel<8, 4, 256>), dim3(grid, G), dim3(256), 0, st, small, small2, s_bs,
-                       big, big2, big_bs, ws, ws2, Ls, Lb, pad, bias_from, ntiles);
-  } else if (Cs == 12 && Cb == 8) {
-    slab = 12 * 8 * 4 + 16;
-    hipLaunchKernelGGL((conv1d_wgrad_direct_kernel<12, 8, 256>), dim3(grid, G), dim3(256), 0, st, small, small2, s_bs,
-                       big, big2, big_bs, ws, ws2, Ls, Lb, pad, bias_from, ntiles);
-  } else {
-    set_last_error("conv1d_wgrad_direct: unsupported shape");
+  if (!conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, pad, bias_from, s_bs, big_bs, small, big) ||
+      (small2 && !conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, pad, bias_from, s_bs, big_bs, small2, big2))) {
+    set_last_error("conv1d_wgrad_direct: unsupported shape or alignment");
     return LSHM_ERR_UNSUPPORTED;
   }
-  int rc = check_launch("conv1d_wgrad_direct");
+  float* ws2 = ws + conv1d_wgrad_direct_workspace_floats(Cs, Cb);
+  const int slab = Cs * Cb * 4 + 16;
+  int grid = 0;
+  int rc = conv1d_wgrad_stream(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, bias_from,
+                               2048 / G, st, &grid);
+
   if (rc) return rc;
   if (defer) {
     const int nw = Cs * Cb * 4;

@@ -241,7 +241,13 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
     }
   } else {
     const int Ls = tr ? L.Win : Wo, Lb = tr ? Wo : L.Win;
-    if (conv1d_wgrad_direct_supported(Cs, Cb, Ls) && gemm_wsf >= G * conv1d_wgrad_direct_workspace_floats(Cs, Cb))
+    const int bias_from = !io.db ? 0 : tr ? 2 : 1;
+    const bool stream_ok =
+        conv1d_wgrad_direct_supported(Cs, Cb, Ls) && gemm_wsf >= G * conv1d_wgrad_direct_workspace_floats(Cs, Cb) &&
+        conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(io), big_of(io)) &&
+        (!io2 || conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(*io2),
+                                               big_of(*io2)));
+    if (stream_ok)
       // weight and bias gradient in one pass (dz is `big` for the transposed conv, `small` otherwise)
       return conv1d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.Cout, L.B, Cs,
                                  Cb, Ls, Lb, tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st,
