@@ -94,6 +94,27 @@ def khm_roofline(dev, N=1 << 20, D=256, K=10, p=4.0):
             "ms": round(ms, 4), "traffic": _pmc_traffic("khm256_kernel<0, 12, 4>") if N == 1 << 20 else None}
 
 
+def khm_distance_roofline(dev, N=1 << 20, D=256, K=10, p=4.0):
+    """The all-pairs latent<->centroid distance pass alone (evaluation mode, src/evaluate_clustering.py:111-115:
+    dist[k] = mean_n ||X_n - M_k||^p): reads X and M once, algorithmic bytes 4 (N D + K D)."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    X = torch.rand(N, D, device=dev)
+    M = torch.rand(K, D, device=dev)
+    dist = torch.empty(K, device=dev)
+    nws = lib.lshm_khm_workspace_floats(N, D, K)
+    ws = torch.empty(nws, device=dev)
+
+    def run():
+        L.check(lib.lshm_khm_mean_distances(L.ptr(X), D, L.ptr(M), N, D, K, p, L.ptr(dist), L.ptr(ws), nws, L.stream()))
+    ms = event_time_ms(run, 10)
+    nbytes = 4.0 * (N * D + K * D)
+    ach = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "khm256_kernel<2, 12, 4> + khm_reduce (distances only)", "shape": f"N={N},D={D},K={K}",
+            "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(ach / HBM_PEAK_GBS, 4), "ms": round(ms, 4)}
+
+
 def _pmc_traffic(kernel_key):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     collected in separate --pmc runs; gfx950 correction 2*FETCH_SIZE; see profiles/r01/hbm_traffic.json)."""
@@ -344,6 +365,7 @@ def main():
         if args.roofline_cold:
             out["roofline_cold"] = dominant_kernel_roofline(tr, dev, cold=True)
         out["khm_roofline"] = khm_roofline(dev)
+        out["khm_distance_roofline"] = khm_distance_roofline(dev)
         out["other_kernels"] = other_kernel_rooflines(tr, dev)
         out["fft_roofline"] = fft_roofline(tr, dev)
     if world > 1:

@@ -3,6 +3,9 @@
 // two multi-job launches instead of ~60 tiny ones (each of which costs a few microseconds of
 // dispatch whatever its size).  Summation order inside a job is fixed: results are bitwise
 // reproducible and independent of what else runs on the device.
+#include <cstdio>
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace lshm {
@@ -135,6 +138,9 @@ int grad_jobs_finish(GradJobs& jobs, hipStream_t st) {
       int lpo = 1;
       while (lpo < 64 && (long)J.n * lpo < 131072 && 4 * lpo <= J.S) lpo *= 2;
       J.lpo = lpo;
+      if (getenv("LSHM_JOBS_LOG"))
+        fprintf(stderr, "[lshm job] n=%d S=%d stride=%ld slab=%d lpo=%d blocks=%d MB=%.2f\n", J.n, J.S, J.stride, J.Mp,
+                lpo, cdiv(J.n, 256 / lpo), 4e-6 * J.n * J.S);
       tab.blk0[j] = blk;
       blk += cdiv(J.n, 256 / J.lpo);
     }

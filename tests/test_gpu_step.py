@@ -271,6 +271,32 @@ def test_full_size_step_is_bitwise_reproducible_and_finite():
     assert torch.isfinite(outs[0][0]).all() and torch.isfinite(outs[0][2]).all()
 
 
+def test_full_size_two_stream_schedule_equals_single_stream():
+    """The side stream (weight-gradient chain, latent-space terms) only re-orders launches: with
+    LSHM_WGRAD_INLINE=1 everything runs on the caller's stream.  Same kernels, same summation orders, so
+    3 iterations at B=256 must agree bit for bit - a missing event dependency would show up here."""
+    import os
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(256, 4, 128, 128, generator=g)
+    uv = 1000.0 * torch.randn(256, 2, generator=g)
+    outs = []
+    for inline in (False, True):
+        if inline:
+            os.environ["LSHM_WGRAD_INLINE"] = "1"
+        try:
+            tr = _full_trainer()  # the engine reads the switch when it is created
+        finally:
+            os.environ.pop("LSHM_WGRAD_INLINE", None)
+        tr.new_minibatch(x.to(DEV), uv.to(DEV))
+        for _ in range(3):
+            tr.step()
+        torch.cuda.synchronize()
+        outs.append((tr.params.clone(), tr.grads.clone(), tr.y[0].clone(), tr.terms[:9].clone()))
+        del tr
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_full_size_batch_additivity():
     """Every loss term is a batch mean (or batch independent): the world=2 shares of the two
     half-batches of a B=256 minibatch sum to the B=256 result (gradients and the 9 terms)."""
