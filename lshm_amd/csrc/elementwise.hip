@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void residual_split_kernel(const float* __rest
   const TileIdx t = tile_idx(P);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float v = (x[t.row_off[i]] - x1[t.row_off[i]]) * 0.5f;
+    const float v = (__builtin_nontemporal_load(x + t.row_off[i]) - x1[t.row_off[i]]) * 0.5f;
     if (out_row) out_row[t.row_off[i]] = v;
     tile[threadIdx.y + 8 * i][threadIdx.x] = v;
   }
@@ -232,11 +232,14 @@ __global__ __launch_bounds__(256) void recon_kernel(
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long o = t.row_off[i];
-    const float xv = x[o], a1 = x1[o], a2 = x2[o];
+    // x and the multipliers are not needed again soon (streamed); x2 / x3 were just written and the
+    // three gradients are read next by the backward: leave those to the cache
+    const float xv = __builtin_nontemporal_load(x + o), a1 = x1[o], a2 = x2[o];
     const float a3 = tile[threadIdx.x][threadIdx.y + 8 * i];
     const float r1 = xv - a1, h = 0.5f * r1, r2 = h - a2, r3 = h - a3;
     const float e = a1 + a2 + a3 - xv;
-    float m1 = y1[o], m2 = y2[o], m3 = y3[o];
+    float m1 = __builtin_nontemporal_load(y1 + o), m2 = __builtin_nontemporal_load(y2 + o),
+          m3 = __builtin_nontemporal_load(y3 + o);
     if (UPD) {
       m1 = fmaf(rho, r1, m1); m2 = fmaf(rho, r2, m2); m3 = fmaf(rho, r3, m3);
       y1[o] = m1; y2[o] = m2; y3[o] = m3;
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(256) void combine_dx1_kernel(const float* __restric
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long o = t.row_off[i];
-    gx1[o] = gx1p[o] - 0.5f * (gT[o] + tile[threadIdx.x][threadIdx.y + 8 * i]);
+    gx1[o] = __builtin_nontemporal_load(gx1p + o) - 0.5f * (gT[o] + tile[threadIdx.x][threadIdx.y + 8 * i]);
   }
 }
 int combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes, int P,
@@ -350,10 +353,12 @@ __global__ __launch_bounds__(256) void multiplier_update_kernel(
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long o = t.row_off[i];
-    const float r1 = x[o] - x1[o], h = 0.5f * r1;
-    y1[o] = fmaf(rho, r1, y1[o]);
-    y2[o] = fmaf(rho, h - x2[o], y2[o]);
-    y3[o] = fmaf(rho, h - tile[threadIdx.x][threadIdx.y + 8 * i], y3[o]);
+    // the multipliers are touched once per iteration: stream them past the caches
+    const float r1 = __builtin_nontemporal_load(x + o) - x1[o], h = 0.5f * r1;
+    __builtin_nontemporal_store(fmaf(rho, r1, __builtin_nontemporal_load(y1 + o)), y1 + o);
+    __builtin_nontemporal_store(fmaf(rho, h - x2[o], __builtin_nontemporal_load(y2 + o)), y2 + o);
+    __builtin_nontemporal_store(fmaf(rho, h - tile[threadIdx.x][threadIdx.y + 8 * i], __builtin_nontemporal_load(y3 + o)),
+                                y3 + o);
   }
 }
 int multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c, float* y1,
