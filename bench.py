@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--save-tuning", default=None, metavar="PATH",
                     help="write the implicit-GEMM tile configurations measured in this run (lshm_amd/tuned_gfx950.txt)")
     ap.add_argument("--no-reuse-mode", action="store_true", help="skip the extra reuse_forward timing")
+    ap.add_argument("--no-lbfgs", action="store_true", help="skip the extra LBFGS-iteration timing")
     ap.add_argument("--only-khm", action="store_true", help="time only the K-harmonic kernel (dev aid)")
     return ap.parse_args()
 
@@ -360,6 +361,26 @@ def main():
                              "note": "whole step, algorithmic 15.04 MB/patch (SURVEY 8d), per GPU"}}
     if reuse is not None:
         out["reuse_forward_mode"] = reuse
+    if not args.no_lbfgs and not use_graph:
+        # the LBFGS iteration (LBFGSNew(history 7, max_iter 4, line search, batch mode), the
+        # commented-out optimiser of src/kharmonic_lofar.py:93) reported beside the Adam iteration
+        opt = tr.make_lbfgs()
+        tr.invalidate_forward()
+        nl = max(2, args.steps // 5)
+        for _ in range(3):  # the inter-batch branch of LBFGSNew only runs from its second step on (lazy kernel loads)
+            tr.step_lbfgs(opt)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(nl):
+            tr.step_lbfgs(opt)
+        barrier()
+        dt3 = time.perf_counter() - t2
+        if world > 1:
+            tt = torch.tensor([dt3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt3 = tt.item()
+        out["lbfgs_iteration"] = {"value": round(world * B * nl / dt3, 1), "unit": "patches/s", "ms_per_step": round(dt3 / nl * 1e3, 3),
+                                  "steps": nl, "note": "one ADMM iteration with LBFGSNew.step(closure) instead of Adam"}
     if rank == 0 and not args.no_roofline:
         out["roofline"] = dominant_kernel_roofline(tr, dev)
         if args.roofline_cold:
