@@ -9,7 +9,7 @@ namespace lshm {
 
 // loss = gscale/(K*D) * sum_i [sum_{j!=i} E_ij] / (E_ii + eps),  E_ij = exp(G_ij/(n_i n_j + eps))
 // dM = C M with the K x K coefficient matrix derived in DESIGN.md (section "cluster similarity").
-__global__ __launch_bounds__(256) void cluster_sim_kernel(const float* __restrict__ M, int K, int D,
+__global__ __launch_bounds__(1024) void cluster_sim_kernel(const float* __restrict__ Mg, int K, int D,
                                                           float eps, float gscale,
                                                           double* __restrict__ loss,
                                                           float* __restrict__ dM, int accumulate) {
@@ -19,15 +19,19 @@ __global__ __launch_bounds__(256) void cluster_sim_kernel(const float* __restric
   float* nrm = C + K * K;   // K
   float* a = nrm + K;       // K : 1/(E_ii+eps)
   float* num = a + K;       // K
+  float* M = num + K;       // K*D centroids (read K times each below: keep them on chip)
   __shared__ double red[16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < K * D; i += blockDim.x) M[i] = Mg[i];
+  __syncthreads();
   // Gram matrix (upper triangle incl. diagonal), one wave per pair
   const int npairs = K * (K + 1) / 2;
   for (int pr = wave; pr < npairs; pr += nw) {
-    // unrank pair index -> (i <= j)
-    int i = 0, rem = pr;
-    while (rem >= K - i) { rem -= K - i; ++i; }
-    const int j = i + rem;
+    // unrank pair index -> (i <= j): rows 0..i-1 hold i K - i (i-1)/2 pairs
+    int i = (int)(((2 * K + 1) - sqrtf((float)((2 * K + 1) * (2 * K + 1) - 8 * pr))) * 0.5f);
+    while (i > 0 && i * K - i * (i - 1) / 2 > pr) --i;
+    while ((i + 1) * K - (i + 1) * i / 2 <= pr) ++i;
+    const int j = i + (pr - (i * K - i * (i - 1) / 2));
     float acc = 0.f;
     for (int c = lane; c < D; c += 64) acc = fmaf(M[(long)i * D + c], M[(long)j * D + c], acc);
     acc = wave_sum(acc);
@@ -98,8 +102,14 @@ int cluster_sim_fwd_bwd(const float* M, int K, int D, float eps, float gscale, d
                         float* dM, int accumulate, hipStream_t st) {
   if (!M || K < 1 || D < 1) { set_last_error("cluster_sim: bad argument"); return LSHM_ERR_ARG; }
   if (K > 64) { set_last_error("cluster_sim: supports K <= 64"); return LSHM_ERR_UNSUPPORTED; }
-  const size_t shmem = ((size_t)2 * K * K + 3 * K) * sizeof(float);
-  hipLaunchKernelGGL(cluster_sim_kernel, dim3(1), dim3(256), shmem, st, M, K, D, eps, gscale, loss,
+  const size_t shmem = ((size_t)2 * K * K + 3 * K + (size_t)K * D) * sizeof(float);
+  if (shmem > 150 * 1024) { set_last_error("cluster_sim: K*latent_dim too large for LDS"); return LSHM_ERR_UNSUPPORTED; }
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cluster_sim_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) { set_last_error("cluster_sim: cannot raise the dynamic LDS limit"); return (int)e; }
+  }
+  hipLaunchKernelGGL(cluster_sim_kernel, dim3(1), dim3(1024), shmem, st, M, K, D, eps, gscale, loss,
                      dM, accumulate);
   return check_launch("cluster_sim");
 }
