@@ -50,6 +50,48 @@ int uv_harmonics_host_scales(const float* uv, const float* scales_host, int H, i
   return check_launch("uv_harmonics");
 }
 
+// Harmonic features and every layer that sees nothing else: uvh (B, 4H) as above, then for each listed
+// dense layer out[b, n] = elu(bias[n] + sum_k w[n, k] uvh[b, k]) written straight into its slot of the
+// autoencoder's concatenation buffers (fcuv1 / fcuv3 of the three networks: src/lofar_models.py:80,89,
+// :165,174).  fmaf chain over k in ascending order, bias added last: bit-for-bit the implicit-GEMM result.
+__global__ __launch_bounds__(256) void uv_features_kernel(const float* __restrict__ uv, ScalesArg sc, int H, int B,
+                                                          float* __restrict__ uvh_out, UvLayers layers) {
+  constexpr int R = 8;  // rows per workgroup
+  __shared__ float f[R][32];
+  const int hd = 4 * H, w = 2 * H;
+  const int r0 = blockIdx.x * R;
+  for (int i = threadIdx.x; i < R * w; i += blockDim.x) {
+    const int r = i / w, j = i - r * w, b = r0 + r;
+    if (b < B) {
+      const float a = sc.s[j >> 1] * uv[2 * b + (j & 1)];
+      const float sn = sinf(a), cs = cosf(a);
+      f[r][j] = sn;
+      f[r][w + j] = cs;
+      uvh_out[(long)b * hd + j] = sn;
+      uvh_out[(long)b * hd + w + j] = cs;
+    }
+  }
+  __syncthreads();
+  const int per = R * hd;
+  for (int i = threadIdx.x; i < layers.n * per; i += blockDim.x) {
+    const int l = i / per, rem = i - l * per;
+    const int r = rem / hd, n = rem - r * hd, b = r0 + r;
+    if (b >= B) continue;
+    const float* wrow = layers.w[l] + (long)n * hd;
+    float acc = 0.f;
+    for (int k = 0; k < hd; ++k) acc = fmaf(f[r][k], wrow[k], acc);
+    layers.out[l][(long)b * layers.ld[l] + n] = elu(acc + layers.bias[l][n]);
+  }
+}
+int uv_features(const float* uv, const float* scales_host, int H, int B, float* uvh, const UvLayers& layers,
+                hipStream_t st) {
+  if (H > 8) { set_last_error("uv_features: at most 8 scales"); return LSHM_ERR_UNSUPPORTED; }
+  ScalesArg sc;
+  for (int i = 0; i < 8; ++i) sc.s[i] = i < H ? scales_host[i] : 0.f;
+  hipLaunchKernelGGL(uv_features_kernel, dim3(cdiv(B, 8)), dim3(256), 0, st, uv, sc, H, B, uvh, layers);
+  return check_launch("uv_features");
+}
+
 __global__ void elu_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ y,
                                float* __restrict__ dz, long n) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

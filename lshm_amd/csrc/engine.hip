@@ -186,7 +186,6 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
   const lshm_step_config& c = e->cfg;
   const AEPlan& a0 = e->ae[idx[0]];
   const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
-  const float* uvh = ws + e->o_uvh;
   float* part = ws + e->lane[ln].o_part;  // a pair uses the lane's two adjacent scratch regions
   const size_t pf = e->part_floats * (G > 1 ? 2 : 1);
   int rc;
@@ -207,8 +206,7 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
   auto lin = [&](long ldx, long ldy, int K, int N, int act) {
     return linear_fwd(l[0], ldx, ldy, B, K, N, act, part, pf, st, G > 1 ? &l[1] : nullptr);
   };
-  for (int g = 0; g < G; ++g) l[g] = LinFwdIO{uvh, prm + A(g).fcuv1w, prm + A(g).fcuv1b, ws + A(g).cat1 + 768};
-  if ((rc = lin(hd, 768 + hd, hd, hd, 1))) return rc;
+  // (elu(fcuv1(uvh)) and elu(fcuv3(uvh)) are already in cat1 / cat3: three_forward's uv_features)
   if (c.rica) {
     for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat1, prm + A(g).fc1w, prm + A(g).fc1b, ws + A(g).z1};
     if ((rc = lin(768 + hd, L, 768 + hd, L, 1))) return rc;
@@ -223,8 +221,6 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
       if ((rc = copy2d(ws + e->o_Mu + A(g).mu_col, D, ws + A(g).cat3, L + hd, B, L, st))) return rc;
   }
   if (after_latent && (rc = (*after_latent)())) return rc;
-  for (int g = 0; g < G; ++g) l[g] = LinFwdIO{uvh, prm + A(g).fcuv3w, prm + A(g).fcuv3b, ws + A(g).cat3 + L};
-  if ((rc = lin(hd, L + hd, hd, hd, 1))) return rc;
   for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat3, prm + A(g).fc3w, prm + A(g).fc3b, ws + A(g).d0};
   if ((rc = lin(L + hd, 768, L + hd, 768, 0))) return rc;
   for (int g = 0; g < G; ++g) in[g] = ws + A(g).d0;
@@ -387,7 +383,18 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   const lshm_step_config& c = e->cfg;
   int rc;
   e->recon_ready = false;  // a new forward: whatever reconstruction terms the workspace held are stale
-  if ((rc = uv_harmonics_host_scales(uv, c.scales, c.H, c.B, ws + e->o_uvh, st))) return rc;
+  {  // harmonic features + the six layers that depend on them alone (fcuv1 / fcuv3 of net, netT, netF)
+    UvLayers ul;
+    ul.n = 0;
+    for (int a = 0; a < 3; ++a) {
+      const AEPlan& A = e->ae[a];
+      ul.w[ul.n] = prm + A.fcuv1w; ul.bias[ul.n] = prm + A.fcuv1b;
+      ul.out[ul.n] = ws + A.cat1 + 768; ul.ld[ul.n] = 768 + e->hdim; ++ul.n;
+      ul.w[ul.n] = prm + A.fcuv3w; ul.bias[ul.n] = prm + A.fcuv3b;
+      ul.out[ul.n] = ws + A.cat3 + A.L; ul.ld[ul.n] = A.L + e->hdim; ++ul.n;
+    }
+    if ((rc = uv_features(uv, c.scales, c.H, c.B, ws + e->o_uvh, ul, st))) return rc;
+  }
   {
     const int i0[1] = {0};
     const float* in0[1] = {x};

@@ -202,6 +202,16 @@ int linear_wgrad(const LinWgradIO& io, long ldx, long lddz, int B, int K, int N,
 
 // ---- elementwise / reductions (elementwise.hip) -----------------------------
 int uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, hipStream_t st);
+// uvh plus the dense layers fed by uvh alone (weights (4H, 4H) row-major, ELU), see uv_features_kernel
+struct UvLayers {
+  int n;
+  const float* w[6];
+  const float* bias[6];
+  float* out[6];
+  long ld[6];
+};
+int uv_features(const float* uv, const float* scales_host, int H, int B, float* uvh, const UvLayers& layers,
+                hipStream_t st);
 int uv_harmonics_host_scales(const float* uv, const float* scales_host, int H, int B, float* out,
                              hipStream_t st);
 int elu_bwd(const float* gy, const float* y, float* dz, long n, hipStream_t st);
