@@ -125,3 +125,23 @@ def test_tuning_table_roundtrip_without_device():
     with open(_lib.TUNE_FILE, "rb") as f:
         table = f.read()
     assert lib.lshm_tuning_import(table) == len(table.decode().strip().splitlines())
+
+
+def test_header_is_plain_c():
+    """include/lshm.h is the contract a foreign-language binding compiles against: it must be valid C99
+    (and C++) on its own, without HIP or torch headers."""
+    import os
+    import shutil
+    import subprocess
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        with open(src, "w") as f:
+            f.write('#include "lshm.h"\nint main(void) { int (*f)(void) = lshm_version; (void)f; return 0; }\n')
+        inc = os.path.join(root, "include")
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, src], check=True)
+        subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-I", inc, src], check=True)
