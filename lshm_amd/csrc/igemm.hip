@@ -37,23 +37,30 @@ struct Pair {
   int zper;  // z-blocks per group (zgroups * splits)
 };
 
-template <class P, int BM, int BN, int BK>
+// KW = 1 ("K over the wavefronts", BM = 16): the four wavefronts share one 16-row output tile and split
+// the k-steps of every staged chunk between them; their partial tiles meet in LDS at the end and are
+// added in wavefront order.  For the deep layers (a few thousand output rows, K in the hundreds or
+// thousands) this gives many small tiles with short main loops in ONE launch, where split-K over
+// workgroups needs a second launch to combine the slabs.
+template <class P, int BM, int BN, int BK, int KW = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   const int grp = blockIdx.z / pp.zper;
   const int zblk = blockIdx.z - grp * pp.zper;
   const typename P::Params& p = pp.p[grp];
   constexpr int NT = 256;
-  constexpr int TM = BM / 64, TN = BN / 16;
+  static_assert(!KW || BM == 16, "KW tiles are 16 rows");
+  constexpr int TM = KW ? 1 : BM / 64, TN = BN / 16;
   // LDS leading dimensions: [k][m]/[k][n] images need ld == 16 (mod 32), [m][k]/[n][k]
   // images ld == BK+2, so that the 2x32-lane groups of ds_read_b32 hit 32 distinct banks.
-  constexpr int LDA = P::A_M_FAST ? (BM + 16) : (BK + 2);
+  constexpr int LDA = P::A_M_FAST ? (KW ? 48 : BM + 16) : (BK + 2);
   constexpr int LDB = P::B_N_FAST ? ((BN % 32 == 16) ? BN : BN + 16) : (BK + 2);
   constexpr int A_ELEMS = P::A_M_FAST ? BK * LDA : BM * LDA;
   constexpr int B_ELEMS = P::B_N_FAST ? BK * LDB : BN * LDB;
   // elements each thread stages per K chunk
   constexpr int NA = BM * BK / NT;
   constexpr int NB = P::B_N_FAST ? (BK + NT / BN - 1) / (NT / BN) : (BN + NT / BK - 1) / (NT / BK);
-  __shared__ float smem[A_ELEMS + B_ELEMS];
+  constexpr int RED_ELEMS = KW ? 4 * TN * 64 * 4 : 0;  // cross-wave combine buffer (reuses the tile images)
+  __shared__ __attribute__((aligned(16))) float smem[(A_ELEMS + B_ELEMS) > RED_ELEMS ? (A_ELEMS + B_ELEMS) : RED_ELEMS];
   float* As = smem;
   float* Bs = smem + A_ELEMS;
 
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   typename P::FastB fb;
   if (P::A_M_FAST) fa = P::a_fast(p, m0 + (t % BM), zg);
   if (P::B_N_FAST) fb = P::b_fast(p, n0 + (t % BN), zg);
-  const int wm0 = wave * (BM / 4);
+  const int wm0 = KW ? 0 : wave * (BM / 4);
 
   float ra[NA], rb[NB];
   // "fast" operands are affine in the K-chunk index: element i of this thread sits at
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
     __syncthreads();
     if (k0 + BK < kend) fetch(k0 + BK);  // loads stay in flight under the MFMAs below
 #pragma unroll
-    for (int ks = 0; ks < BK / 4; ++ks) {
+    for (int ks = KW ? wave : 0; ks < BK / 4; ks += KW ? 4 : 1) {
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -194,6 +201,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
     __syncthreads();
   }
   // ---- epilogue: lane holds rows 4*lk..4*lk+3 of column lm in each 16x16 tile
+  if constexpr (KW) {
+    // the four partial tiles -> LDS -> wavefront j finishes n-tile j (sum in wavefront order)
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) red[(wave * TN + j) * 64 + lane] = acc[0][j];
+    __syncthreads();
+    for (int j = wave; j < TN; j += 4) {
+      f32x4 v = red[j * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v += red[(w * TN + j) * 64 + lane];
+      const int m = m0 + 4 * lk, n = n0 + 16 * j + lm;
+      if (splits > 1) {
+        const int Mp = (p.M + 3) & ~3;
+        if (m < Mp && n < p.N) *reinterpret_cast<f32x4*>(p.sk.partial + ((long)zblk * p.N + n) * Mp + m) = v;
+      } else {
+        P::store(p, m, n, v, zg);
+      }
+    }
+    return;
+  }
   if (splits > 1) {
     // raw partial sums, layout [z][n][Mp] (Mp = M rounded up to 4); combined by splitk_epilogue_kernel
     const int Mp = (p.M + 3) & ~3;
@@ -657,7 +684,7 @@ static SplitPlan plan_split(long tiles, int K, int M, int N, int zgroups, size_t
 
 static const long kSplitTargets[3] = {768, 0, 1536};
 
-template <class P, int BM, int BN, int BK>
+template <class P, int BM, int BN, int BK, int KW = 0>
 static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1, int M, int N, int Z,
                       float* ws, size_t wsf, int smode, hipStream_t st, GradJobs* defer) {
   const int G = p1 ? 2 : 1;
@@ -674,7 +701,7 @@ static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1
   }
   pp.zper = Z * sp.splits;
   dim3 grid(cdiv(M, BM), cdiv(N, BN), Z * sp.splits * G);
-  hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK>), grid, dim3(256), 0, st, pp);
+  hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, KW>), grid, dim3(256), 0, st, pp);
   int rc = check_launch("igemm");
   if (rc || sp.splits == 1) return rc;
   if (defer && Z == 1) {  // leave the slabs where they are; the combine joins the backward's job list
@@ -697,21 +724,24 @@ static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1
 }
 
 // choose the N tile from the real N so padding waste stays small
-template <class P, int BM, int BK>
+template <class P, int BM, int BK, int KW = 0>
 static int launch_by_n(const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
                        float* ws, size_t wsf, int smode, hipStream_t st, GradJobs* defer) {
-  if (N <= 16) return launch_cfg<P, BM, 16, BK>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
-  if (N <= 32) return launch_cfg<P, BM, 32, BK>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+  if (N <= 16) return launch_cfg<P, BM, 16, BK, KW>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+  if (N <= 32) return launch_cfg<P, BM, 32, BK, KW>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
   if (N <= 48 || (N % 48 == 0 && N % 64 != 0))
-    return launch_cfg<P, BM, 48, BK>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
-  return launch_cfg<P, BM, 64, BK>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+    return launch_cfg<P, BM, 48, BK, KW>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
+  return launch_cfg<P, BM, 64, BK, KW>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
 }
 
-// A launch configuration is (M tile 64|128) x (K chunk 16|32) x (split-K mode): index bits 0, 1, 2..3.
-constexpr int kNumConfigs = 12;
+// A launch configuration is (M tile 64|128) x (K chunk 16|32) x (split-K mode): index bits 0, 1, 2..3;
+// 12, 13: the K-over-wavefronts form (16-row tiles, K chunk 64) without / with split-K.
+constexpr int kNumConfigs = 14;
 template <class P>
 static int launch_idx(int c, const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
                       float* ws, size_t wsf, hipStream_t st, GradJobs* defer = nullptr) {
+  if (c == 12) return launch_by_n<P, 16, 64, 1>(p, p1, M, N, Z, ws, wsf, 1, st, defer);
+  if (c == 13) return launch_by_n<P, 16, 64, 1>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
   const int smode = c >> 2;
   switch (c & 3) {
     case 0: return launch_by_n<P, 64, 16>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
@@ -823,7 +853,8 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
   float best_ms = 1e30f;
   static const int reps = getenv("LSHM_TUNE_REPS") ? std::max(1, atoi(getenv("LSHM_TUNE_REPS"))) : 3;
   for (int c = 0; c < kNumConfigs; ++c) {
-    if ((c & 1) && M <= 64) continue;
+    if (c < 12 && (c & 1) && M <= 64) continue;
+    if (c >= 12 && (long)cdiv(M, 16) * Z > 65535) continue;  // 16-row tiles: keep grid.x sane, these are for small M
     int rc = launch_idx<P>(c, p, p1, M, N, Z, ws, wsf, st);  // warm
     if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     (void)hipEventRecord(e0, st);
@@ -842,7 +873,8 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
   }
   if (getenv("LSHM_TUNE_LOG"))
     fprintf(stderr, "[lshm tune] policy %d M=%d N=%d K=%d Z=%d G=%d -> cfg %d (BM %d BK %d split-mode %d) %.1f us\n",
-            key.pol, M, N, p.K, Z, key.G, best, (best & 1) ? 128 : 64, (best & 2) ? 32 : 16, best >> 2,
+            key.pol, M, N, p.K, Z, key.G, best, best >= 12 ? 16 : (best & 1) ? 128 : 64,
+            best >= 12 ? 64 : (best & 2) ? 32 : 16, best == 12 ? 1 : best == 13 ? 0 : best >> 2,
             best_ms * 1000.f / reps);
   return launch_idx<P>(best, p, p1, M, N, Z, ws, wsf, st, defer);  // candidates ran their combine in place
 }

@@ -35,9 +35,9 @@ def test_conv_layer_fwd_bwd_vs_golden(kind, i):
     _check_conv_layer(kind, i)
 
 
-@pytest.mark.parametrize("cfg", range(12))
+@pytest.mark.parametrize("cfg", range(14))
 def test_every_gemm_tile_configuration(cfg):
-    """The implicit-GEMM launcher autotunes over 12 (M tile, K chunk, split-K) configurations; pin each
+    """The implicit-GEMM launcher autotunes over 14 (M tile, K chunk, split-K / K-over-wavefronts) configurations; pin each
     one in turn so that whichever the tuner picks on a given box has been checked against the goldens."""
     from lshm_amd import _lib
     lib = _lib.load()
@@ -98,10 +98,12 @@ def test_linear_vs_torch(B, K, N, act):
     if act:
         yr = torch.nn.functional.elu(yr)
     (yr * gy.cpu().double()).sum().backward()
-    assert rel_err(y, yr) < 2e-6
-    assert rel_err(x.grad, xr.grad) < 5e-6
-    assert rel_err(w.grad, wr.grad) < 5e-6
-    assert rel_err(b.grad, br.grad) < 5e-6
+    # fp32 sums of up to 784 terms against fp64: a few 1e-6 whatever the association order of the tile
+    # configuration (sequential chain, split-K slabs, K over the wavefronts)
+    assert rel_err(y, yr) < 4e-6
+    assert rel_err(x.grad, xr.grad) < 1e-5
+    assert rel_err(w.grad, wr.grad) < 1e-5
+    assert rel_err(b.grad, br.grad) < 1e-5
 
 
 @pytest.mark.parametrize("name,L,C,nd,rica", [("ae2d_rica", 224, 4, 2, True), ("ae2d_norica", 224, 4, 2, False),
