@@ -47,7 +47,7 @@ int lshm_version(void);
 const char* lshm_last_error_string(void);
 /* GEMM-shaped kernels pick their tile configuration per problem shape.  mode 1 (default, or env
  * LSHM_TUNE=1): the first eager call of a shape times the candidates on the caller's buffers and
- * caches the winner; mode 0: static heuristic.  force >= 0 pins configuration `force` (0..11) for
+ * caches the winner; mode 0: static heuristic.  force >= 0 pins configuration `force` (0..15) for
  * every launch (parity tests sweep it); -1 unpins.  Clears the cache. */
 void lshm_set_tuning(int mode, int force);
 /* The cache as text ("policy M N K Z groups config" per line).  export returns the buffer size needed

@@ -37,9 +37,9 @@ struct Pair {
   int zper;  // z-blocks per group (zgroups * splits)
 };
 
-// KW = 1 ("K over the wavefronts", BM = 16): the four wavefronts share one 16-row output tile and split
-// the k-steps of every staged chunk between them; their partial tiles meet in LDS at the end and are
-// added in wavefront order.  For the deep layers (a few thousand output rows, K in the hundreds or
+// KW = 4 or 2 ("K over the wavefronts", BM = 64 / KW): KW wavefronts share each 16-row output tile and
+// split the k-steps of every staged chunk between them; their partial tiles meet in LDS at the end and
+// are added in wavefront order.  For the deep layers (a few thousand output rows, K in the hundreds or
 // thousands) this gives many small tiles with short main loops in ONE launch, where split-K over
 // workgroups needs a second launch to combine the slabs.
 template <class P, int BM, int BN, int BK, int KW = 0>
@@ -48,11 +48,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   const int zblk = blockIdx.z - grp * pp.zper;
   const typename P::Params& p = pp.p[grp];
   constexpr int NT = 256;
-  static_assert(!KW || BM == 16, "KW tiles are 16 rows");
+  static_assert(KW == 0 || ((KW == 2 || KW == 4) && BM * KW == 64), "KW wavefronts per 16-row tile");
+  constexpr int WM = KW ? 4 / KW : 4;  // wavefronts along M
   constexpr int TM = KW ? 1 : BM / 64, TN = BN / 16;
   // LDS leading dimensions: [k][m]/[k][n] images need ld == 16 (mod 32), [m][k]/[n][k]
   // images ld == BK+2, so that the 2x32-lane groups of ds_read_b32 hit 32 distinct banks.
-  constexpr int LDA = P::A_M_FAST ? (KW ? 48 : BM + 16) : (BK + 2);
+  constexpr int LDA = P::A_M_FAST ? (KW ? 48 : BM + 16) : (BK + 2);  // 48 == 16 (mod 32) holds 16 or 32 rows
   constexpr int LDB = P::B_N_FAST ? ((BN % 32 == 16) ? BN : BN + 16) : (BK + 2);
   constexpr int A_ELEMS = P::A_M_FAST ? BK * LDA : BM * LDA;
   constexpr int B_ELEMS = P::B_N_FAST ? BK * LDB : BN * LDB;
@@ -88,7 +89,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   typename P::FastB fb;
   if (P::A_M_FAST) fa = P::a_fast(p, m0 + (t % BM), zg);
   if (P::B_N_FAST) fb = P::b_fast(p, n0 + (t % BN), zg);
-  const int wm0 = KW ? 0 : wave * (BM / 4);
+  const int wm0 = KW ? (wave % WM) * 16 : wave * (BM / 4);
+  const int wk = KW ? wave / WM : 0;  // which share of the k-steps
 
   float ra[NA], rb[NB];
   // "fast" operands are affine in the K-chunk index: element i of this thread sits at
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
     __syncthreads();
     if (k0 + BK < kend) fetch(k0 + BK);  // loads stay in flight under the MFMAs below
 #pragma unroll
-    for (int ks = KW ? wave : 0; ks < BK / 4; ks += KW ? 4 : 1) {
+    for (int ks = wk; ks < BK / 4; ks += KW ? KW : 1) {
       float a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -202,16 +204,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   }
   // ---- epilogue: lane holds rows 4*lk..4*lk+3 of column lm in each 16x16 tile
   if constexpr (KW) {
-    // the four partial tiles -> LDS -> wavefront j finishes n-tile j (sum in wavefront order)
+    // the KW partial tiles of each m-tile -> LDS -> share wk of the wavefronts finishes n-tiles j == wk
+    // (mod KW), summing in share order
     f32x4* red = reinterpret_cast<f32x4*>(smem);
 #pragma unroll
     for (int j = 0; j < TN; ++j) red[(wave * TN + j) * 64 + lane] = acc[0][j];
     __syncthreads();
-    for (int j = wave; j < TN; j += 4) {
-      f32x4 v = red[j * 64 + lane];
+    const int wmi = wave % WM;
+    for (int j = wk; j < TN; j += KW) {
+      f32x4 v = red[(wmi * TN + j) * 64 + lane];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) v += red[(w * TN + j) * 64 + lane];
-      const int m = m0 + 4 * lk, n = n0 + 16 * j + lm;
+      for (int w = 1; w < KW; ++w) v += red[((w * WM + wmi) * TN + j) * 64 + lane];
+      const int m = m0 + wm0 + 4 * lk, n = n0 + 16 * j + lm;
       if (splits > 1) {
         const int Mp = (p.M + 3) & ~3;
         if (m < Mp && n < p.N) *reinterpret_cast<f32x4*>(p.sk.partial + ((long)zblk * p.N + n) * Mp + m) = v;
@@ -735,13 +739,16 @@ static int launch_by_n(const typename P::Params& p, const typename P::Params* p1
 }
 
 // A launch configuration is (M tile 64|128) x (K chunk 16|32) x (split-K mode): index bits 0, 1, 2..3;
-// 12, 13: the K-over-wavefronts form (16-row tiles, K chunk 64) without / with split-K.
-constexpr int kNumConfigs = 14;
+// 12, 13: the K-over-wavefronts form with 16-row tiles (four wavefronts per tile, K chunk 64) without /
+// with split-K; 14, 15: the same with 32-row tiles (two wavefronts per 16 rows).
+constexpr int kNumConfigs = 16;
 template <class P>
 static int launch_idx(int c, const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
                       float* ws, size_t wsf, hipStream_t st, GradJobs* defer = nullptr) {
-  if (c == 12) return launch_by_n<P, 16, 64, 1>(p, p1, M, N, Z, ws, wsf, 1, st, defer);
-  if (c == 13) return launch_by_n<P, 16, 64, 1>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
+  if (c == 12) return launch_by_n<P, 16, 64, 4>(p, p1, M, N, Z, ws, wsf, 1, st, defer);
+  if (c == 13) return launch_by_n<P, 16, 64, 4>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
+  if (c == 14) return launch_by_n<P, 32, 64, 2>(p, p1, M, N, Z, ws, wsf, 1, st, defer);
+  if (c == 15) return launch_by_n<P, 32, 64, 2>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
   const int smode = c >> 2;
   switch (c & 3) {
     case 0: return launch_by_n<P, 64, 16>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
@@ -873,8 +880,8 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
   }
   if (getenv("LSHM_TUNE_LOG"))
     fprintf(stderr, "[lshm tune] policy %d M=%d N=%d K=%d Z=%d G=%d -> cfg %d (BM %d BK %d split-mode %d) %.1f us\n",
-            key.pol, M, N, p.K, Z, key.G, best, best >= 12 ? 16 : (best & 1) ? 128 : 64,
-            best >= 12 ? 64 : (best & 2) ? 32 : 16, best == 12 ? 1 : best == 13 ? 0 : best >> 2,
+            key.pol, M, N, p.K, Z, key.G, best, best >= 14 ? 32 : best >= 12 ? 16 : (best & 1) ? 128 : 64,
+            best >= 12 ? 64 : (best & 2) ? 32 : 16, best >= 12 ? 1 - (best & 1) : best >> 2,
             best_ms * 1000.f / reps);
   return launch_idx<P>(best, p, p1, M, N, Z, ws, wsf, st, defer);  // candidates ran their combine in place
 }

@@ -35,9 +35,9 @@ def test_conv_layer_fwd_bwd_vs_golden(kind, i):
     _check_conv_layer(kind, i)
 
 
-@pytest.mark.parametrize("cfg", range(14))
+@pytest.mark.parametrize("cfg", range(16))
 def test_every_gemm_tile_configuration(cfg):
-    """The implicit-GEMM launcher autotunes over 14 (M tile, K chunk, split-K / K-over-wavefronts) configurations; pin each
+    """The implicit-GEMM launcher autotunes over 16 (M tile, K chunk, split-K / K-over-wavefronts) configurations; pin each
     one in turn so that whichever the tuner picks on a given box has been checked against the goldens."""
     from lshm_amd import _lib
     lib = _lib.load()
