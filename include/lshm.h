@@ -17,8 +17,9 @@
  *    queries; scalars returned on the device are double precision;
  *  - `stream` is a hipStream_t (pass the caller's current stream); calls only
  *    enqueue work (no synchronisation) and are HIP-graph capturable;
- *  - no global mutable state; distinct streams may be driven from distinct
- *    threads.
+ *  - no global mutable state except the mutex-guarded tile-configuration cache
+ *    (lshm_set_tuning / lshm_tuning_import); distinct streams may be driven from
+ *    distinct threads.
  */
 #ifndef LSHM_H
 #define LSHM_H
