@@ -271,6 +271,17 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     }
     return LSHM_OK;
   };
+  // The small layers' weight gradients are released in groups: every release costs a barrier packet
+  // on both queues (a few microseconds each), which for 5-10 us kernels is most of their run time.
+  static const int group = [] { const char* v = getenv("LSHM_WGRAD_GROUP"); return v ? atoi(v) : 1; }();
+  std::vector<std::function<int()>> pending;
+  auto release = [&](bool force) -> int {
+    if (pending.empty() || (!force && (int)pending.size() < group)) return LSHM_OK;
+    int r = dz_ready();
+    for (auto& f : pending) if (!r) r = f();
+    pending.clear();
+    return r;
+  };
   const float* dz[2];
   for (int g = 0; g < G; ++g) dz[g] = dz_out[g];
   // ---- decoder, last layer first
@@ -285,16 +296,20 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       // previous activation is an ELU output (except fc3's output feeding tconv0)
       dg[g] = ConvDgradIO{dz[g], prm + A(g).tw[i], dx[g], i == 0 ? nullptr : xin};
     }
-    if ((rc = dz_ready())) return rc;
-    if ((rc = conv_layer_wgrad(a0.dec[i], wg[0], nullptr, 0, 0, wst, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
+    pending.push_back([&, i, w0 = wg[0], w1 = wg[1]]() {
+      return conv_layer_wgrad(a0.dec[i], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
+    });
+    if ((rc = release(i >= 4))) return rc;
     if ((rc = conv_layer_dgrad(a0.dec[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
   LinWgradIO lw[2];
   LinDgradIO ld[2];
   auto wgrad = [&](long ldx, long lddz, int K, int N) {
-    int r = dz_ready();
-    return r ? r : linear_wgrad(lw[0], ldx, lddz, B, K, N, nullptr, 0, wst, G > 1 ? &lw[1] : nullptr, &jobs);
+    pending.push_back([&, ldx, lddz, K, N, w0 = lw[0], w1 = lw[1]]() {
+      return linear_wgrad(w0, ldx, lddz, B, K, N, nullptr, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
+    });
+    return release(false);
   };
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr);
@@ -336,6 +351,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   if ((rc = wgrad(hd, 768 + hd, hd, hd))) return rc;
   // the decoder's and the dense layers' closing sums go now (side stream, behind their producers): the
   // tail after the last weight gradient then only has the encoder's
+  if ((rc = release(true))) return rc;
   if (side && (rc = grad_jobs_finish(jobs, wst))) return rc;
   // ---- encoder
   for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_dcat1;
@@ -349,8 +365,10 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).cw[i], grd + A(g).cb[i]};
       dg[g] = ConvDgradIO{dz[g], prm + A(g).cw[i], dx[g], i == 0 ? nullptr : xin};
     }
-    if ((rc = dz_ready())) return rc;
-    if ((rc = conv_layer_wgrad(a0.enc[i], wg[0], nullptr, 0, 0, wst, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
+    pending.push_back([&, i, w0 = wg[0], w1 = wg[1]]() {
+      return conv_layer_wgrad(a0.enc[i], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
+    });
+    if ((rc = release(i <= 2))) return rc;
     if (i == 0 && !dinput[0]) break;
     if ((rc = conv_layer_dgrad(a0.enc[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];

@@ -46,20 +46,28 @@ template <class P, int BM, int BN, int BK, int KW = 0>
 __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   const int grp = blockIdx.z / pp.zper;
   const int zblk = blockIdx.z - grp * pp.zper;
-  const typename P::Params& p = pp.p[grp];
+  const typename P::Params p = pp.p[grp];  // by value: the fields live in SGPRs instead of being re-read from the kernarg segment inside the K loop
   constexpr int NT = 256;
   static_assert(KW == 0 || ((KW == 2 || KW == 4) && BM * KW == 64), "KW wavefronts per 16-row tile");
+  static_assert(BK % 16 == 0 && (KW == 0 || BK / 16 >= KW), "K chunks are whole 16-wide k-blocks");
   constexpr int WM = KW ? 4 / KW : 4;  // wavefronts along M
   constexpr int TM = KW ? 1 : BM / 64, TN = BN / 16;
-  // LDS leading dimensions: [k][m]/[k][n] images need ld == 16 (mod 32), [m][k]/[n][k]
-  // images ld == BK+2, so that the 2x32-lane groups of ds_read_b32 hit 32 distinct banks.
-  constexpr int LDA = P::A_M_FAST ? (KW ? 48 : BM + 16) : (BK + 2);  // 48 == 16 (mod 32) holds 16 or 32 rows
-  constexpr int LDB = P::B_N_FAST ? ((BN % 32 == 16) ? BN : BN + 16) : (BK + 2);
-  constexpr int A_ELEMS = P::A_M_FAST ? BK * LDA : BM * LDA;
-  constexpr int B_ELEMS = P::B_N_FAST ? BK * LDB : BN * LDB;
-  // elements each thread stages per K chunk
-  constexpr int NA = BM * BK / NT;
-  constexpr int NB = P::B_N_FAST ? (BK + NT / BN - 1) / (NT / BN) : (BN + NT / BK - 1) / (NT / BK);
+  // LDS images, both operands: [k-block of 16][row][24], the 16 k of a row stored as 4 slots of 4 with
+  // k = slot + 4e at slot*4 + e.  Lane (lm, lk) of an MFMA tile then gets its operand for the four
+  // k-steps of a k-block (k = 4e + lk, e = 0..3) with ONE ds_read_b128 at row lm, slot lk: a quarter of
+  // the LDS instructions (and waits) of dword reads at twice their bytes per clock.  Row pitch 24
+  // floats makes the four 16-lane groups of ds_read_b128 conflict-free (slot (6 row + lk) mod 16); the
+  // k-block pitch is 16 (mod 32) so that the dword stores of a k-fast operand spread over all banks.
+  constexpr int LDK = 24;
+  constexpr int NKB = BK / 16;
+  constexpr int A_KBS = BM * LDK + 16, B_KBS = BN * LDK + 16;
+  constexpr int A_ELEMS = NKB * A_KBS, B_ELEMS = NKB * B_KBS;
+  // an m-fast (n-fast) operand is staged in float4 groups (row, k-block, slot): group G = t + 256 j
+  constexpr int A_GROUPS = BM * BK / 4, B_GROUPS = BN * BK / 4;
+  constexpr int NGA = (A_GROUPS + NT - 1) / NT, NGB = (B_GROUPS + NT - 1) / NT;
+  // a k-fast operand in single elements: k = t % BK, rows t / BK + i * (NT / BK)
+  constexpr int NA = P::A_M_FAST ? 4 * NGA : BM * BK / NT;
+  constexpr int NB = P::B_N_FAST ? 4 * NGB : (BN + NT / BK - 1) / (NT / BK);
   constexpr int RED_ELEMS = KW ? 4 * TN * 64 * 4 : 0;  // cross-wave combine buffer (reuses the tile images)
   __shared__ __attribute__((aligned(16))) float smem[(A_ELEMS + B_ELEMS) > RED_ELEMS ? (A_ELEMS + B_ELEMS) : RED_ELEMS];
   float* As = smem;
@@ -84,13 +92,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // per-thread fixed "fast" coordinates of the gathers
-  typename P::FastA fa;
-  typename P::FastB fb;
-  if (P::A_M_FAST) fa = P::a_fast(p, m0 + (t % BM), zg);
-  if (P::B_N_FAST) fb = P::b_fast(p, n0 + (t % BN), zg);
   const int wm0 = KW ? (wave % WM) * 16 : wave * (BM / 4);
-  const int wk = KW ? wave / WM : 0;  // which share of the k-steps
+  const int wk = KW ? wave / WM : 0;  // which share of the k-blocks
 
   float ra[NA], rb[NB];
   // "fast" operands are affine in the K-chunk index: element i of this thread sits at
@@ -100,23 +103,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   const float* abase = nullptr;
   const float* bbase = nullptr;
   long astep = 0, bstep = 0;
+  typename P::FastA fa;
+  typename P::FastB fb;
+  // k (within the chunk) of element e of group g: 16 (g / 4) + (g % 4) + 4 e
   if constexpr (P::A_M_FAST) {
+    static_assert(NT % BM == 0 && A_GROUPS % NT == 0, "every thread stages whole groups of one row");
+    fa = P::a_fast(p, m0 + t % BM, zg);
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      bool ok;
-      P::a_affine(p, fa, m0 + t % BM, t / BM + i * (NT / BM), zg, aoff[i], ok);
-      avalid |= (unsigned)ok << i;
+    for (int j = 0; j < NGA; ++j) {
+      const int g = t / BM + j * (NT / BM);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bool ok;
+        P::a_affine(p, fa, m0 + t % BM, 16 * (g >> 2) + (g & 3) + 4 * e, zg, aoff[4 * j + e], ok);
+        avalid |= (unsigned)ok << (4 * j + e);
+      }
     }
     astep = P::a_step(p, BK);
     abase = P::a_base(p, fa) + (long)(kbeg / BK) * astep;
   }
   if constexpr (P::B_N_FAST) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      bool ok;
-      const int kl = t / BN + i * (NT / BN);
-      P::b_affine(p, fb, n0 + t % BN, kl, zg, boff[i], ok);
-      bvalid |= (unsigned)(ok && kl < BK) << i;
+    for (int j = 0; j < NGB; ++j) {
+      const int G = t + j * NT;
+      const int n = G % BN, g = G / BN;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        bool ok;
+        P::b_affine(p, P::b_fast(p, n0 + n, zg), n0 + n, 16 * (g >> 2) + (g & 3) + 4 * e, zg, boff[4 * j + e], ok);
+        bvalid |= (unsigned)(ok && G < B_GROUPS) << (4 * j + e);
+      }
     }
     bstep = P::b_step(p, BK);
     bbase = P::b_base(p) + (long)(kbeg / BK) * bstep;
@@ -126,9 +142,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
     const int krem = kend - k0;  // elements of this chunk that exist
     if constexpr (P::A_M_FAST) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int kl = t / BM + i * (NT / BM);
-        ra[i] = ((avalid >> i) & 1u) && kl < krem ? abase[aoff[i]] : 0.f;
+      for (int j = 0; j < NGA; ++j) {
+        const int g = t / BM + j * (NT / BM);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * j + e, kl = 16 * (g >> 2) + (g & 3) + 4 * e;
+          ra[i] = ((avalid >> i) & 1u) && kl < krem ? abase[aoff[i]] : 0.f;
+        }
       }
       abase += astep;
     } else {
@@ -140,9 +160,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
     }
     if constexpr (P::B_N_FAST) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int kl = t / BN + i * (NT / BN);
-        rb[i] = ((bvalid >> i) & 1u) && kl < krem ? bbase[boff[i]] : 0.f;
+      for (int j = 0; j < NGB; ++j) {
+        const int g = (t + j * NT) / BN;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int i = 4 * j + e, kl = 16 * (g >> 2) + (g & 3) + 4 * e;
+          rb[i] = ((bvalid >> i) & 1u) && kl < krem ? bbase[boff[i]] : 0.f;
+        }
       }
       bbase += bstep;
     } else {
@@ -155,25 +179,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
       }
     }
   };
+  // position of this thread's k (k-fast operands) inside the image of one row
+  const int kf = t % BK;
+  const int kf_pos = (kf & 3) * 4 + ((kf & 15) >> 2);
   auto stage = [&]() {
-    if (P::A_M_FAST) {
+    if constexpr (P::A_M_FAST) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) As[(t / BM + i * (NT / BM)) * LDA + t % BM] = ra[i];
+      for (int j = 0; j < NGA; ++j) {
+        const int g = t / BM + j * (NT / BM);
+        *reinterpret_cast<f32x4*>(As + (g >> 2) * A_KBS + (t % BM) * LDK + 4 * (g & 3)) =
+            (f32x4){ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]};
+      }
     } else {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) As[(t / BK + i * (NT / BK)) * LDA + t % BK] = ra[i];
+      for (int i = 0; i < NA; ++i) As[(kf >> 4) * A_KBS + (t / BK + i * (NT / BK)) * LDK + kf_pos] = ra[i];
     }
-    if (P::B_N_FAST) {
+    if constexpr (P::B_N_FAST) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int kl = t / BN + i * (NT / BN);
-        if (kl < BK) Bs[kl * LDB + t % BN] = rb[i];
+      for (int j = 0; j < NGB; ++j) {
+        const int G = t + j * NT;
+        const int n = G % BN, g = G / BN;
+        if (G < B_GROUPS)
+          *reinterpret_cast<f32x4*>(Bs + (g >> 2) * B_KBS + n * LDK + 4 * (g & 3)) =
+              (f32x4){rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]};
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int nl = t / BK + i * (NT / BK);
-        if (nl < BN) Bs[nl * LDB + t % BK] = rb[i];
+        if (nl < BN) Bs[(kf >> 4) * B_KBS + nl * LDK + kf_pos] = rb[i];
       }
     }
   };
@@ -184,21 +218,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
     __syncthreads();
     if (k0 + BK < kend) fetch(k0 + BK);  // loads stay in flight under the MFMAs below
 #pragma unroll
-    for (int ks = wk; ks < BK / 4; ks += KW ? KW : 1) {
-      float a[TM], b[TN];
+    for (int kb = wk; kb < NKB; kb += KW ? KW : 1) {
+      f32x4 a[TM], b[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        a[i] = P::A_M_FAST ? As[(4 * ks + lk) * LDA + wm0 + 16 * i + lm]
-                           : As[(wm0 + 16 * i + lm) * LDA + 4 * ks + lk];
+        a[i] = *reinterpret_cast<const f32x4*>(As + kb * A_KBS + (wm0 + 16 * i + lm) * LDK + 4 * lk);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        b[j] = P::B_N_FAST ? Bs[(4 * ks + lk) * LDB + 16 * j + lm]
-                           : Bs[(16 * j + lm) * LDB + 4 * ks + lk];
+        b[j] = *reinterpret_cast<const f32x4*>(Bs + kb * B_KBS + (16 * j + lm) * LDK + 4 * lk);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
@@ -277,6 +311,24 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const Pair<P> pp, 
   }
 }
 
+// Division of an index by a kernel-uniform extent (rows per image, outputs per row ...).  Every layer of
+// the 128 x 128 configuration has power-of-two extents, where this is a shift and a mask on a scalar
+// condition; the generic sequence (~30 vector instructions) stays for everything else.  The gathers of
+// the weight gradients decode their position once per K chunk, the epilogues once per output row.
+struct UDiv { int d, sh; };
+__device__ __forceinline__ UDiv udiv(int d) { return UDiv{d, (d & (d - 1)) == 0 ? 31 - __clz(d) : -1}; }
+__device__ __forceinline__ int divmod(const UDiv u, int x, int& r) {
+  int q;
+  if (u.sh >= 0) {
+    q = x >> u.sh;
+    r = x & (u.d - 1);
+  } else {
+    q = x / u.d;
+    r = x - q * u.d;
+  }
+  return q;
+}
+
 __device__ __forceinline__ float epi(float v, float bias, int act) {
   v += bias;
   return act ? elu(v) : v;
@@ -295,9 +347,9 @@ struct Conv2dFwd {
   __device__ static FastA a_fast(const Params& p, int m, int) {
     FastA f;
     if (m >= p.M) { f.base = nullptr; f.iy0 = f.ix0 = 0; return f; }
-    const int hw = p.Ho * p.Wo;
-    const int b = m / hw, r = m - b * hw;
-    const int oy = r / p.Wo, ox = r - oy * p.Wo;
+    int r, ox;
+    const int b = divmod(udiv(p.Ho * p.Wo), m, r);
+    const int oy = divmod(udiv(p.Wo), r, ox);
     f.base = p.x + (long)b * p.x_bs;
     f.iy0 = 2 * oy - 1;
     f.ix0 = 2 * ox - 1;
@@ -324,7 +376,8 @@ struct Conv2dFwd {
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (m >= p.M || n >= p.N) return;
     const int hw = p.Ho * p.Wo;
-    const int b = m / hw, r = m - b * hw;
+    int r;
+    const int b = divmod(udiv(hw), m, r);
     const long idx = (long)b * p.y_bs + (long)n * hw + r;
     const float bias = p.bias ? p.bias[n] : 0.f;
     f32x4 o;
@@ -353,10 +406,9 @@ struct Conv2dDgrad {
   __device__ static FastA a_fast(const Params& p, int m, int) {
     FastA f;
     if (m >= p.M) { f.base = nullptr; f.mm = f.nn = 0; return f; }
-    const int hw = p.Hs * p.Ws;
-    const int b = m / hw, r = m - b * hw;
-    f.mm = r / p.Ws;
-    f.nn = r - f.mm * p.Ws;
+    int r;
+    const int b = divmod(udiv(p.Hs * p.Ws), m, r);
+    f.mm = divmod(udiv(p.Ws), r, f.nn);
     f.base = p.s + (long)b * p.s_bs;
     return f;
   }
@@ -397,8 +449,9 @@ struct Conv2dDgrad {
     for (int i = 0; i < 4; ++i) {
       const int mr = m + i;
       if (mr >= p.M) break;
-      const int b = mr / hw, r = mr - b * hw;
-      const int mm = r / p.Ws, nn = r - mm * p.Ws;
+      int r, nn;
+      const int b = divmod(udiv(hw), mr, r);
+      const int mm = divmod(udiv(p.Ws), r, nn);
       const long idx = (long)b * p.big_bs + ((long)n * Hb + 2 * mm + (z >> 1)) * Wb + 2 * nn + (z & 1);
       float o = epi(v[i], bias, p.act);
       if (p.dact) o *= elu_grad_from_out(p.dact[idx]);
@@ -418,17 +471,17 @@ struct Conv2dWgrad {
   struct FastA { const float* base; };
   struct FastB { const float* base; int iy0, ix0; };
   __device__ static FastA a_fast(const Params& p, int k, int) {
-    const int hw = p.Hs * p.Ws;
-    const int b = k / hw, r = k - b * hw;
+    int r;
+    const int b = divmod(udiv(p.Hs * p.Ws), k, r);
     return FastA{p.s + (long)b * p.s_bs + r};
   }
   __device__ static float a_load(const Params& p, const FastA& f, int m, int, int) {
     return m < p.M ? f.base[m * p.Hs * p.Ws] : 0.f;
   }
   __device__ static FastB b_fast(const Params& p, int k, int) {
-    const int hw = p.Hs * p.Ws;
-    const int b = k / hw, r = k - b * hw;
-    const int oy = r / p.Ws, ox = r - oy * p.Ws;
+    int r, ox;
+    const int b = divmod(udiv(p.Hs * p.Ws), k, r);
+    const int oy = divmod(udiv(p.Ws), r, ox);
     return FastB{p.big + (long)b * p.big_bs, 2 * oy - 1, 2 * ox - 1};
   }
   __device__ static float b_load(const Params& p, const FastB& f, int, int n, int) {
@@ -462,7 +515,8 @@ struct Conv1dFwd {
   struct FastB { int k; };
   __device__ static FastA a_fast(const Params& p, int m, int) {
     if (m >= p.M) return FastA{nullptr, 0};
-    const int b = m / p.Lo, j = m - b * p.Lo;
+    int j;
+    const int b = divmod(udiv(p.Lo), m, j);
     return FastA{p.x + (long)b * p.x_bs, 4 * j - p.pad};
   }
   __device__ static void a_affine(const Params& p, const FastA& f, int, int kl, int, int& off, bool& ok) {
@@ -484,7 +538,8 @@ struct Conv1dFwd {
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (m >= p.M || n >= p.N) return;
-    const int b = m / p.Lo, j = m - b * p.Lo;
+    int j;
+    const int b = divmod(udiv(p.Lo), m, j);
     const long idx = (long)b * p.y_bs + (long)n * p.Lo + j;
     const float bias = p.bias ? p.bias[n] : 0.f;
     f32x4 o;
@@ -512,7 +567,8 @@ struct Conv1dDgrad {
   struct FastB { int n; };
   __device__ static FastA a_fast(const Params& p, int m, int) {
     if (m >= p.M) return FastA{nullptr};
-    const int b = m / p.Ls, i = m - b * p.Ls;
+    int i;
+    const int b = divmod(udiv(p.Ls), m, i);
     return FastA{p.s + (long)b * p.s_bs + i};
   }
   __device__ static void a_affine(const Params& p, const FastA& f, int, int kl, int, int& off, bool& ok) {
@@ -542,7 +598,8 @@ struct Conv1dDgrad {
     for (int r = 0; r < 4; ++r) {
       const int mr = m + r;
       if (mr >= p.M) break;
-      const int b = mr / p.Ls, i = mr - b * p.Ls;
+      int i;
+      const int b = divmod(udiv(p.Ls), mr, i);
       const long row = (long)b * p.big_bs + (long)cb * p.Lb;
       const int pos = 4 * i + tt - p.pad;
       if ((unsigned)pos < (unsigned)p.Lb) {
@@ -567,14 +624,16 @@ struct Conv1dWgrad {
   struct FastA { const float* base; };
   struct FastB { const float* base; int pos0; };
   __device__ static FastA a_fast(const Params& p, int k, int) {
-    const int b = k / p.Ls, i = k - b * p.Ls;
+    int i;
+    const int b = divmod(udiv(p.Ls), k, i);
     return FastA{p.s + (long)b * p.s_bs + i};
   }
   __device__ static float a_load(const Params& p, const FastA& f, int m, int, int) {
     return m < p.M ? f.base[m * p.Ls] : 0.f;
   }
   __device__ static FastB b_fast(const Params& p, int k, int) {
-    const int b = k / p.Ls, i = k - b * p.Ls;
+    int i;
+    const int b = divmod(udiv(p.Ls), k, i);
     return FastB{p.big + (long)b * p.big_bs, 4 * i - p.pad};
   }
   __device__ static float b_load(const Params& p, const FastB& f, int, int n, int) {
@@ -859,6 +918,7 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
   int best = heuristic;
   float best_ms = 1e30f;
   static const int reps = getenv("LSHM_TUNE_REPS") ? std::max(1, atoi(getenv("LSHM_TUNE_REPS"))) : 3;
+  static const bool verbose = getenv("LSHM_TUNE_LOG") && atoi(getenv("LSHM_TUNE_LOG")) > 1;
   for (int c = 0; c < kNumConfigs; ++c) {
     if (c < 12 && (c & 1) && M <= 64) continue;
     if (c >= 12 && (long)cdiv(M, 16) * Z > 65535) continue;  // 16-row tiles: keep grid.x sane, these are for small M
@@ -871,6 +931,8 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (ms < best_ms) { best_ms = ms; best = c; }
+    if (verbose) fprintf(stderr, "[lshm tune]   pol %d M=%d N=%d K=%d Z=%d G=%d cfg %2d: %.1f us\n", key.pol, M, N, p.K, Z,
+                         key.G, c, ms * 1000.f / reps);
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
