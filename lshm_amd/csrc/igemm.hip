@@ -751,7 +751,7 @@ template <class P, int BM, int BN, int BK, int KW = 0>
 static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1, int M, int N, int Z,
                       float* ws, size_t wsf, int smode, hipStream_t st, GradJobs* defer) {
   const int G = p1 ? 2 : 1;
-  const size_t wsg = ws ? wsf / G : 0;  // split-K scratch per group
+  const size_t wsg = ws ? (wsf / G) & ~(size_t)63 : 0;  // split-K scratch per group (256-byte aligned)
   const long tiles = (long)cdiv(M, BM) * cdiv(N, BN) * Z * G;
   const SplitPlan sp = plan_split(tiles, p0.K, M, N, Z, wsg, BK, kSplitTargets[smode]);
   Pair<P> pp;

@@ -91,7 +91,7 @@ struct GradJobs {
   float* scratch = nullptr;
   size_t cap = 0, used = 0;
   float* take(size_t n) {
-    n = (n + 3) & ~(size_t)3;
+    n = (n + 63) & ~(size_t)63;  // 256-byte boundaries: slabs are written in full cache lines
     if (used + n > cap) return nullptr;
     float* p = scratch + used;
     used += n;

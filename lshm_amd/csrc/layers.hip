@@ -80,10 +80,10 @@ size_t conv_workspace_floats(const ConvLayer& L) {
 
 // scratch a deferred weight-gradient call of this layer takes from its GradJobs list (G problems per launch)
 size_t conv_wgrad_defer_floats(const ConvLayer& L, int G) {
-  return (conv_workspace_floats(L) + 4) * G + (size_t)G * (256 * (size_t)L.Cout + 4);
+  return (conv_workspace_floats(L) + 64) * G + (size_t)G * (256 * (size_t)L.Cout + 64);  // each take() rounds up to 64 floats
 }
 size_t linear_wgrad_defer_floats(int B, int K, int N, int G) {
-  return (igemm_workspace_floats(N, K, B, 1) + 16 + 4) * G;
+  return (igemm_workspace_floats(N, K, B, 1) + 16 + 64) * G;
 }
 
 // ---- problem descriptors from pointer bundles ---------------------------------------------
