@@ -141,7 +141,8 @@ int lshm_residual_split(const float* x, const float* x1, float* out_row, float* 
 int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_stream_t stream);
 size_t lshm_recon_workspace_floats(int planes, int P);
 /* sums7 = [sum e^2, y1.r1, sum r1^2, y2.r2, sum r2^2, y3.r3, sum r3^2]; gradients scaled by 1/n;
- * x3c / gx3c are in the column-vectorised (per-plane transposed) layout of the third AE. */
+ * x3c / gx3c are in the column-vectorised (per-plane transposed) layout of the third AE.
+ * gx1_partial, gx2, gx3c all NULL: only the sums (a closure evaluated under no_grad, :133-134). */
 int lshm_recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
                               const float* y1, const float* y2, const float* y3, float rho,
                               int planes, int P, double* sums7, float* gx1_partial, float* gx2,

@@ -180,8 +180,8 @@ int lshm_recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, 
                               const float* y1, const float* y2, const float* y3, float rho, int planes,
                               int P, double* sums7, float* gx1p, float* gx2, float* gx3c, float* ws,
                               lshm_stream_t s) {
-  REQUIRE(x && x1 && x2 && x3c && y1 && y2 && y3 && sums7 && gx1p && gx2 && gx3c && ws && planes > 0,
-          "recon_losses: null pointer");
+  REQUIRE(x && x1 && x2 && x3c && y1 && y2 && y3 && sums7 && ws && planes > 0, "recon_losses: null pointer");
+  REQUIRE((gx1p && gx2 && gx3c) || (!gx1p && !gx2 && !gx3c), "recon_losses: gradient images are all set or all NULL");
   return recon_losses_fwd_bwd(x, x1, x2, x3c, y1, y2, y3, rho, planes, P, sums7, gx1p, gx2, gx3c, ws, ST(s));
 }
 int lshm_combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes, int P,

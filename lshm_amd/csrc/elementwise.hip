@@ -257,7 +257,8 @@ int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* d
 // UPD: first advance the multipliers, y_k += rho r_k (src/kharmonic_lofar.py:200-202), write them back, and
 // evaluate everything else with the new values: the multiplier update of one ADMM iteration and the
 // reconstruction terms of the next one read the same seven arrays, so they can share one pass.
-template <bool UPD>
+// GRAD = false: only the seven sums (the gradient-free closures of a line search).
+template <bool UPD, bool GRAD = true>
 __global__ __launch_bounds__(256) void recon_kernel(
     const float* __restrict__ x, const float* __restrict__ x1, const float* __restrict__ x2,
     const float* __restrict__ x3c, float* y1, float* y2, float* y3, float rho, float inv_n, int P,
@@ -290,14 +291,18 @@ __global__ __launch_bounds__(256) void recon_kernel(
     s[1] += m1 * r1; s[2] += r1 * r1;
     s[3] += m2 * r2; s[4] += r2 * r2;
     s[5] += m3 * r3; s[6] += r3 * r3;
-    const float t2 = m2 + rho * r2, t3 = m3 + rho * r3;
-    gx2[o] = (2.f * e - t2) * inv_n;
-    g3[i] = (2.f * e - t3) * inv_n;
-    gx1p[o] = (2.f * e - m1 - rho * r1) * inv_n - 0.5f * (t2 + t3) * inv_n;
+    if (GRAD) {
+      const float t2 = m2 + rho * r2, t3 = m3 + rho * r3;
+      gx2[o] = (2.f * e - t2) * inv_n;
+      g3[i] = (2.f * e - t3) * inv_n;
+      gx1p[o] = (2.f * e - m1 - rho * r1) * inv_n - 0.5f * (t2 + t3) * inv_n;
+    }
   }
-  __syncthreads();
+  if (GRAD) {
+    __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = g3[i];
+    for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = g3[i];
+  }
   // per-wavefront sums in fp32 (256 terms each), combined across the 4 waves and all tiles in fp64
   const int tid = threadIdx.y * TILE + threadIdx.x;
   const int lane = tid & 63, w = tid >> 6;
@@ -307,8 +312,10 @@ __global__ __launch_bounds__(256) void recon_kernel(
     if (lane == 0) red[w][q] = v;
   }
   __syncthreads();
+  if (GRAD) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) gx3c[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
+    for (int i = 0; i < 4; ++i) gx3c[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
+  }
   const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   if (tid < 7)
     partials[blk * 7 + tid] = ((double)red[0][tid] + (double)red[1][tid]) + ((double)red[2][tid] + (double)red[3][tid]);
@@ -332,7 +339,10 @@ static int recon_launch(bool upd, const float* x, const float* x1, const float* 
   const double n = (double)planes * P * P;
   double* part = reinterpret_cast<double*>(block_partials);
   dim3 grid(P / TILE, P / TILE, planes);
-  if (upd)
+  if (!gx1p && !upd)  // no gradient buffers: the sums alone
+    hipLaunchKernelGGL((recon_kernel<false, false>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
+                       (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
+  else if (upd)
     hipLaunchKernelGGL(recon_kernel<true>, grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
                        (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
   else
@@ -463,11 +473,23 @@ int scale_flat(float* x, float alpha, long n, hipStream_t st) {
 // two-stage deterministic dot product; ws >= 2*DOT_BLOCKS floats (holds doubles)
 #define DOT_BLOCKS 256
 __global__ __launch_bounds__(256) void dot_stage1(const float* __restrict__ a, const float* __restrict__ b,
-                                                  long n, double* __restrict__ part) {
+                                                  long n, double* __restrict__ part, int vec) {
   __shared__ double red[16];
   double acc = 0.0;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    acc += (double)a[i] * (double)b[i];
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  if (vec) {  // both pointers 16-byte aligned: float4 loads, the n % 4 tail goes to the first threads
+    const long n4 = n >> 2;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    for (long i = gid; i < n4; i += stride) {
+      const f32x4 x = a4[i], y = b4[i];
+      acc += ((double)x[0] * (double)y[0] + (double)x[1] * (double)y[1]) +
+             ((double)x[2] * (double)y[2] + (double)x[3] * (double)y[3]);
+    }
+    if (gid < (n & 3)) acc += (double)a[4 * n4 + gid] * (double)b[4 * n4 + gid];
+  } else {
+    for (long i = gid; i < n; i += stride) acc += (double)a[i] * (double)b[i];
+  }
   const double tot = block_sum<double>(acc, red);
   if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
@@ -498,7 +520,8 @@ int asum_flat(const float* a, long n, double* out, float* ws, hipStream_t st) {
 }
 int dot_flat(const float* a, const float* b, long n, double* out, float* ws, hipStream_t st) {
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(dot_stage1, dim3(DOT_BLOCKS), dim3(256), 0, st, a, b, n, part);
+  const int vec = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+  hipLaunchKernelGGL(dot_stage1, dim3(DOT_BLOCKS), dim3(256), 0, st, a, b, n, part, vec);
   int rc = check_launch("dot1");
   if (rc) return rc;
   hipLaunchKernelGGL(dot_stage2, dim3(1), dim3(256), 0, st, part, DOT_BLOCKS, out);

@@ -518,9 +518,10 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   int rc;
   // reconstruction terms; the kernel's 1/n uses the local element count, rescale for world > 1 below
   // gradients carry this rank's share of the global mean (1/world folded into the kernel's 1/n)
+  // (a gradient-free closure passes no gradient images: the kernel then only reads)
   if (!recon_done && (rc = recon_losses_fwd_bwd(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3,
-                                 c.rho, planes, c.P, scal, ws + e->o_gx1p, ws + e->o_gx2,
-                                 ws + e->o_gx3c, ws + e->lane[0].o_part, st, (float)(1.0 / world)))) return rc;
+                                 c.rho, planes, c.P, scal, grd ? ws + e->o_gx1p : nullptr, grd ? ws + e->o_gx2 : nullptr,
+                                 grd ? ws + e->o_gx3c : nullptr, ws + e->lane[0].o_part, st, (float)(1.0 / world)))) return rc;
   const double inv_count = 1.0 / (world * (double)B * c.K * D);
   double* rica_part = scal + 16 + (B + c.bpb - 1) / c.bpb;  // [LOGCOSH3_BLOCKS][3]
   if (e->latent_event) {  // the latent-space terms ran beside the decoders

@@ -411,3 +411,56 @@ def test_fft_cascade_matches_oracle_composition():
     assert rel_err(Fhat, Fho) < 2e-5 and rel_err(fmu, fmuo) < 2e-5
     Z = fft_cascade_latents(net, fnet, x.to(DEV), uv.to(DEV))
     assert Z.shape == (2, 224 + 64) and rel_err(Z, torch.cat((muo, fmuo), 1)) < 2e-5
+
+
+def test_recon_losses_and_gradient_free_variant():
+    """Reconstruction terms of the closure (src/kharmonic_lofar.py:150-158) against the formulas in fp64, and
+    the variant without gradient images (a closure under no_grad) giving the same seven sums."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    planes, P, rho = 6, 64, 0.7
+    g = torch.Generator().manual_seed(5)
+    x, x1, x2, x3, y1, y2, y3 = [torch.randn(planes, P, P, generator=g) for _ in range(7)]
+    x3c = x3.transpose(1, 2).contiguous()
+    dev = [t.to(DEV) for t in (x, x1, x2, x3c, y1, y2, y3)]
+    nws = lib.lshm_recon_workspace_floats(planes, P)
+    ws = torch.empty(nws, device=DEV)
+    sums = torch.zeros(8, device=DEV, dtype=torch.float64)
+    grads = [torch.empty(planes, P, P, device=DEV) for _ in range(3)]
+    L.check(lib.lshm_recon_losses_fwd_bwd(*[L.ptr(t) for t in dev], rho, planes, P, L.ptr(sums), *[L.ptr(t) for t in grads],
+                                          L.ptr(ws), L.stream()))
+    X, X1, X2, X3, Y1, Y2, Y3 = [t.double() for t in (x, x1, x2, x3, y1, y2, y3)]
+    r1 = X - X1; h = 0.5 * r1; r2 = h - X2; r3 = h - X3; e = X1 + X2 + X3 - X
+    want = [float((e * e).sum()), float((Y1 * r1).sum()), float((r1 * r1).sum()), float((Y2 * r2).sum()),
+            float((r2 * r2).sum()), float((Y3 * r3).sum()), float((r3 * r3).sum())]
+    got = sums[:7].cpu().numpy()
+    np.testing.assert_allclose(got, want, rtol=2e-6, atol=1e-3)
+    n = planes * P * P
+    t2, t3 = Y2 + rho * r2, Y3 + rho * r3
+    assert_close(grads[1], ((2 * e - t2) / n).float().numpy(), rtol=1e-5, atol=1e-9)
+    assert_close(grads[2].transpose(1, 2), ((2 * e - t3) / n).float().numpy(), rtol=1e-5, atol=1e-9)
+    assert_close(grads[0], (((2 * e - Y1 - rho * r1) - 0.5 * (t2 + t3)) / n).float().numpy(), rtol=1e-5, atol=1e-9)
+    sums2 = torch.zeros(8, device=DEV, dtype=torch.float64)
+    L.check(lib.lshm_recon_losses_fwd_bwd(*[L.ptr(t) for t in dev], rho, planes, P, L.ptr(sums2), None, None, None,
+                                          L.ptr(ws), L.stream()))
+    assert torch.equal(sums[:7], sums2[:7])
+    # mixed NULL / non-NULL gradient images are refused
+    assert lib.lshm_recon_losses_fwd_bwd(*[L.ptr(t) for t in dev], rho, planes, P, L.ptr(sums2), L.ptr(grads[0]), None, None,
+                                         L.ptr(ws), L.stream()) != 0
+
+
+def test_flat_dot_alignment_and_tail():
+    """lshm_dot_flat (src/lbfgsnew.py inner products): float4 path with an n % 4 tail, and the scalar path
+    for a pointer that is not 16-byte aligned."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(9)
+    base_a = torch.randn(100003 + 1, generator=g).to(DEV)
+    base_b = torch.randn(100003 + 1, generator=g).to(DEV)
+    out = torch.zeros(1, device=DEV, dtype=torch.float64)
+    ws = torch.empty(512, device=DEV)
+    for off in (0, 1):
+        a, b = base_a[off:off + 100003], base_b[off:off + 100003]
+        L.check(lib.lshm_dot_flat(L.ptr(a), L.ptr(b), a.numel(), L.ptr(out), L.ptr(ws), L.stream()))
+        want = float((a.double() * b.double()).sum())
+        assert abs(float(out[0]) - want) <= 1e-9 * max(1.0, abs(want))
