@@ -51,6 +51,7 @@ def parse():
                     help="write the implicit-GEMM tile configurations measured in this run (lshm_amd/tuned_gfx950.txt)")
     ap.add_argument("--no-reuse-mode", action="store_true", help="skip the extra reuse_forward timing")
     ap.add_argument("--no-lbfgs", action="store_true", help="skip the extra LBFGS-iteration timing")
+    ap.add_argument("--no-rica", action="store_true", help="skip the dictionary-learning (rica_lofar) timing")
     ap.add_argument("--only-khm", action="store_true", help="time only the K-harmonic kernel (dev aid)")
     return ap.parse_args()
 
@@ -178,6 +179,41 @@ def fft_roofline(tr, dev):
     return {"kernel": "lshm::fft2_feature_kernel", "shape": f"({B},4,128,128)", "bound": "hbm",
             "bytes_per_launch": nbytes, "ms": round(ms, 4), "achieved": round(nbytes / ms / 1e6, 1), "unit": "GB/s",
             "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+
+MFMA_F32_PEAK_TFLOPS = 157.0  # dense fp32 matrix-core peak, MI355X_MICROARCH.md
+
+
+def rica_dictionary_roofline(dev, nbatch=1152, L=4 * 128 * 128, M=256):
+    """SURVEY 8 f4, not the headline: dictionary learning of src/rica_lofar.py at its own sizes (L = 4*128*128,
+    M = 256 :36-40; default_batch = 128 baselines x 9 patches = 1152 columns).  The closure is two fp32 GEMMs
+    of 2 nbatch L M flop (A S and the code gradient), the dictionary update two more -- the one
+    matrix-core-bound workload of the repository, priced against the dense fp32 MFMA peak."""
+    from lshm_amd.rica_lofar import RicaDictionary
+    g = torch.Generator().manual_seed(11)
+    rd = RicaDictionary(L, M, device=dev, A=torch.rand(L, M, generator=g))
+    x = torch.randn(nbatch, L, generator=g).to(dev)  # resident, like the headline's inputs
+    rd.set_minibatch(x)
+    St = torch.rand(nbatch, M, generator=g).to(dev).requires_grad_(True)
+    ms_c = event_time_ms(lambda: rd.loss(St, True), 10, warm=2)
+    with torch.no_grad():
+        ms_l = event_time_ms(lambda: rd.loss(St, False), 10, warm=2)
+    ms_u = event_time_ms(lambda: rd.update_dictionary(St.detach().t()), 5, warm=1)
+    rd.A.copy_(torch.rand(L, M, generator=g))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nit = 3
+    for _ in range(nit):
+        rd.iteration(x)
+    torch.cuda.synchronize()
+    ms_it = (time.perf_counter() - t0) / nit * 1e3
+    gemm = 2.0 * nbatch * L * M
+    return {"workload": f"X ~ A S, L={L}, M={M}, nbatch={nbatch} (src/rica_lofar.py:36-40,59-95)", "bound": "mfma",
+            "closure_ms": round(ms_c, 3), "closure_no_grad_ms": round(ms_l, 3), "dictionary_update_ms": round(ms_u, 3),
+            "achieved": round(2 * gemm / (ms_c * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(2 * gemm / (ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "iteration_ms": round(ms_it, 2), "patches_per_s": round(nbatch / (ms_it * 1e-3), 1),
+            "note": "iteration = fresh codes + LBFGSNew(history 7, max_iter 10, line search, batch mode).step + dictionary update"}
 
 
 def other_kernel_rooflines(tr, dev):
@@ -389,6 +425,8 @@ def main():
         out["khm_distance_roofline"] = khm_distance_roofline(dev)
         out["other_kernels"] = other_kernel_rooflines(tr, dev)
         out["fft_roofline"] = fft_roofline(tr, dev)
+        if not args.no_rica:
+            out["rica_dictionary"] = rica_dictionary_roofline(dev)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

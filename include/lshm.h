@@ -134,6 +134,21 @@ int lshm_aug_loss_fwd_bwd(const float* Z, long ldz, int rows, int D, int bpb, in
 int lshm_logcosh_fwd_bwd(const float* z, long ldz, int rows, int cols, float scale, double* loss,
                          float* dz, long lddz, int accumulate, lshm_stream_t stream);
 
+/* ---- dictionary learning X ~ A S                               src/rica_lofar.py:53-97
+ * Everything transposed (patch-major, as the loader delivers it): Xt = x.view(-1, L) (B,L), A (L,M),
+ * St = S^T (B,M); all contiguous.  workspace >= lshm_rica_workspace_floats(B, L, M) floats.
+ * loss_grad replaces the closure (:72-81): loss[0] = ||X - A S||^2/(B L) + lambda1 ||S||_1/(M B), where
+ * ||S||_1 is torch.linalg.norm(S, 1) of a matrix, the largest column sum of |S|; dSt = d loss / d St
+ * (NULL: loss only, the closure under no_grad).  update_dictionary replaces :84-93: E = X - A S,
+ * A += eta E S^T / B; dA_norm_sq[0] = ||E S^T||_F^2 (the logged ||dA|| is its root over B), may be NULL. */
+size_t lshm_rica_workspace_floats(int B, int L, int M);
+int lshm_rica_loss_grad(const float* Xt, const float* A, const float* St, int B, int L, int M,
+                        float lambda1, double* loss, float* dSt, float* workspace,
+                        size_t workspace_floats, lshm_stream_t stream);
+int lshm_rica_update_dictionary(const float* Xt, float* A, const float* St, int B, int L, int M,
+                                float eta, double* dA_norm_sq, float* workspace,
+                                size_t workspace_floats, lshm_stream_t stream);
+
 /* ---- glue of the closure                                        src/kharmonic_lofar.py:137-158 */
 /* out_row = (x-x1)/2, out_col = per-plane transpose of it (planes = B*C planes of P x P) */
 int lshm_residual_split(const float* x, const float* x1, float* out_row, float* out_col, int planes,

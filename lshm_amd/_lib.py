@@ -76,6 +76,9 @@ _SIGNATURES = {
                                      c_int, c_void_p]),
     "lshm_residual_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lshm_plane_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lshm_rica_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "lshm_rica_loss_grad": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lshm_rica_update_dictionary": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lshm_recon_workspace_floats": (c_size_t, [c_int, c_int]),
     "lshm_recon_losses_fwd_bwd": (c_int, [c_void_p] * 7 + [c_float, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "lshm_combine_dx1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),

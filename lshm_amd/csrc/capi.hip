@@ -175,6 +175,19 @@ int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_st
   REQUIRE(in && out && planes > 0, "plane_transpose: bad argument");
   return plane_transpose(in, out, planes, P, ST(s));
 }
+size_t lshm_rica_workspace_floats(int B, int L, int M) {
+  return (B > 0 && L > 0 && M > 0) ? rica_workspace_floats(B, L, M) : 0;
+}
+int lshm_rica_loss_grad(const float* Xt, const float* A, const float* St, int B, int L, int M, float lambda1,
+                        double* loss, float* dSt, float* ws, size_t wsf, lshm_stream_t s) {
+  REQUIRE(Xt && A && St && loss && ws && B > 0 && L > 0 && M > 0, "rica_loss_grad: bad argument");
+  return rica_loss_grad(Xt, A, St, B, L, M, lambda1, loss, dSt, ws, wsf, ST(s));
+}
+int lshm_rica_update_dictionary(const float* Xt, float* A, const float* St, int B, int L, int M, float eta,
+                                double* dA_norm_sq, float* ws, size_t wsf, lshm_stream_t s) {
+  REQUIRE(Xt && A && St && ws && B > 0 && L > 0 && M > 0, "rica_update_dictionary: bad argument");
+  return rica_update_dictionary(Xt, A, St, B, L, M, eta, dA_norm_sq, ws, wsf, ST(s));
+}
 size_t lshm_recon_workspace_floats(int planes, int P) { return recon_partials_floats(planes, P); }
 int lshm_recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
                               const float* y1, const float* y2, const float* y3, float rho, int planes,

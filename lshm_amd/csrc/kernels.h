@@ -200,6 +200,13 @@ int copy2d(const float* src, long lds, float* dst, long ldd, int rows, int cols,
 int linear_wgrad(const LinWgradIO& io, long ldx, long lddz, int B, int K, int N, float* ws, size_t wsf,
                  hipStream_t st, const LinWgradIO* io2 = nullptr, GradJobs* defer = nullptr);
 
+// ---- dictionary learning (rica.hip; src/rica_lofar.py) ------------------------------------------
+size_t rica_workspace_floats(int B, int L, int M);
+int rica_loss_grad(const float* Xt, const float* A, const float* St, int B, int L, int M, float lambda1,
+                   double* loss, float* dSt, float* ws, size_t wsf, hipStream_t st);
+int rica_update_dictionary(const float* Xt, float* A, const float* St, int B, int L, int M, float eta,
+                           double* dA_norm_sq, float* ws, size_t wsf, hipStream_t st);
+
 // ---- elementwise / reductions (elementwise.hip) -----------------------------
 int uv_harmonics(const float* uv, const float* scales, int H, int B, float* out, hipStream_t st);
 // uvh plus the dense layers fed by uvh alone (weights (4H, 4H) row-major, ELU), see uv_features_kernel

@@ -454,3 +454,43 @@ def admm_iteration(params, M, x, uv, y, cfg: StepConfig, adam: AdamState,
     adam.step(grads)
     y_new = multiplier_update(params, x, uv, y, cfg)
     return [float(t.detach()) for t in terms], y_new, grads
+
+
+# --------------------------------------------------------------------------
+# dictionary learning X ~ A S  (src/rica_lofar.py:53-97), SURVEY 8 f4
+# --------------------------------------------------------------------------
+def rica_closed_form(L: int, M: int, B: int, dtype=torch.float32):
+    """Deterministic stand-ins for the script's random draws: the minibatch X (L x B) (:69), the dictionary
+    A = torch.rand((L, M)) (:51) and the codes S = torch.rand((M, B)) (:71); A and S in [0, 1) like rand."""
+    X = closed_form((L, B), "rica.X", 1.0).to(dtype)
+    A = (0.5 + 0.5 * closed_form((L, M), "rica.A", 1.0)).to(dtype)
+    S = (0.5 + 0.5 * closed_form((M, B), "rica.S", 1.0)).to(dtype)
+    return X, A, S
+
+
+def rica_loss(X: Tensor, A: Tensor, S: Tensor, lambda1: float) -> Tensor:
+    """The closure's loss (:76): MSELoss(reduction='sum')(X, A S) / (nbatch L) + lambda1 ||S||_1 / S.numel(),
+    with torch.linalg.norm(S, 1) of a 2-D tensor = the matrix 1-norm (largest column sum of |S|)."""
+    L, B = X.shape
+    sse = ((X - A @ S) ** 2).sum()
+    norm1 = S.abs().sum(dim=0).max()
+    return sse / (B * L) + lambda1 * norm1 / S.numel()
+
+
+def rica_loss_grad(X: Tensor, A: Tensor, S: Tensor, lambda1: float) -> Tuple[Tensor, Tensor]:
+    """Closed-form gradient of rica_loss w.r.t. S: -2 A^T (X - A S) / (B L) plus lambda1 / numel * sign(S) on
+    the arg-max column of the 1-norm (first one on ties)."""
+    L, B = X.shape
+    E = X - A @ S
+    g = -2.0 * (A.t() @ E) / (B * L)
+    col = int(torch.argmax(S.abs().sum(dim=0)))
+    g[:, col] += lambda1 / S.numel() * torch.sign(S[:, col])
+    return rica_loss(X, A, S, lambda1), g
+
+
+def rica_dictionary_update(X: Tensor, A: Tensor, S: Tensor, eta: float) -> Tuple[Tensor, float]:
+    """:84-93: E = X - A S; dA = sum_b outer(E[:, b], S[:, b]) / nbatch = E S^T / nbatch; A += eta dA.
+    Returns (new A, ||dA||_F) -- the value the script prints."""
+    B = X.shape[1]
+    dA = (X - A @ S) @ S.t() / B
+    return A + eta * dA, float(torch.linalg.norm(dA))
