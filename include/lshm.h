@@ -18,8 +18,9 @@
  *  - `stream` is a hipStream_t (pass the caller's current stream); calls only
  *    enqueue work (no synchronisation) and are HIP-graph capturable;
  *  - no global mutable state except the mutex-guarded tile-configuration cache
- *    (lshm_set_tuning / lshm_tuning_import); distinct streams may be driven from
- *    distinct threads.
+ *    (lshm_set_tuning / lshm_tuning_import) and the process-wide matrix-operand
+ *    precision switch (lshm_set_matrix_precision); distinct streams may be driven
+ *    from distinct threads.
  */
 #ifndef LSHM_H
 #define LSHM_H
@@ -51,6 +52,13 @@ const char* lshm_last_error_string(void);
  * caches the winner; mode 0: static heuristic.  force >= 0 pins configuration `force` (0..15) for
  * every launch (parity tests sweep it); -1 unpins.  Clears the cache. */
 void lshm_set_tuning(int mode, int force);
+/* Operand precision of the GEMM-shaped kernels (conv2-5 / tconv0-3 of the three autoencoders, their
+ * weight gradients, the dense layers, the dictionary-learning GEMMs).  0 (default): fp32 operands on
+ * v_mfma_f32_16x16x4_f32, bitwise an fmaf chain.  1: operands rounded to bf16 (nearest even) as they are
+ * staged in LDS, v_mfma_f32_16x16x16_bf16, fp32 accumulation -- BASELINE.json configs[2]; everything in
+ * HBM, the bandwidth-bound outer layers, losses and optimiser stay fp32. */
+void lshm_set_matrix_precision(int bf16);
+int lshm_get_matrix_precision(void);
 /* The cache as text ("policy M N K Z groups config" per line).  export returns the buffer size needed
  * (terminating 0 included) and fills buf up to cap; import merges entries and returns how many it read.
  * Importing the table measured on the target GPU makes runs start without timing launches and

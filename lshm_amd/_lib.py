@@ -39,6 +39,8 @@ _SIGNATURES = {
     "lshm_version": (c_int, []),
     "lshm_last_error_string": (C.c_char_p, []),
     "lshm_set_tuning": (None, [c_int, c_int]),
+    "lshm_set_matrix_precision": (None, [c_int]),
+    "lshm_get_matrix_precision": (c_int, []),
     "lshm_tuning_export": (c_size_t, [c_void_p, c_size_t]),
     "lshm_tuning_import": (c_int, [C.c_char_p]),
     "lshm_uv_harmonics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -53,6 +53,8 @@ extern "C" {
 int lshm_version(void) { return 100; }
 const char* lshm_last_error_string(void) { return g_err; }
 void lshm_set_tuning(int mode, int force) { igemm_set_tuning(mode, force); }
+void lshm_set_matrix_precision(int bf16) { igemm_set_matrix_precision(bf16); }
+int lshm_get_matrix_precision(void) { return igemm_matrix_precision(); }
 size_t lshm_tuning_export(char* buf, size_t cap) { return igemm_tuning_export(buf, cap); }
 int lshm_tuning_import(const char* text) { return igemm_tuning_import(text); }
 

@@ -14,6 +14,7 @@
 // 64-wide wavefronts: a 256-thread workgroup is 4 waves stacked along M; each
 // wave owns (BM/64) x (BN/16) accumulator tiles.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -42,7 +43,15 @@ struct Pair {
 // are added in wavefront order.  For the deep layers (a few thousand output rows, K in the hundreds or
 // thousands) this gives many small tiles with short main loops in ONE launch, where split-K over
 // workgroups needs a second launch to combine the slabs.
-template <class P, int BM, int BN, int BK, int KW = 0>
+// BF: the operands are rounded to bf16 (nearest even) on their way into LDS and multiplied with
+// v_mfma_f32_16x16x16_bf16 (one instruction per k-block instead of four, 8-byte operand reads); the
+// accumulators, the epilogues and everything in HBM stay fp32.  Opt-in (lshm_set_matrix_precision).
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned bf16_bits(float v) {  // round to nearest even; NaN stays NaN
+  const unsigned u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+template <class P, int BM, int BN, int BK, int KW = 0, bool BF = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   const int grp = blockIdx.z / pp.zper;
   const int zblk = blockIdx.z - grp * pp.zper;
@@ -72,6 +81,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   __shared__ __attribute__((aligned(16))) float smem[(A_ELEMS + B_ELEMS) > RED_ELEMS ? (A_ELEMS + B_ELEMS) : RED_ELEMS];
   float* As = smem;
   float* Bs = smem + A_ELEMS;
+  // bf16 images: same [k-block][row][24] element layout with the 16 k of a row in natural order
+  // (lane (lm, lk) reads k = 4 lk .. 4 lk + 3 as one 8-byte word; 48-byte rows are conflict-free for ds_read_b64)
+  unsigned short* Ah = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Bh = Ah + A_ELEMS;
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -105,7 +118,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   long astep = 0, bstep = 0;
   typename P::FastA fa;
   typename P::FastB fb;
-  // k (within the chunk) of element e of group g: 16 (g / 4) + (g % 4) + 4 e
+  // k (within the chunk) of element e of group g: 16 (g / 4) + (g % 4) + 4 e   (bf16: ... + 4 (g % 4) + e)
+  auto kmap = [](int g, int e) { return BF ? 16 * (g >> 2) + 4 * (g & 3) + e : 16 * (g >> 2) + (g & 3) + 4 * e; };
   if constexpr (P::A_M_FAST) {
     static_assert(NT % BM == 0 && A_GROUPS % NT == 0, "every thread stages whole groups of one row");
     fa = P::a_fast(p, m0 + t % BM, zg);
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bool ok;
-        P::a_affine(p, fa, m0 + t % BM, 16 * (g >> 2) + (g & 3) + 4 * e, zg, aoff[4 * j + e], ok);
+        P::a_affine(p, fa, m0 + t % BM, kmap(g, e), zg, aoff[4 * j + e], ok);
         avalid |= (unsigned)ok << (4 * j + e);
       }
     }
@@ -130,7 +144,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bool ok;
-        P::b_affine(p, P::b_fast(p, n0 + n, zg), n0 + n, 16 * (g >> 2) + (g & 3) + 4 * e, zg, boff[4 * j + e], ok);
+        P::b_affine(p, P::b_fast(p, n0 + n, zg), n0 + n, kmap(g, e), zg, boff[4 * j + e], ok);
         bvalid |= (unsigned)(ok && G < B_GROUPS) << (4 * j + e);
       }
     }
@@ -146,7 +160,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
         const int g = t / BM + j * (NT / BM);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int i = 4 * j + e, kl = 16 * (g >> 2) + (g & 3) + 4 * e;
+          const int i = 4 * j + e, kl = kmap(g, e);
           ra[i] = ((avalid >> i) & 1u) && kl < krem ? abase[aoff[i]] : 0.f;
         }
       }
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
         const int g = (t + j * NT) / BN;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int i = 4 * j + e, kl = 16 * (g >> 2) + (g & 3) + 4 * e;
+          const int i = 4 * j + e, kl = kmap(g, e);
           rb[i] = ((bvalid >> i) & 1u) && kl < krem ? bbase[boff[i]] : 0.f;
         }
       }
@@ -181,33 +195,49 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   };
   // position of this thread's k (k-fast operands) inside the image of one row
   const int kf = t % BK;
-  const int kf_pos = (kf & 3) * 4 + ((kf & 15) >> 2);
+  const int kf_pos = BF ? (kf & 15) : (kf & 3) * 4 + ((kf & 15) >> 2);
+  auto pack = [](float lo, float hi) { return bf16_bits(lo) | (bf16_bits(hi) << 16); };
   auto stage = [&]() {
     if constexpr (P::A_M_FAST) {
 #pragma unroll
       for (int j = 0; j < NGA; ++j) {
         const int g = t / BM + j * (NT / BM);
-        *reinterpret_cast<f32x4*>(As + (g >> 2) * A_KBS + (t % BM) * LDK + 4 * (g & 3)) =
-            (f32x4){ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]};
+        const int o = (g >> 2) * A_KBS + (t % BM) * LDK + 4 * (g & 3);
+        if constexpr (BF)
+          *reinterpret_cast<uint2*>(Ah + o) = make_uint2(pack(ra[4 * j], ra[4 * j + 1]), pack(ra[4 * j + 2], ra[4 * j + 3]));
+        else
+          *reinterpret_cast<f32x4*>(As + o) = (f32x4){ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]};
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) As[(kf >> 4) * A_KBS + (t / BK + i * (NT / BK)) * LDK + kf_pos] = ra[i];
+      for (int i = 0; i < NA; ++i) {
+        const int o = (kf >> 4) * A_KBS + (t / BK + i * (NT / BK)) * LDK + kf_pos;
+        if constexpr (BF) Ah[o] = (unsigned short)bf16_bits(ra[i]);
+        else As[o] = ra[i];
+      }
     }
     if constexpr (P::B_N_FAST) {
 #pragma unroll
       for (int j = 0; j < NGB; ++j) {
         const int G = t + j * NT;
         const int n = G % BN, g = G / BN;
-        if (G < B_GROUPS)
-          *reinterpret_cast<f32x4*>(Bs + (g >> 2) * B_KBS + n * LDK + 4 * (g & 3)) =
-              (f32x4){rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]};
+        const int o = (g >> 2) * B_KBS + n * LDK + 4 * (g & 3);
+        if (G < B_GROUPS) {
+          if constexpr (BF)
+            *reinterpret_cast<uint2*>(Bh + o) = make_uint2(pack(rb[4 * j], rb[4 * j + 1]), pack(rb[4 * j + 2], rb[4 * j + 3]));
+          else
+            *reinterpret_cast<f32x4*>(Bs + o) = (f32x4){rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]};
+        }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int nl = t / BK + i * (NT / BK);
-        if (nl < BN) Bs[(kf >> 4) * B_KBS + nl * LDK + kf_pos] = rb[i];
+        const int o = (kf >> 4) * B_KBS + nl * LDK + kf_pos;
+        if (nl < BN) {
+          if constexpr (BF) Bh[o] = (unsigned short)bf16_bits(rb[i]);
+          else Bs[o] = rb[i];
+        }
       }
     }
   };
@@ -219,20 +249,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
     if (k0 + BK < kend) fetch(k0 + BK);  // loads stay in flight under the MFMAs below
 #pragma unroll
     for (int kb = wk; kb < NKB; kb += KW ? KW : 1) {
-      f32x4 a[TM], b[TN];
+      if constexpr (BF) {
+        bf16x4 a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(As + kb * A_KBS + (wm0 + 16 * i + lm) * LDK + 4 * lk);
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const bf16x4*>(Ah + kb * A_KBS + (wm0 + 16 * i + lm) * LDK + 4 * lk);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const f32x4*>(Bs + kb * B_KBS + (16 * j + lm) * LDK + 4 * lk);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const bf16x4*>(Bh + kb * B_KBS + (16 * j + lm) * LDK + 4 * lk);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a[i], b[j], acc[i][j], 0, 0, 0);
+      } else {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const f32x4*>(As + kb * A_KBS + (wm0 + 16 * i + lm) * LDK + 4 * lk);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          b[j] = *reinterpret_cast<const f32x4*>(Bs + kb * B_KBS + (16 * j + lm) * LDK + 4 * lk);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+      }
     }
     __syncthreads();
   }
@@ -746,6 +791,9 @@ static SplitPlan plan_split(long tiles, int K, int M, int N, int zgroups, size_t
 }
 
 static const long kSplitTargets[3] = {768, 0, 1536};
+static std::atomic<int> g_matrix_bf16{0};
+void igemm_set_matrix_precision(int bf16) { g_matrix_bf16.store(bf16 ? 1 : 0); }
+int igemm_matrix_precision() { return g_matrix_bf16.load(); }
 
 template <class P, int BM, int BN, int BK, int KW = 0>
 static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1, int M, int N, int Z,
@@ -764,7 +812,10 @@ static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1
   }
   pp.zper = Z * sp.splits;
   dim3 grid(cdiv(M, BM), cdiv(N, BN), Z * sp.splits * G);
-  hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, KW>), grid, dim3(256), 0, st, pp);
+  if (g_matrix_bf16.load())
+    hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, KW, true>), grid, dim3(256), 0, st, pp);
+  else
+    hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, KW, false>), grid, dim3(256), 0, st, pp);
   int rc = check_launch("igemm");
   if (rc || sp.splits == 1) return rc;
   if (defer && Z == 1) {  // leave the slabs where they are; the combine joins the backward's job list

@@ -57,16 +57,24 @@ class TrainConfig:
     # bit-for-bit the same trajectory, one forward per iteration instead of two.  Only valid while
     # parameters and inputs change through this trainer's own methods (see invalidate_forward).
     reuse_forward: bool = False
+    # "bf16": the GEMM-shaped kernels (conv2-5 / tconv0-3, their weight gradients, the dense layers) round
+    # their operands to bf16 and multiply on the bf16 matrix cores, fp32 accumulation; storage, the outer
+    # layers, losses and Adam stay fp32 (BASELINE.json configs[2]).  Process-wide switch of the library
+    # (lshm_set_matrix_precision): the last trainer constructed decides.
+    matrix_precision: str = "fp32"
 
 
 class KHarmonicTrainer:
     def __init__(self, cfg: TrainConfig, batch: int, batch_per_bline: int, default_batch: Optional[int] = None,
                  device: Optional[torch.device] = None, process_group=None):
         self.cfg = cfg
+        if cfg.matrix_precision not in ("fp32", "bf16"):
+            raise ValueError("matrix_precision must be 'fp32' or 'bf16'")
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise RuntimeError("KHarmonicTrainer needs a HIP device; there is no CPU path")
         self.lib = L.load()
+        self.lib.lshm_set_matrix_precision(1 if cfg.matrix_precision == "bf16" else 0)
         self.pg = process_group
         self.world = 1
         if process_group is not None:

@@ -464,3 +464,54 @@ def test_flat_dot_alignment_and_tail():
         L.check(lib.lshm_dot_flat(L.ptr(a), L.ptr(b), a.numel(), L.ptr(out), L.ptr(ws), L.stream()))
         want = float((a.double() * b.double()).sum())
         assert abs(float(out[0]) - want) <= 1e-9 * max(1.0, abs(want))
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 6, 9, 12, 13, 14, 15])
+def test_bf16_matrix_operands(cfg):
+    """lshm_set_matrix_precision(1), BASELINE configs[2]: the GEMM-shaped kernels round their operands to bf16
+    (nearest even) and accumulate in fp32.  Checked against fp64 products of the bf16-rounded operands
+    (that is the exact result up to fp32 summation), tight, and against the fp32 result, loose -- and the
+    difference from the fp32 result must be visible, i.e. the switch really reached the kernel."""
+    from lshm_amd import _lib
+    lib = _lib.load()
+    Fh = _F()
+    B, K, N = 48, 784, 224
+    x = O.closed_form((B, K), "bf:x", 1.0, 0.31).to(DEV)
+    w = O.closed_form((N, K), "bf:w", K ** -0.5, 0.77).to(DEV)
+    b = O.closed_form((N,), "bf:b", 0.1, 0.53).to(DEV)
+    gy = O.closed_form((B, N), "bf:gy", 1.0, 0.91).to(DEV)
+
+    def run():
+        xs, ws, bs = (t.clone().requires_grad_(True) for t in (x, w, b))
+        y = Fh.linear_act(xs, ws, bs, False)
+        (y * gy).sum().backward()
+        return y.detach(), xs.grad, ws.grad, bs.grad
+    y32, dx32, dw32, db32 = run()
+    lib.lshm_set_tuning(1, cfg)
+    lib.lshm_set_matrix_precision(1)
+    try:
+        assert lib.lshm_get_matrix_precision() == 1
+        y16, dx16, dw16, db16 = run()
+        # a convolution through the same template: conv2d layer 3 (24 -> 48 channels at 16 x 16)
+        xc = O.closed_form((2, 24, 16, 16), "bf:xc", 1.0, 0.2113).to(DEV)
+        wc = O.closed_form((48, 24, 4, 4), "bf:wc", (3.0 / 384) ** 0.5).to(DEV)
+        bc = O.closed_form((48,), "bf:bc", 0.05).to(DEV)
+        yc16 = Fh.conv_act(xc, wc, bc, KINDS["conv2d"], False)
+    finally:
+        lib.lshm_set_matrix_precision(0)
+        lib.lshm_set_tuning(1, -1)
+    assert lib.lshm_get_matrix_precision() == 0
+    xd, wd, gd = _bf16_round(x).double().cpu(), _bf16_round(w).double().cpu(), _bf16_round(gy).double().cpu()
+    assert rel_err(y16, xd @ wd.t() + b.double().cpu()) < 5e-6
+    assert rel_err(dx16, gd @ wd) < 5e-6
+    assert rel_err(dw16, gd.t() @ xd) < 5e-6
+    assert rel_err(db16, db32) < 1e-6                      # column sums are not a GEMM: unchanged
+    for a16, a32 in ((y16, y32), (dx16, dx32), (dw16, dw32)):
+        assert 1e-4 < rel_err(a16, a32) < 5e-2             # bf16 operands: 2^-9 per factor, cancelling sums
+    yc = torch.nn.functional.conv2d(_bf16_round(xc).double().cpu(), _bf16_round(wc).double().cpu(), bc.double().cpu(),
+                                    stride=2, padding=1)
+    assert rel_err(yc16, yc) < 5e-6

@@ -375,3 +375,50 @@ def test_reuse_forward_is_bitwise_the_same_trajectory():
     assert all(torch.equal(p, q) for p, q in zip(a[1], b[1]))
     assert torch.equal(a[2], b[2])
     assert torch.equal(a[3], b[3])
+
+
+def test_bf16_matrix_precision_step_vs_fp32_oracle():
+    """BASELINE configs[2] (TrainConfig.matrix_precision='bf16'): bf16 operands in the GEMM-shaped layers.
+    Gate of SURVEY 8(c): total loss within rtol 2e-2 of the fp32 reference; here also every logged term, the
+    gradients (3e-2 of the whole vector's norm) and three Adam iterations; and the fp32 mode is restored for later tests."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig, _lib
+    B, K, bpb, bs = 4, 5, 2, 2
+    ocfg = O.StepConfig(K=K, bpb=bpb, batch_size=bs)
+    params, M = O.make_params(ocfg)
+    x, uv = O.closed_form_inputs(B, 4)
+    try:
+        tr = KHarmonicTrainer(TrainConfig(Kc=K, matrix_precision="bf16"), batch=B, batch_per_bline=bpb, default_batch=bs,
+                              device=DEV)
+        assert _lib.load().lshm_get_matrix_precision() == 1
+        tr.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
+        tr.new_minibatch(x.to(DEV), uv.to(DEV))
+        tr.closure_only()
+        y = [torch.zeros(x.numel()) for _ in range(3)]
+        leaves = O.flat_leaves(params, M)
+        for l in leaves:
+            l.requires_grad_(True)
+        total, terms = O.closure_losses(params, M, x, uv, y, ocfg)
+        grads = torch.autograd.grad(total, leaves)
+        for l in leaves:
+            l.requires_grad_(False)
+        t = tr.read_terms()
+        assert abs(t["total"] - total.item()) <= 2e-2 * abs(total.item())
+        for n, ref in zip(("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica"), terms):
+            assert abs(t[n] - float(ref)) <= 2e-2 * abs(float(ref)) + 1e-7, n
+        names = [f"{g}.{k}" for g in O.GROUPS for k in params[g]] + ["mod.M"]
+        # per-tensor errors are dominated by a few cancelling sums (bias gradients of the deep layers): gate the
+        # whole gradient vector, and the median tensor
+        num = sum(float((tr.view(n, tr.grads).cpu().double() - gr.double()).pow(2).sum()) for n, gr in zip(names, grads))
+        den = sum(float(gr.double().pow(2).sum()) for gr in grads)
+        errs = sorted((rel_err(tr.view(n, tr.grads), gr), n) for n, gr in zip(names, grads))
+        assert 1e-5 < (num / den) ** 0.5 < 3e-2, ((num / den) ** 0.5, errs[-3:])
+        assert errs[len(errs) // 2][0] < 1e-1, errs[len(errs) // 2]   # measured 3.5e-2 (net.tconv1.weight)
+        adam = O.AdamState(leaves, ocfg.lr)
+        for _ in range(3):
+            tr.step()
+            ref_terms, y, _ = O.admm_iteration(params, M, x, uv, y, ocfg, adam)
+        t = tr.read_terms()
+        for n, ref in zip(("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica"), ref_terms):
+            assert abs(t[n] - ref) <= 2e-2 * abs(ref) + 1e-7, n
+    finally:
+        _lib.load().lshm_set_matrix_precision(0)
