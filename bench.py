@@ -210,10 +210,13 @@ def rica_dictionary_roofline(dev, nbatch=1152, L=4 * 128 * 128, M=256):
     torch.cuda.synchronize()
     ms_it = (time.perf_counter() - t0) / nit * 1e3
     gemm = 2.0 * nbatch * L * M
+    bf16 = bool(rd.lib.lshm_get_matrix_precision())
+    peak = 2500.0 if bf16 else MFMA_F32_PEAK_TFLOPS  # dense matrix peaks, MI355X_MICROARCH.md
     return {"workload": f"X ~ A S, L={L}, M={M}, nbatch={nbatch} (src/rica_lofar.py:36-40,59-95)", "bound": "mfma",
+            "operands": "bf16" if bf16 else "f32",
             "closure_ms": round(ms_c, 3), "closure_no_grad_ms": round(ms_l, 3), "dictionary_update_ms": round(ms_u, 3),
-            "achieved": round(2 * gemm / (ms_c * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(2 * gemm / (ms_c * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            "achieved": round(2 * gemm / (ms_c * 1e-3) / 1e12, 1), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(2 * gemm / (ms_c * 1e-3) / 1e12 / peak, 4),
             "iteration_ms": round(ms_it, 2), "patches_per_s": round(nbatch / (ms_it * 1e-3), 1),
             "note": "iteration = fresh codes + LBFGSNew(history 7, max_iter 10, line search, batch mode).step + dictionary update"}
 
