@@ -78,6 +78,7 @@ struct lshm_engine {
   std::vector<hipEvent_t> events;
   mutable size_t next_event;
   hipEvent_t latent_event;  // set while the latent-space terms of the current forward are in flight
+  bool sim_started = false;  // cluster_similarity of the current forward already launched (side stream)
   bool recon_ready;         // the workspace already holds the reconstruction terms of the next closure
   size_t o_latent_ws, latent_ws_floats;
   bool side_ok;
@@ -457,9 +458,13 @@ static int latent_losses(lshm_engine* e, const float* prm, float* grd, float* ws
   const float* M = prm + e->Moff;
   int rc;
   const double inv_count = 1.0 / (world * (double)B * c.K * D);
+  // the centroid-similarity term depends on the parameters alone: with a side stream it was started at the
+  // beginning of the forward (start_similarity) and already wrote dM; the K-harmonic term then adds to it
+  const bool sim_done = e->sim_started;
+  e->sim_started = false;
   if ((rc = khm_fwd_bwd(Mu, D, M, B, D, c.K, c.p, 1e-9f, inv_count, c.alpha, scal + 7, gMu, D, dM, 0,
-                        ws + e->o_latent_ws, e->latent_ws_floats, st))) return rc;
-  if ((rc = cluster_sim_fwd_bwd(M, c.K, D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 1, st))) return rc;
+                        ws + e->o_latent_ws, e->latent_ws_floats, st, sim_done ? 1 : 0))) return rc;
+  if (!sim_done && (rc = cluster_sim_fwd_bwd(M, c.K, D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 1, st))) return rc;
   const int bs_global = (int)(c.batch_size * world);
   {
     // augmented loss: local groups, global normalisation.  aug_loss_fwd_bwd normalises by
@@ -500,8 +505,29 @@ static int start_latent_losses(lshm_engine* e, const float* prm, float* grd, flo
   }
   return LSHM_OK;
 }
+// cluster_similarity (src/lofar_models.py:214-229) needs only M: on the side stream it runs beside the whole
+// forward instead of queueing behind the K-harmonic kernel (at K = 64 it is the longest latent-space kernel)
+static int start_similarity(lshm_engine* e, const float* prm, float* grd, float* ws, hipStream_t st) {
+  e->sim_started = false;
+  if (!(e->side_ok && e->side_wgrad)) return LSHM_OK;
+  const lshm_step_config& c = e->cfg;
+  const double world = c.world > 0 ? c.world : 1;
+  hipEvent_t ev = e->take_event();
+  if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->wstream, ev, 0) != hipSuccess) {
+    set_last_error("engine: stream fork failed");
+    return LSHM_ERR_ARG;
+  }
+  double* scal = reinterpret_cast<double*>(ws + e->o_scal);
+  float* dM = grd ? grd + e->Moff : ws + e->o_dMscratch;
+  int rc = cluster_sim_fwd_bwd(prm + e->Moff, c.K, e->D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 0, e->wstream);
+  if (rc) return rc;
+  e->sim_started = true;
+  return LSHM_OK;
+}
 static int forward_with_latent_losses(lshm_engine* e, const float* prm, float* grd, const float* x, const float* uv,
                                       float* ws, hipStream_t st) {
+  int rc0 = start_similarity(e, prm, grd, ws, st);
+  if (rc0) return rc0;
   const std::function<int()> hook = [&]() -> int { return start_latent_losses(e, prm, grd, ws, st); };
   return three_forward(e, prm, x, uv, ws, st, &hook);
 }

@@ -271,7 +271,7 @@ size_t khm_workspace_floats(int N, int D, int K);
 // dX = gscale * d(loss_mean)/dX, dM likewise, with loss_mean = loss_sum/(Ntot*K*D)
 int khm_fwd_bwd(const float* X, long ldx, const float* M, int N, int D, int K, float p, float eps,
                 double inv_count, float gscale, double* loss_sum, float* dX, long lddx, float* dM,
-                int accumulate_dx, float* ws, size_t ws_floats, hipStream_t st);
+                int accumulate_dx, float* ws, size_t ws_floats, hipStream_t st, int accumulate_dm = 0);
 int khm_offline_partials(const float* X, long ldx, const float* M, int N, int D, int K, float p,
                          float eps, float* num, float* den, float* ws, size_t ws_floats,
                          hipStream_t st);

@@ -535,10 +535,10 @@ static int khm_run(const float* X, long ldx, const float* M, int N, int D, int K
 
 int khm_fwd_bwd(const float* X, long ldx, const float* M, int N, int D, int K, float p, float eps,
                 double inv_count, float gscale, double* loss_sum, float* dX, long lddx, float* dM,
-                int accumulate_dx, float* ws, size_t ws_floats, hipStream_t st) {
+                int accumulate_dx, float* ws, size_t ws_floats, hipStream_t st, int accumulate_dm) {
   const float wscale = (float)((double)gscale * inv_count * (double)K);
   return khm_run<KHM_FWD_BWD>(X, ldx, M, N, D, K, p, eps, wscale, dX, lddx, accumulate_dx, dM,
-                              nullptr, loss_sum, 0, ws, ws_floats, st);
+                              nullptr, loss_sum, accumulate_dm, ws, ws_floats, st);
 }
 int khm_offline_partials(const float* X, long ldx, const float* M, int N, int D, int K, float p,
                          float eps, float* num, float* den, float* ws, size_t ws_floats,
