@@ -173,6 +173,103 @@ __global__ __launch_bounds__(NW * 64) void khm_kernel(
 }
 
 // --------------------------------------------------------------------------
+// K > 16 (config 5: K = 64): RS = ceil(D/64) wavefronts share each row, wavefront w owning columns
+// 64w .. 64w+63 (one per lane).  The centroid-side sums then need KT accumulator registers per lane
+// instead of KT*RS (64 instead of 256 at K = 64, D = 256): a workgroup no longer fills a SIMD's register
+// file, so the decoders running beside it on the other stream keep finding CUs to start on (with one
+// wavefront per row, 434 VGPRs, the first decoder GEMM waited 156 us for a 12 us launch).  The partial
+// squared distances of the RS column chunks meet in LDS (one barrier per row, double-buffered, added in
+// wavefront order); every wavefront then derives the same soft-min weights.  Disjoint columns: the slab
+// is written without a block-level combine.
+// --------------------------------------------------------------------------
+template <int MODE, int KT, int RS>
+__global__ __launch_bounds__(RS * 64) void khm_rowsplit_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ Mg, int N, int D, int K,
+    float p, int pint, float eps, float wscale, float* __restrict__ dX, long lddx, int accumulate_dx,
+    float* __restrict__ partial /* [grid][K*D + K] */, double* __restrict__ loss_partial /* [grid] */) {
+  extern __shared__ float lds[];
+  float* Ms = lds;                    // K*D centroids
+  float* exch = lds + (size_t)K * D;  // [2][RS][64] partial squared distances
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = 64 * wave + lane;
+  const bool incol = col < D;
+  for (int i = threadIdx.x; i < K * D; i += blockDim.x) Ms[i] = Mg[i];
+  __syncthreads();
+
+  float T[KT];        // sum_i w_ik x_i[col]
+  float S_mine = 0.f; // lane k: sum_i w_ik
+#pragma unroll
+  for (int k = 0; k < KT; ++k) T[k] = 0.f;
+  double lsum = 0.0;
+  int buf = 0;
+  for (int row = blockIdx.x; row < N; row += gridDim.x) {  // workgroup-uniform bound: barriers are safe
+    const float xr = incol ? X[(long)row * ldx + col] : 0.f;
+    float part = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      if (k < K) {
+        const float d = incol ? xr - Ms[k * D + col] : 0.f;
+        const float a = wave_sum(d * d);
+        if (lane == k) part = a;
+      }
+    }
+    float s_mine = part;
+    if (RS > 1) {
+      float* e = exch + buf * (RS * 64);
+      e[wave * 64 + lane] = part;
+      __syncthreads();
+      s_mine = e[lane];
+#pragma unroll
+      for (int w = 1; w < RS; ++w) s_mine += e[w * 64 + lane];
+      buf ^= 1;  // the other buffer is free again: its readers passed this iteration's barrier
+    }
+    const bool act = lane < K;
+    const float ph = pow_half(s_mine, p, pint);
+    float w_mine;
+    if (MODE == KHM_DIST) {
+      w_mine = act ? ph : 0.f;
+    } else {
+      const float g = ph + eps;
+      const float inv = act ? 1.f / g : 0.f;
+      const float e = wave_sum(inv);
+      if (MODE == KHM_FWD_BWD) {
+        const float ee = e + eps;
+        if (threadIdx.x == 0) lsum += (double)((float)K / ee);
+        w_mine = act ? wscale / (ee * ee) * p * pow_half_m1(s_mine, p, pint) * inv * inv : 0.f;
+      } else {
+        const float alpha = 1.f / (e * e + eps);
+        w_mine = act ? alpha / (ph * s_mine + eps) : 0.f;
+      }
+    }
+    S_mine += w_mine;
+    float dx = 0.f, wsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < KT; ++k) {
+      if (k < K) {
+        const float wk = __shfl(w_mine, k, 64);
+        if (MODE != KHM_DIST) T[k] = fmaf(wk, xr, T[k]);
+        if (MODE == KHM_FWD_BWD) {
+          wsum += wk;
+          if (incol) dx = fmaf(-wk, Ms[k * D + col], dx);
+        }
+      }
+    }
+    if (MODE == KHM_FWD_BWD && dX && incol) {
+      float* dp = dX + (long)row * lddx + col;
+      const float v = fmaf(wsum, xr, dx);
+      *dp = accumulate_dx ? *dp + v : v;
+    }
+  }
+  const int slab = K * D + K;
+  float* out = partial + (size_t)blockIdx.x * slab;
+#pragma unroll
+  for (int k = 0; k < KT; ++k)
+    if (k < K && incol) out[k * D + col] = T[k];
+  if (wave == 0 && lane < K) out[K * D + lane] = S_mine;
+  if (threadIdx.x == 0 && loss_partial) loss_partial[blockIdx.x] = lsum;
+}
+
+// --------------------------------------------------------------------------
 // Streaming fast path for latent_dim == 256 and K <= 16 (the training configuration):
 //   * a wavefront handles 4 rows at a time, 16 lanes per row; lane j of a row owns columns
 //     64q + 4j .. 64q + 4j + 3 (q = 0..3): every load/store instruction moves four 256-byte
@@ -466,6 +563,30 @@ static int khm_launch(dim3 grid, size_t shmem, hipStream_t st, const float* X, l
   return check_launch("khm");
 }
 
+template <int MODE, int KT, int RS>
+static int khm_launch_rowsplit(dim3 grid, hipStream_t st, const float* X, long ldx, const float* M, int N, int D,
+                               int K, float p, int pint, float eps, float wscale, float* dX, long lddx,
+                               int acc_dx, float* partial, double* lpart) {
+  const size_t shmem = ((size_t)K * D + 2 * RS * 64) * sizeof(float);
+  auto kern = khm_rowsplit_kernel<MODE, KT, RS>;
+  if (shmem > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) { set_last_error("khm: cannot raise dynamic LDS limit"); return (int)e; }
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(RS * 64), shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx,
+                     acc_dx, partial, lpart);
+  return check_launch("khm_rowsplit");
+}
+template <int MODE, int RS>
+static int khm_launch_rowsplit_kt(dim3 grid, hipStream_t st, const float* X, long ldx, const float* M, int N,
+                                  int D, int K, float p, int pint, float eps, float wscale, float* dX,
+                                  long lddx, int acc_dx, float* partial, double* lpart) {
+  if (K <= 32)
+    return khm_launch_rowsplit<MODE, 32, RS>(grid, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
+  return khm_launch_rowsplit<MODE, 64, RS>(grid, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
+}
+
 template <int MODE, int NC>
 static int khm_launch_kt(dim3 grid, size_t shmem, hipStream_t st, const float* X, long ldx,
                          const float* M, int N, int D, int K, float p, int pint, float eps,
@@ -478,8 +599,7 @@ static int khm_launch_kt(dim3 grid, size_t shmem, hipStream_t st, const float* X
   if (K <= 8) KHM_GO(8, 4);
   if (K <= 12) KHM_GO(12, 4);
   if (K <= 16) KHM_GO(16, 4);
-  if (K <= 32) KHM_GO(32, 1);
-  KHM_GO(64, 1);
+  KHM_GO(16, 4);  // K > 16 takes the row-split kernel (khm_run)
 #undef KHM_GO
 }
 
@@ -523,6 +643,13 @@ static int khm_run(const float* X, long ldx, const float* M, int N, int D, int K
     else KHM_FAST(16);
 #undef KHM_FAST
     rc = check_launch("khm256");
+  } else if (K > 16) {  // row-split form: RS wavefronts per row
+#define KHM_RS(RSV) rc = khm_launch_rowsplit_kt<MODE, RSV>(grid, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart)
+    if (nc <= 1) KHM_RS(1);
+    else if (nc <= 2) KHM_RS(2);
+    else if (nc <= 4) KHM_RS(4);
+    else KHM_RS(8);
+#undef KHM_RS
   } else if (nc <= 1) rc = khm_launch_kt<MODE, 1>(grid, shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
   else if (nc <= 2) rc = khm_launch_kt<MODE, 2>(grid, shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);
   else if (nc <= 4) rc = khm_launch_kt<MODE, 4>(grid, shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart);

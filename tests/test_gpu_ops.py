@@ -196,7 +196,9 @@ def test_khm_known_answer_equal_distances():
 
 def test_khm_ragged_sizes_and_offline_partials():
     Fh = _F()
-    for (N, K, D, p) in [(1, 1, 8, 2), (7, 3, 100, 4), (130, 17, 256, 4), (33, 64, 256, 3), (1000, 10, 256, 4)]:
+    # K > 16 takes the row-split kernel: one, two, four and eight wavefronts per row (D <= 64, 128, 256, 512)
+    for (N, K, D, p) in [(1, 1, 8, 2), (7, 3, 100, 4), (130, 17, 256, 4), (33, 64, 256, 3), (1000, 10, 256, 4),
+                         (9, 20, 40, 4), (700, 33, 100, 2), (5, 64, 300, 4), (21, 17, 512, 4)]:
         X = 0.8 * O.closed_form((N, D), "rag:X", 1.0, 0.4142) + 0.3
         M = 0.5 + 0.5 * O.closed_form((K, D), "rag:M", 1.0, 0.618)
         Xg, Mg = X.to(DEV).requires_grad_(True), M.to(DEV).requires_grad_(True)
