@@ -186,14 +186,14 @@ def fft_roofline(tr, dev):
 MFMA_F32_PEAK_TFLOPS = 157.0  # dense fp32 matrix-core peak, MI355X_MICROARCH.md
 
 
-def rica_dictionary_roofline(dev, nbatch=1152, L=4 * 128 * 128, M=256):
+def rica_dictionary_roofline(dev, nbatch=1152, L=4 * 128 * 128, M=256, bf16=False):
     """SURVEY 8 f4, not the headline: dictionary learning of src/rica_lofar.py at its own sizes (L = 4*128*128,
     M = 256 :36-40; default_batch = 128 baselines x 9 patches = 1152 columns).  The closure is two fp32 GEMMs
     of 2 nbatch L M flop (A S and the code gradient), the dictionary update two more -- the one
     matrix-core-bound workload of the repository, priced against the dense fp32 MFMA peak."""
     from lshm_amd.rica_lofar import RicaDictionary
     g = torch.Generator().manual_seed(11)
-    rd = RicaDictionary(L, M, device=dev, A=torch.rand(L, M, generator=g))
+    rd = RicaDictionary(L, M, device=dev, A=torch.rand(L, M, generator=g), matrix_precision="bf16" if bf16 else "fp32")
     x = torch.randn(nbatch, L, generator=g).to(dev)  # resident, like the headline's inputs
     rd.set_minibatch(x)
     St = torch.rand(nbatch, M, generator=g).to(dev).requires_grad_(True)
@@ -210,7 +210,7 @@ def rica_dictionary_roofline(dev, nbatch=1152, L=4 * 128 * 128, M=256):
     torch.cuda.synchronize()
     ms_it = (time.perf_counter() - t0) / nit * 1e3
     gemm = 2.0 * nbatch * L * M
-    bf16 = bool(rd.lib.lshm_get_matrix_precision())
+    bf16 = rd.bf16
     peak = 2500.0 if bf16 else MFMA_F32_PEAK_TFLOPS  # dense matrix peaks, MI355X_MICROARCH.md
     return {"workload": f"X ~ A S, L={L}, M={M}, nbatch={nbatch} (src/rica_lofar.py:36-40,59-95)", "bound": "mfma",
             "operands": "bf16" if bf16 else "f32",
@@ -291,8 +291,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # one process per GPU, started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the
+        # environment): never report a 1-GPU measurement under an N-GPU label
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"`python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} "
+                         f"--master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     if os.environ.get("LSHM_SHARE_GPU0") == "1":  # rehearsal of the N>1 path on a one-GPU box
         local = 0
@@ -310,6 +314,9 @@ def main():
             dist.init_process_group(backend)
         pg = dist.group.WORLD
 
+    if args.save_tuning:  # measuring mode: every GEMM shape of this run times its tile configurations once
+        from lshm_amd import _lib as _L
+        _L.load().lshm_set_tuning(1, -1)
     if args.only_khm:
         print(json.dumps({"khm_roofline": khm_roofline(dev), "khm_B256": khm_roofline(dev, N=256)}))
         return
@@ -431,7 +438,7 @@ def main():
         out["other_kernels"] = other_kernel_rooflines(tr, dev)
         out["fft_roofline"] = fft_roofline(tr, dev)
         if not args.no_rica:
-            out["rica_dictionary"] = rica_dictionary_roofline(dev)
+            out["rica_dictionary"] = rica_dictionary_roofline(dev, bf16=args.bf16)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -18,9 +18,12 @@
  *  - `stream` is a hipStream_t (pass the caller's current stream); calls only
  *    enqueue work (no synchronisation) and are HIP-graph capturable;
  *  - no global mutable state except the mutex-guarded tile-configuration cache
- *    (lshm_set_tuning / lshm_tuning_import) and the process-wide matrix-operand
- *    precision switch (lshm_set_matrix_precision); distinct streams may be driven
- *    from distinct threads.
+ *    (lshm_set_tuning / lshm_tuning_import); operand precision is per call (`_bf16`
+ *    suffix) or per engine (lshm_step_config.precision); distinct streams may be
+ *    driven from distinct threads;
+ *  - an engine remembers the HIP device that was current at lshm_engine_create and makes
+ *    it current for the duration of every engine call; the per-op entry points run on the
+ *    calling thread's current device (the caller's stream must belong to it).
  */
 #ifndef LSHM_H
 #define LSHM_H
@@ -47,18 +50,21 @@ typedef void* lshm_stream_t; /* hipStream_t */
 
 int lshm_version(void);
 const char* lshm_last_error_string(void);
-/* GEMM-shaped kernels pick their tile configuration per problem shape.  mode 1 (default, or env
- * LSHM_TUNE=1): the first eager call of a shape times the candidates on the caller's buffers and
- * caches the winner; mode 0: static heuristic.  force >= 0 pins configuration `force` (0..15) for
- * every launch (parity tests sweep it); -1 unpins.  Clears the cache. */
+/* GEMM-shaped kernels pick their tile configuration per problem shape: from the table of measured shapes
+ * (lshm_tuning_import; the one measured on MI355X ships with the package), else a static heuristic -- no
+ * timing, no synchronisation, the same kernels in every process (mode 0, the default).  mode 1 (or env
+ * LSHM_TUNE=1) is the measuring mode: the table is cleared and the first eager call of each shape times the
+ * candidates on the caller's buffers (this synchronises inside the call) and caches the winner.  force >= 0
+ * pins configuration `force` (0..21) for every launch (parity tests sweep it); -1 unpins. */
 void lshm_set_tuning(int mode, int force);
 /* Operand precision of the GEMM-shaped kernels (conv2-5 / tconv0-3 of the three autoencoders, their
- * weight gradients, the dense layers, the dictionary-learning GEMMs).  0 (default): fp32 operands on
- * v_mfma_f32_16x16x4_f32, bitwise an fmaf chain.  1: operands rounded to bf16 (nearest even) as they are
- * staged in LDS, v_mfma_f32_16x16x16_bf16, fp32 accumulation -- BASELINE.json configs[2]; everything in
- * HBM, the bandwidth-bound outer layers, losses and optimiser stay fp32. */
-void lshm_set_matrix_precision(int bf16);
-int lshm_get_matrix_precision(void);
+ * weight gradients, the dense layers, the dictionary-learning GEMMs) is chosen per call: the plain entry
+ * points use fp32 operands on v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain); their `_bf16` forms (below,
+ * next to each family) round the operands to bf16 (nearest even) as they are staged in LDS and multiply
+ * on v_mfma_f32_16x16x16_bf16 with fp32 accumulation -- BASELINE.json configs[2].  An engine takes its
+ * precision from lshm_step_config.precision. */
+#define LSHM_PRECISION_F32 0
+#define LSHM_PRECISION_BF16_OPERANDS 1
 /* The cache as text ("policy M N K Z groups config" per line).  export returns the buffer size needed
  * (terminating 0 included) and fills buf up to cap; import merges entries and returns how many it read.
  * Importing the table measured on the target GPU makes runs start without timing launches and
@@ -97,6 +103,15 @@ int lshm_conv_dgrad(int kind, const float* dz, const float* w, float* dx, const 
 int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float* db, int B, int Cin,
                     int Cout, int Hin, int Win, long in_bs, long out_bs, float* workspace,
                     size_t workspace_floats, int accumulate, lshm_stream_t stream);
+int lshm_conv_fwd_bf16(int kind, const float* x, const float* w, const float* bias, float* y, int B,
+                       int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, int act,
+                       float* workspace, size_t workspace_floats, lshm_stream_t stream);
+int lshm_conv_dgrad_bf16(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved,
+                         int B, int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs,
+                         float* workspace, size_t workspace_floats, lshm_stream_t stream);
+int lshm_conv_wgrad_bf16(int kind, const float* x, const float* dz, float* dw, float* db, int B, int Cin,
+                         int Cout, int Hin, int Win, long in_bs, long out_bs, float* workspace,
+                         size_t workspace_floats, int accumulate, lshm_stream_t stream);
 /* dz = gy * ELU'(y) from the saved output y                      (autograd of F.elu) */
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t stream);
 
@@ -111,6 +126,16 @@ int lshm_linear_dgrad(const float* dz, long lddz, const float* w, float* dx, lon
 int lshm_linear_wgrad(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db,
                       int B, int K, int N, float* workspace, size_t workspace_floats,
                       lshm_stream_t stream);
+
+int lshm_linear_fwd_bf16(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                         int B, int K, int N, int act, float* workspace, size_t workspace_floats,
+                         lshm_stream_t stream);
+int lshm_linear_dgrad_bf16(const float* dz, long lddz, const float* w, float* dx, long lddx,
+                           const float* x_saved, long ldxs, int B, int K, int N, float* workspace,
+                           size_t workspace_floats, lshm_stream_t stream);
+int lshm_linear_wgrad_bf16(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db,
+                           int B, int K, int N, float* workspace, size_t workspace_floats,
+                           lshm_stream_t stream);
 
 /* ---- K-harmonic means                                           src/lofar_models.py:199-212
  * X (N,D) with leading dimension ldx, M (K,D).  loss_sum[0] = sum_i K/(e_i+eps) (caller divides by
@@ -156,6 +181,13 @@ int lshm_rica_loss_grad(const float* Xt, const float* A, const float* St, int B,
 int lshm_rica_update_dictionary(const float* Xt, float* A, const float* St, int B, int L, int M,
                                 float eta, double* dA_norm_sq, float* workspace,
                                 size_t workspace_floats, lshm_stream_t stream);
+
+int lshm_rica_loss_grad_bf16(const float* Xt, const float* A, const float* St, int B, int L, int M,
+                             float lambda1, double* loss, float* dSt, float* workspace,
+                             size_t workspace_floats, lshm_stream_t stream);
+int lshm_rica_update_dictionary_bf16(const float* Xt, float* A, const float* St, int B, int L, int M,
+                                     float eta, double* dA_norm_sq, float* workspace,
+                                     size_t workspace_floats, lshm_stream_t stream);
 
 /* ---- glue of the closure                                        src/kharmonic_lofar.py:137-158 */
 /* out_row = (x-x1)/2, out_col = per-plane transpose of it (planes = B*C planes of P x P) */
@@ -216,6 +248,7 @@ typedef struct lshm_step_config {
   int H;                /* number of harmonic scales (4) */
   float scales[8];
   int world;            /* data-parallel world size (gradients are averaged over it) */
+  int precision;        /* LSHM_PRECISION_*: operand precision of this engine's GEMM-shaped layers */
 } lshm_step_config;
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);
@@ -229,11 +262,21 @@ int lshm_engine_param_name(const lshm_engine* e, int index, char* buf, int bufle
 size_t lshm_engine_workspace_floats(const lshm_engine* e);
 /* closure forward + backward: fills grads (same layout as params) and terms[16] (double, device):
  * [0..7] = loss0, loss1, loss2, loss3, kdist, aug, sim, rica (already weighted, as logged upstream),
- * [8] = total.  With world > 1 the loss terms / gradients are this rank's share (sum over ranks = global). */
+ * [8] = total, [9] = how many of [0..7] are NaN or infinite (0 = healthy; sums over ranks like the rest).  With world > 1 the loss terms / gradients are this rank's share (sum over ranks = global). */
 int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* grads, const float* x,
                                  const float* uv, const float* y1, const float* y2, const float* y3,
                                  double* terms, float* workspace, size_t workspace_floats,
                                  lshm_stream_t stream);
+/* flags of lshm_engine_forward_backward_ex */
+#define LSHM_STEP_RECON_READY 1u /* the last engine call on this workspace was lshm_engine_multiplier_update_next
+                                  * with these params / x / uv and the multipliers have not changed since: the
+                                  * reconstruction terms and their three gradient images it left behind are the ones
+                                  * this closure would compute (bit for bit), so that pass is skipped; the forward
+                                  * itself is recomputed, as upstream does (src/kharmonic_lofar.py:135-150) */
+int lshm_engine_forward_backward_ex(lshm_engine* e, const float* params, float* grads, const float* x,
+                                    const float* uv, const float* y1, const float* y2, const float* y3,
+                                    double* terms, float* workspace, size_t workspace_floats, unsigned flags,
+                                    lshm_stream_t stream);
 /* The same closure on the activations a previous forward left in `workspace`.  Inside the ADMM loop
  * (src/kharmonic_lofar.py:131-202) the no-grad forward of iteration k (lshm_engine_multiplier_update,
  * after the optimizer step) and the closure forward of iteration k+1 evaluate the same networks on the
@@ -246,7 +289,8 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
                                float* workspace, size_t workspace_floats, lshm_stream_t stream);
 /* lshm_engine_multiplier_update that also leaves the reconstruction terms of the *next* closure in the
  * workspace (they read the same seven image-sized arrays as the multiplier update: one pass instead of two).
- * A following lshm_engine_backward_saved picks them up; any other forward discards them. */
+ * A following lshm_engine_backward_saved, or lshm_engine_forward_backward_ex with LSHM_STEP_RECON_READY, picks
+ * them up; any other forward discards them. */
 int lshm_engine_multiplier_update_next(lshm_engine* e, const float* params, const float* x, const float* uv,
                                        float* y1, float* y2, float* y3, float* workspace,
                                        size_t workspace_floats, lshm_stream_t stream);

@@ -32,15 +32,18 @@ class StepConfig(C.Structure):
     _fields_ = [("B", c_int), ("C", c_int), ("P", c_int), ("L", c_int), ("Lt", c_int), ("K", c_int),
                 ("p", c_float), ("alpha", c_float), ("beta", c_float), ("gamma", c_float),
                 ("rho", c_float), ("rica_lambda", c_float), ("rica", c_int), ("bpb", c_int),
-                ("batch_size", c_int), ("H", c_int), ("scales", c_float * 8), ("world", c_int)]
+                ("batch_size", c_int), ("H", c_int), ("scales", c_float * 8), ("world", c_int),
+                ("precision", c_int)]
+
+
+PRECISION_F32, PRECISION_BF16_OPERANDS = 0, 1
+STEP_RECON_READY = 1
 
 
 _SIGNATURES = {
     "lshm_version": (c_int, []),
     "lshm_last_error_string": (C.c_char_p, []),
     "lshm_set_tuning": (None, [c_int, c_int]),
-    "lshm_set_matrix_precision": (None, [c_int]),
-    "lshm_get_matrix_precision": (c_int, []),
     "lshm_tuning_export": (c_size_t, [c_void_p, c_size_t]),
     "lshm_tuning_import": (c_int, [C.c_char_p]),
     "lshm_uv_harmonics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
@@ -103,12 +106,18 @@ _SIGNATURES = {
                                        C.POINTER(c_long), C.POINTER(c_int), C.POINTER(c_long)]),
     "lshm_engine_workspace_floats": (c_size_t, [c_void_p]),
     "lshm_engine_forward_backward": (c_int, [c_void_p] * 9 + [c_void_p, c_size_t, c_void_p]),
+    "lshm_engine_forward_backward_ex": (c_int, [c_void_p] * 9 + [c_void_p, c_size_t, C.c_uint, c_void_p]),
     "lshm_engine_forward_loss": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_backward_saved": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_multiplier_update": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_multiplier_update_next": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_encode": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
 }
+# `_bf16` forms of the GEMM-shaped entry points: same prototypes (include/lshm.h)
+for _n in ("lshm_conv_fwd", "lshm_conv_dgrad", "lshm_conv_wgrad", "lshm_linear_fwd", "lshm_linear_dgrad",
+           "lshm_linear_wgrad", "lshm_rica_loss_grad", "lshm_rica_update_dictionary"):
+    _SIGNATURES[_n + "_bf16"] = _SIGNATURES[_n]
+del _n
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -173,15 +182,29 @@ _scratch = {}
 
 
 def scratch(device, nfloats: int):
-    """Per-device split-K scratch reused by the autograd wrappers (work on one stream is ordered,
-    so one buffer per device is enough); grows on demand."""
-    key = (device.type, device.index)
+    """Split-K scratch reused by the autograd wrappers, one buffer per (device, stream): work on one
+    stream is ordered, work on two streams is not, so they never share.  Grows on demand."""
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, torch.cuda.current_stream(index).cuda_stream)
     t = _scratch.get(key)
     if t is None or t.numel() < nfloats:
-        t = torch.empty(max(int(nfloats), 1 << 20), device=device, dtype=torch.float32)
+        t = torch.empty(max(int(nfloats), 1 << 20), device=torch.device("cuda", index), dtype=torch.float32)
         _scratch[key] = t
     return t
 
 
-def stream():
-    return torch.cuda.current_stream().cuda_stream
+def stream(device=None):
+    """hipStream_t of torch's current stream on `device` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def on_device(device):
+    """Context manager: `device` is the current HIP device inside (kernels are launched on the current
+    device; a tensor or stream of another one would fault or cross the fabric silently)."""
+    return torch.cuda.device(device)
+
+
+def fn(name: str, bf16: bool = False):
+    """Entry point `name`, or its `_bf16` form (operands rounded to bf16 in the GEMM-shaped kernels)."""
+    return getattr(load(), name + "_bf16" if bf16 else name)

@@ -53,8 +53,6 @@ extern "C" {
 int lshm_version(void) { return 100; }
 const char* lshm_last_error_string(void) { return g_err; }
 void lshm_set_tuning(int mode, int force) { igemm_set_tuning(mode, force); }
-void lshm_set_matrix_precision(int bf16) { igemm_set_matrix_precision(bf16); }
-int lshm_get_matrix_precision(void) { return igemm_matrix_precision(); }
 size_t lshm_tuning_export(char* buf, size_t cap) { return igemm_tuning_export(buf, cap); }
 int lshm_tuning_import(const char* text) { return igemm_tuning_import(text); }
 
@@ -247,6 +245,54 @@ int lshm_patches_from_vis(const int8_t* vis, const float* scale, int nb, int nti
 int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv, lshm_stream_t s) {
   REQUIRE(x && out && B > 0 && C > 0, "fft2: bad argument");
   return fft2_ortho_shift_cat_clamp(x, out, B, C, clampv, ST(s));
+}
+
+/* ---- `_bf16` forms of the GEMM-shaped entry points: same arguments, operands rounded to bf16 at LDS
+ * staging (v_mfma_f32_16x16x16_bf16), fp32 accumulation and storage.  The precision is a property of the
+ * call (scope of the calling thread), never of the process. */
+int lshm_conv_fwd_bf16(int kind, const float* x, const float* w, const float* bias, float* y, int B, int Cin,
+                       int Cout, int Hin, int Win, long in_bs, long out_bs, int act, float* ws, size_t wsf,
+                       lshm_stream_t s) {
+  MatrixPrecisionScope sc(1);
+  return lshm_conv_fwd(kind, x, w, bias, y, B, Cin, Cout, Hin, Win, in_bs, out_bs, act, ws, wsf, s);
+}
+int lshm_conv_dgrad_bf16(int kind, const float* dz, const float* w, float* dx, const float* y_in_saved, int B,
+                         int Cin, int Cout, int Hin, int Win, long in_bs, long out_bs, float* ws, size_t wsf,
+                         lshm_stream_t s) {
+  MatrixPrecisionScope sc(1);
+  return lshm_conv_dgrad(kind, dz, w, dx, y_in_saved, B, Cin, Cout, Hin, Win, in_bs, out_bs, ws, wsf, s);
+}
+int lshm_conv_wgrad_bf16(int kind, const float* x, const float* dz, float* dw, float* db, int B, int Cin,
+                         int Cout, int Hin, int Win, long in_bs, long out_bs, float* ws, size_t wsf,
+                         int accumulate, lshm_stream_t s) {
+  MatrixPrecisionScope sc(1);
+  return lshm_conv_wgrad(kind, x, dz, dw, db, B, Cin, Cout, Hin, Win, in_bs, out_bs, ws, wsf, accumulate, s);
+}
+int lshm_linear_fwd_bf16(const float* x, long ldx, const float* w, const float* bias, float* y, long ldy,
+                         int B, int K, int N, int act, float* ws, size_t wsf, lshm_stream_t s) {
+  MatrixPrecisionScope sc(1);
+  return lshm_linear_fwd(x, ldx, w, bias, y, ldy, B, K, N, act, ws, wsf, s);
+}
+int lshm_linear_dgrad_bf16(const float* dz, long lddz, const float* w, float* dx, long lddx,
+                           const float* x_saved, long ldxs, int B, int K, int N, float* ws, size_t wsf,
+                           lshm_stream_t s) {
+  MatrixPrecisionScope sc(1);
+  return lshm_linear_dgrad(dz, lddz, w, dx, lddx, x_saved, ldxs, B, K, N, ws, wsf, s);
+}
+int lshm_linear_wgrad_bf16(const float* x, long ldx, const float* dz, long lddz, float* dw, float* db, int B,
+                           int K, int N, float* ws, size_t wsf, lshm_stream_t s) {
+  MatrixPrecisionScope sc(1);
+  return lshm_linear_wgrad(x, ldx, dz, lddz, dw, db, B, K, N, ws, wsf, s);
+}
+int lshm_rica_loss_grad_bf16(const float* Xt, const float* A, const float* St, int B, int L, int M, float lambda1,
+                             double* loss, float* dSt, float* ws, size_t wsf, lshm_stream_t s) {
+  MatrixPrecisionScope sc(1);
+  return lshm_rica_loss_grad(Xt, A, St, B, L, M, lambda1, loss, dSt, ws, wsf, s);
+}
+int lshm_rica_update_dictionary_bf16(const float* Xt, float* A, const float* St, int B, int L, int M, float eta,
+                                     double* dA_norm_sq, float* ws, size_t wsf, lshm_stream_t s) {
+  MatrixPrecisionScope sc(1);
+  return lshm_rica_update_dictionary(Xt, A, St, B, L, M, eta, dA_norm_sq, ws, wsf, s);
 }
 
 }  // extern "C"

@@ -87,6 +87,7 @@ struct lshm_engine {
   hipEvent_t take_event() const { return events[next_event++ % events.size()]; }
   size_t part_floats;
   size_t ws_floats;
+  int device;      // HIP device current at creation (-1: none); the side stream and the events live there
 };
 
 namespace lshm {
@@ -398,6 +399,11 @@ __global__ void finalize_terms_kernel(const double* __restrict__ scal, double* _
   terms[0] = l0; terms[1] = l1; terms[2] = l2; terms[3] = l3;
   terms[4] = kd; terms[5] = aug; terms[6] = sim; terms[7] = rc;
   terms[8] = l0 + l1 + l2 + l3 + kd + aug + sim + rc;
+  // failure detection (the reference only guards LBFGS scalars, src/lbfgsnew.py:153,170,237,...): number of
+  // logged terms that are NaN or infinite; under data parallelism the slot sums to the job-wide count
+  int bad = 0;
+  for (int i = 0; i < 8; ++i) bad += !(fabs(terms[i]) <= 1.79769313486231570e308);
+  terms[9] = (double)bad;
 }
 
 static int three_forward(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws,
@@ -605,6 +611,37 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
 
 }  // namespace lshm
 
+// Scope of one engine call: the engine's device is current, its operand precision applies to the launches
+// of this thread, and a stream capture is refused where it is known to crash the runtime.
+struct EngineCall {
+  MatrixPrecisionScope prec;
+  int prev_dev = -1;
+  bool switched = false;
+  explicit EngineCall(const lshm_engine* e) : prec(e->cfg.precision == LSHM_PRECISION_BF16_OPERANDS) {
+    if (e->device >= 0 && hipGetDevice(&prev_dev) == hipSuccess && prev_dev != e->device)
+      switched = hipSetDevice(e->device) == hipSuccess;
+  }
+  ~EngineCall() {
+    if (switched) (void)hipSetDevice(prev_dev);
+  }
+};
+// Fork mode (LSHM_FORK=1: netT and netF on two streams, each with its own weight-gradient fork) nests stream
+// forks; ending a capture of that topology crashes hipStreamEndCapture (ROCm 7.2).  Refuse it up front.
+static int capture_fence(const lshm_engine* e, hipStream_t st) {
+  if (e->pair_mode || !e->side_ok) return LSHM_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return LSHM_OK; }
+  if (cap == hipStreamCaptureStatusNone) return LSHM_OK;
+  set_last_error("engine: stream capture is not supported in fork mode (LSHM_FORK=1); use the default paired launches");
+  return LSHM_ERR_UNSUPPORTED;
+}
+#define ENGINE_ENTER(e, st)                       \
+  EngineCall engine_call_scope(e);                \
+  do {                                            \
+    const int rc_fence = capture_fence(e, st);    \
+    if (rc_fence) return rc_fence;                \
+  } while (0)
+
 extern "C" {
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
@@ -613,6 +650,10 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   if (cfg->B < 1 || cfg->C < 1 || cfg->L < 1 || cfg->Lt < 1 || cfg->K < 1 || cfg->H < 1 || cfg->H > 8 ||
       cfg->bpb < 1 || cfg->batch_size < 1) {
     set_last_error("engine_create: bad configuration");
+    return LSHM_ERR_ARG;
+  }
+  if (cfg->precision != LSHM_PRECISION_F32 && cfg->precision != LSHM_PRECISION_BF16_OPERANDS) {
+    set_last_error("engine_create: unknown precision");
     return LSHM_ERR_ARG;
   }
   if (cfg->K > 64 || cfg->L + 2 * cfg->Lt > 512 || cfg->bpb > 32) {
@@ -707,10 +748,12 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->side_ok = false;
   e->next_event = 0;
   e->pair_mode = getenv("LSHM_FORK") == nullptr;
+  e->device = -1;
   {
     int ndev = 0;
     e->side_wgrad = getenv("LSHM_WGRAD_INLINE") == nullptr;
-    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && (!e->pair_mode || e->side_wgrad)) {
+    if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDevice(&e->device) != hipSuccess) e->device = -1;
+    if (e->device >= 0 && (!e->pair_mode || e->side_wgrad)) {
       bool ok = hipStreamCreateWithFlags(&e->wstream, hipStreamNonBlocking) == hipSuccess;
       e->events.resize(128);
       for (size_t i = 0; i < e->events.size() && ok; ++i)
@@ -729,6 +772,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
 void lshm_engine_destroy(lshm_engine* e) {
   if (!e) return;
   if (e->side_ok) {
+    EngineCall scope(e);
     (void)hipStreamDestroy(e->wstream);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   }
@@ -774,16 +818,26 @@ size_t lshm_engine_workspace_floats(const lshm_engine* e) { return e ? e->ws_flo
     }                               \
   } while (0)
 
-int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* grads, const float* x,
-                                 const float* uv, const float* y1, const float* y2, const float* y3,
-                                 double* terms, float* ws, size_t wsf, lshm_stream_t s) {
+int lshm_engine_forward_backward_ex(lshm_engine* e, const float* params, float* grads, const float* x,
+                                    const float* uv, const float* y1, const float* y2, const float* y3,
+                                    double* terms, float* ws, size_t wsf, unsigned flags, lshm_stream_t s) {
   ENGINE_CHECK(e && params && grads && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_backward: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  ENGINE_ENTER(e, st);
   e->next_event = 0;
+  // the forward below is recomputed either way; only the reconstruction pass can be the one the preceding
+  // lshm_engine_multiplier_update_next already made with the same inputs
+  const bool recon_done = (flags & LSHM_STEP_RECON_READY) && e->recon_ready;
   int rc = forward_with_latent_losses(e, params, grads, x, uv, ws, st);
   if (rc) return rc;
-  return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st);
+  return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st, recon_done);
+}
+
+int lshm_engine_forward_backward(lshm_engine* e, const float* params, float* grads, const float* x,
+                                 const float* uv, const float* y1, const float* y2, const float* y3,
+                                 double* terms, float* ws, size_t wsf, lshm_stream_t s) {
+  return lshm_engine_forward_backward_ex(e, params, grads, x, uv, y1, y2, y3, terms, ws, wsf, 0u, s);
 }
 
 int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads, const float* x, const float* y1,
@@ -792,6 +846,7 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
   ENGINE_CHECK(e && params && grads && x && y1 && y2 && y3 && terms && ws, "engine_backward_saved: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  ENGINE_ENTER(e, st);
   e->next_event = 0;
   const bool recon_done = e->recon_ready;
   e->recon_ready = false;
@@ -805,6 +860,7 @@ int lshm_engine_multiplier_update_next(lshm_engine* e, const float* params, cons
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update_next: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  ENGINE_ENTER(e, st);
   e->next_event = 0;
   e->recon_ready = false;
   int rc = three_forward(e, params, x, uv, ws, st);
@@ -825,6 +881,7 @@ int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_loss: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  ENGINE_ENTER(e, st);
   e->next_event = 0;
   int rc = forward_with_latent_losses(e, params, nullptr, x, uv, ws, st);
   if (rc) return rc;
@@ -837,6 +894,7 @@ int lshm_engine_multiplier_update(lshm_engine* e, const float* params, const flo
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  ENGINE_ENTER(e, st);
   e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
@@ -850,6 +908,7 @@ int lshm_engine_encode(lshm_engine* e, const float* params, const float* x, cons
   ENGINE_CHECK(e && params && x && uv && ws, "engine_encode: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
+  ENGINE_ENTER(e, st);
   e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;

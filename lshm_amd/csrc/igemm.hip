@@ -45,7 +45,7 @@ struct Pair {
 // workgroups needs a second launch to combine the slabs.
 // BF: the operands are rounded to bf16 (nearest even) on their way into LDS and multiplied with
 // v_mfma_f32_16x16x16_bf16 (one instruction per k-block instead of four, 8-byte operand reads); the
-// accumulators, the epilogues and everything in HBM stay fp32.  Opt-in (lshm_set_matrix_precision).
+// accumulators, the epilogues and everything in HBM stay fp32.  Opt-in (MatrixPrecisionScope).
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned bf16_bits(float v) {  // round to nearest even; NaN stays NaN
   const unsigned u = __float_as_uint(v);
@@ -791,9 +791,10 @@ static SplitPlan plan_split(long tiles, int K, int M, int N, int zgroups, size_t
 }
 
 static const long kSplitTargets[3] = {768, 0, 1536};
-static std::atomic<int> g_matrix_bf16{0};
-void igemm_set_matrix_precision(int bf16) { g_matrix_bf16.store(bf16 ? 1 : 0); }
-int igemm_matrix_precision() { return g_matrix_bf16.load(); }
+static thread_local int t_matrix_bf16 = 0;
+MatrixPrecisionScope::MatrixPrecisionScope(int bf16) : prev(t_matrix_bf16) { t_matrix_bf16 = bf16 ? 1 : 0; }
+MatrixPrecisionScope::~MatrixPrecisionScope() { t_matrix_bf16 = prev; }
+int igemm_matrix_precision() { return t_matrix_bf16; }
 
 template <class P, int BM, int BN, int BK, int KW = 0>
 static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1, int M, int N, int Z,
@@ -812,7 +813,7 @@ static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1
   }
   pp.zper = Z * sp.splits;
   dim3 grid(cdiv(M, BM), cdiv(N, BN), Z * sp.splits * G);
-  if (g_matrix_bf16.load())
+  if (t_matrix_bf16)
     hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, KW, true>), grid, dim3(256), 0, st, pp);
   else
     hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, KW, false>), grid, dim3(256), 0, st, pp);
@@ -851,7 +852,10 @@ static int launch_by_n(const typename P::Params& p, const typename P::Params* p1
 // A launch configuration is (M tile 64|128) x (K chunk 16|32) x (split-K mode): index bits 0, 1, 2..3;
 // 12, 13: the K-over-wavefronts form with 16-row tiles (four wavefronts per tile, K chunk 64) without /
 // with split-K; 14, 15: the same with 32-row tiles (two wavefronts per 16 rows).
-constexpr int kNumConfigs = 16;
+// 16..21: deep K chunks without the K-over-wavefronts split (64 / 128 / 64 elements of K per barrier for
+// 64- / 64- / 128-row tiles; even: unsplit, odd: split-K towards 768 workgroups): the mid layers are bound by
+// the chain of dependent global loads, one per K chunk, so fewer, fatter chunks keep more loads in flight.
+constexpr int kNumConfigs = 22;
 template <class P>
 static int launch_idx(int c, const typename P::Params& p, const typename P::Params* p1, int M, int N, int Z,
                       float* ws, size_t wsf, hipStream_t st, GradJobs* defer = nullptr) {
@@ -859,6 +863,12 @@ static int launch_idx(int c, const typename P::Params& p, const typename P::Para
   if (c == 13) return launch_by_n<P, 16, 64, 4>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
   if (c == 14) return launch_by_n<P, 32, 64, 2>(p, p1, M, N, Z, ws, wsf, 1, st, defer);
   if (c == 15) return launch_by_n<P, 32, 64, 2>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
+  if (c == 16) return launch_by_n<P, 64, 64>(p, p1, M, N, Z, ws, wsf, 1, st, defer);
+  if (c == 17) return launch_by_n<P, 64, 64>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
+  if (c == 18) return launch_by_n<P, 64, 128>(p, p1, M, N, Z, ws, wsf, 1, st, defer);
+  if (c == 19) return launch_by_n<P, 64, 128>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
+  if (c == 20) return launch_by_n<P, 128, 64>(p, p1, M, N, Z, ws, wsf, 1, st, defer);
+  if (c == 21) return launch_by_n<P, 128, 64>(p, p1, M, N, Z, ws, wsf, 0, st, defer);
   const int smode = c >> 2;
   switch (c & 3) {
     case 0: return launch_by_n<P, 64, 16>(p, p1, M, N, Z, ws, wsf, smode, st, defer);
@@ -875,14 +885,14 @@ static int launch_idx(int c, const typename P::Params& p, const typename P::Para
 // arrive while the stream is being captured take the static heuristic and leave the cache alone.
 // --------------------------------------------------------------------------
 struct TuneKey {
-  int pol, M, N, K, Z, G;
+  int pol, M, N, K, Z, G, prec;  // prec: operand precision the entry was measured with (0 fp32, 1 bf16)
   bool operator<(const TuneKey& o) const {
-    return std::tie(pol, M, N, K, Z, G) < std::tie(o.pol, o.M, o.N, o.K, o.Z, o.G);
+    return std::tie(pol, M, N, K, Z, G, prec) < std::tie(o.pol, o.M, o.N, o.K, o.Z, o.G, o.prec);
   }
 };
 static std::mutex g_tune_mu;
 static std::map<TuneKey, int> g_tuned;
-static int g_tune_mode = -1;   // -1: read LSHM_TUNE on first use; 0 off; 1 on
+static int g_tune_mode = -1;   // -1: read LSHM_TUNE on first use; 0: table, else static heuristic (default); 1: table, else time
 static int g_tune_force = -1;  // >= 0: every launch uses this configuration (tests)
 template <class P>
 static int policy_id() { return P::ID; }
@@ -891,15 +901,16 @@ static auto accumulates(const T& p, int) -> decltype(p.accumulate, true) { retur
 template <class T>
 static bool accumulates(const T&, long) { return false; }
 
-// Cache <-> text, one "policy M N K Z groups config" line per shape: lets a process start with the
-// configurations measured earlier (same results bit for bit from run to run, no timing launches).
+// Cache <-> text, one "policy M N K Z groups config [precision]" line per shape: lets a process start with
+// the configurations measured earlier (same results bit for bit from run to run, no timing launches).
 size_t igemm_tuning_export(char* buf, size_t cap) {
   std::lock_guard<std::mutex> lk(g_tune_mu);
   std::string out;
   char line[96];
   for (const auto& kv : g_tuned) {
     const TuneKey& k = kv.first;
-    snprintf(line, sizeof line, "%d %d %d %d %d %d %d\n", k.pol, k.M, k.N, k.K, k.Z, k.G, kv.second);
+    if (k.prec) snprintf(line, sizeof line, "%d %d %d %d %d %d %d %d\n", k.pol, k.M, k.N, k.K, k.Z, k.G, kv.second, k.prec);
+    else snprintf(line, sizeof line, "%d %d %d %d %d %d %d\n", k.pol, k.M, k.N, k.K, k.Z, k.G, kv.second);
     out += line;
   }
   if (buf && cap > 0) {
@@ -916,12 +927,17 @@ int igemm_tuning_import(const char* text) {
   const char* p = text;
   while (*p) {
     TuneKey k;
+    k.prec = 0;
     int cfg = 0, used = 0;
     if (sscanf(p, "%d %d %d %d %d %d %d%n", &k.pol, &k.M, &k.N, &k.K, &k.Z, &k.G, &cfg, &used) == 7 && cfg >= 0 &&
         cfg < kNumConfigs) {
+      p += used;
+      int prec = 0, used2 = 0;  // optional 8th field on the same line
+      const char* q = p;
+      while (*q == ' ' || *q == '\t') ++q;
+      if (*q >= '0' && *q <= '9' && sscanf(q, "%d%n", &prec, &used2) == 1) { k.prec = prec ? 1 : 0; p = q + used2; }
       g_tuned[k] = cfg;
       ++n;
-      p += used;
     }
     while (*p && *p != '\n') ++p;
     if (*p == '\n') ++p;
@@ -933,7 +949,7 @@ void igemm_set_tuning(int mode, int force) {
   std::lock_guard<std::mutex> lk(g_tune_mu);
   g_tune_mode = mode;
   g_tune_force = force;
-  g_tuned.clear();
+  if (mode == 1) g_tuned.clear();  // re-measure; modes 0 / force keep the imported table
 }
 
 template <class P>
@@ -945,20 +961,22 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     if (g_tune_mode < 0) {
+      // timing launches synchronise inside the call and make the choice (hence the summation order) depend on
+      // wall time: opt-in only (LSHM_TUNE=1, lshm_set_tuning(1, -1), bench.py --save-tuning)
       const char* e = getenv("LSHM_TUNE");
-      g_tune_mode = e ? atoi(e) != 0 : 1;
+      g_tune_mode = e ? atoi(e) != 0 : 0;
     }
     mode = g_tune_mode;
     force = g_tune_force;
   }
   if (force >= 0) return launch_idx<P>(force % kNumConfigs, p, p1, M, N, Z, ws, wsf, st, defer);
-  if (!mode) return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st, defer);
-  const TuneKey key{policy_id<P>(), M, N, p.K, Z, p1 ? 2 : 1};
+  const TuneKey key{policy_id<P>(), M, N, p.K, Z, p1 ? 2 : 1, t_matrix_bf16};
   {
     std::lock_guard<std::mutex> lk(g_tune_mu);
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) return launch_idx<P>(it->second, p, p1, M, N, Z, ws, wsf, st, defer);
   }
+  if (!mode) return launch_idx<P>(heuristic, p, p1, M, N, Z, ws, wsf, st, defer);
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   (void)hipStreamIsCapturing(st, &cap);
   if (cap != hipStreamCaptureStatusNone || accumulates(p, 0) || (p1 && accumulates(*p1, 0)))
@@ -972,7 +990,8 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
   static const bool verbose = getenv("LSHM_TUNE_LOG") && atoi(getenv("LSHM_TUNE_LOG")) > 1;
   for (int c = 0; c < kNumConfigs; ++c) {
     if (c < 12 && (c & 1) && M <= 64) continue;
-    if (c >= 12 && (long)cdiv(M, 16) * Z > 65535) continue;  // 16-row tiles: keep grid.x sane, these are for small M
+    if (c >= 20 && M <= 64) continue;
+    if (c >= 12 && c < 16 && (long)cdiv(M, 16) * Z > 65535) continue;  // 16-row tiles: keep grid.x sane, these are for small M
     int rc = launch_idx<P>(c, p, p1, M, N, Z, ws, wsf, st);  // warm
     if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
     (void)hipEventRecord(e0, st);

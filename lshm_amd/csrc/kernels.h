@@ -128,8 +128,17 @@ bool tconv1d_stream_supported(const Conv1dDgradParams& p);
 int tconv1d_stream(const Conv1dDgradParams& p, const Conv1dDgradParams* p1, hipStream_t st);
 // mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
 void igemm_set_tuning(int mode, int force);
-void igemm_set_matrix_precision(int bf16);
-int igemm_matrix_precision();
+// Operand precision of the GEMM-shaped launches made by the calling thread while the scope lives
+// (0: fp32 operands, 1: operands rounded to bf16 at LDS staging).  Engines carry theirs in
+// lshm_step_config.precision, the per-op C ABI in the `_bf16` suffix: no process-wide switch.
+struct MatrixPrecisionScope {
+  int prev;
+  explicit MatrixPrecisionScope(int bf16);
+  ~MatrixPrecisionScope();
+  MatrixPrecisionScope(const MatrixPrecisionScope&) = delete;
+  MatrixPrecisionScope& operator=(const MatrixPrecisionScope&) = delete;
+};
+int igemm_matrix_precision();  // of the calling thread's innermost scope
 size_t igemm_tuning_export(char* buf, size_t cap);  // returns the bytes needed (with the terminating 0)
 int igemm_tuning_import(const char* text);          // returns the entries read
 

@@ -22,6 +22,9 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU: make this rank's device current before anything allocates or launches
+    if torch.cuda.is_available() and torch.cuda.device_count() > 0 and (backend is None or backend == "nccl"):
+        torch.cuda.set_device(device if device is not None else local % torch.cuda.device_count())
     if world == 1:
         return rank, world, local, None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -8,12 +8,27 @@ no eager/PyTorch fallback.
 """
 from __future__ import annotations
 
+import functools
+
 import torch
 
 from . import _lib as L
 
 CONV2D, TCONV2D, CONV1D, TCONV1D = 0, 1, 2, 3
 EPS_KHM = 1e-9
+
+
+def _on_tensor_device(f):
+    """Run `f` with the device of its first tensor argument current: HIP launches go to the current
+    device, whatever device the pointers and the stream belong to."""
+    @functools.wraps(f)
+    def wrapped(*args, **kw):
+        for t in args:
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                with torch.cuda.device(t.device):
+                    return f(*args, **kw)
+        return f(*args, **kw)
+    return wrapped
 
 
 def _geom(kind: int, x: torch.Tensor, w: torch.Tensor):
@@ -53,7 +68,8 @@ class _ConvAct(torch.autograd.Function):
     """y = act(conv(x, w) + b) for the four conv flavours (src/lofar_models.py:73-78,93-98,158-163,178-183)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, kind, act):
+    @_on_tensor_device
+    def forward(ctx, x, w, b, kind, act, bf16=False):
         L.require_device(x, w, b)
         x = x.contiguous()
         w = w.contiguous()
@@ -63,13 +79,14 @@ class _ConvAct(torch.autograd.Function):
         if B > 0:
             nws = lib.lshm_conv_workspace_floats(kind, B, Cin, Cout, Hin, Win)
             ws = L.scratch(x.device, nws)
-            L.check(lib.lshm_conv_fwd(kind, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, Cin, Cout, Hin, Win,
-                                      0, 0, int(act), L.ptr(ws), ws.numel(), L.stream()), "conv_fwd")
+            L.check(L.fn("lshm_conv_fwd", bf16)(kind, L.ptr(x), L.ptr(w), L.ptr(b), L.ptr(y), B, Cin, Cout, Hin, Win,
+                                                0, 0, int(act), L.ptr(ws), ws.numel(), L.stream()), "conv_fwd")
         ctx.save_for_backward(x, w, y)
-        ctx.kind, ctx.act, ctx.has_bias = kind, act, b is not None
+        ctx.kind, ctx.act, ctx.has_bias, ctx.bf16 = kind, act, b is not None, bool(bf16)
         return y
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         lib = L.load()
@@ -85,30 +102,32 @@ class _ConvAct(torch.autograd.Function):
         dx = dw = db = None
         if B == 0:
             return (torch.zeros_like(x), torch.zeros_like(w),
-                    torch.zeros(Cout, device=x.device) if ctx.has_bias else None, None, None)
+                    torch.zeros(Cout, device=x.device) if ctx.has_bias else None, None, None, None)
         nws = lib.lshm_conv_workspace_floats(kind, B, Cin, Cout, Hin, Win)
         ws = L.scratch(x.device, nws)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.check(lib.lshm_conv_dgrad(kind, L.ptr(dz), L.ptr(w), L.ptr(dx), None, B, Cin, Cout, Hin, Win,
-                                        0, 0, L.ptr(ws), ws.numel(), st), "conv_dgrad")
+            L.check(L.fn("lshm_conv_dgrad", ctx.bf16)(kind, L.ptr(dz), L.ptr(w), L.ptr(dx), None, B, Cin, Cout, Hin, Win,
+                                                      0, 0, L.ptr(ws), ws.numel(), st), "conv_dgrad")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db = torch.empty(Cout, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-            L.check(lib.lshm_conv_wgrad(kind, L.ptr(x), L.ptr(dz), L.ptr(dw), L.ptr(db), B, Cin, Cout, Hin,
-                                        Win, 0, 0, L.ptr(ws), ws.numel(), 0, st), "conv_wgrad")
-        return dx, dw, db, None, None
+            L.check(L.fn("lshm_conv_wgrad", ctx.bf16)(kind, L.ptr(x), L.ptr(dz), L.ptr(dw), L.ptr(db), B, Cin, Cout,
+                                                      Hin, Win, 0, 0, L.ptr(ws), ws.numel(), 0, st), "conv_wgrad")
+        return dx, dw, db, None, None, None
 
 
-def conv_act(x, w, b, kind: int, act: bool):
-    return _ConvAct.apply(x, w, b, kind, act)
+def conv_act(x, w, b, kind: int, act: bool, bf16: bool = False):
+    """bf16: operands of the GEMM-shaped layers rounded to bf16 for this call (fp32 accumulation / storage)."""
+    return _ConvAct.apply(x, w, b, kind, act, bf16)
 
 
 class _LinearAct(torch.autograd.Function):
     """y = act(x @ w.T + b) (src/lofar_models.py:80-83,89-91,67-68)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, act):
+    @_on_tensor_device
+    def forward(ctx, x, w, b, act, bf16=False):
         L.require_device(x, w, b)
         if x.dim() != 2:
             raise RuntimeError("linear expects a 2-D input")
@@ -122,13 +141,14 @@ class _LinearAct(torch.autograd.Function):
         if B > 0:
             lib = L.load()
             ws = L.scratch(x.device, lib.lshm_linear_workspace_floats(B, K, N))
-            L.check(lib.lshm_linear_fwd(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), N, B, K, N, int(act),
-                                        L.ptr(ws), ws.numel(), L.stream()), "linear_fwd")
+            L.check(L.fn("lshm_linear_fwd", bf16)(L.ptr(x), K, L.ptr(w), L.ptr(b), L.ptr(y), N, B, K, N, int(act),
+                                                  L.ptr(ws), ws.numel(), L.stream()), "linear_fwd")
         ctx.save_for_backward(x, w, y)
-        ctx.act, ctx.has_bias = act, b is not None
+        ctx.act, ctx.has_bias, ctx.bf16 = act, b is not None, bool(bf16)
         return y
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         lib = L.load()
@@ -137,7 +157,8 @@ class _LinearAct(torch.autograd.Function):
         st = L.stream()
         gy = gy.contiguous()
         if B == 0:
-            return torch.zeros_like(x), torch.zeros_like(w), (torch.zeros(N, device=x.device) if ctx.has_bias else None), None
+            return (torch.zeros_like(x), torch.zeros_like(w),
+                    (torch.zeros(N, device=x.device) if ctx.has_bias else None), None, None)
         if ctx.act:
             dz = torch.empty_like(gy)
             L.check(lib.lshm_elu_bwd(L.ptr(gy), L.ptr(y), L.ptr(dz), dz.numel(), st), "elu_bwd")
@@ -147,20 +168,21 @@ class _LinearAct(torch.autograd.Function):
         ws = L.scratch(x.device, lib.lshm_linear_workspace_floats(B, K, N))
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            L.check(lib.lshm_linear_dgrad(L.ptr(dz), N, L.ptr(w), L.ptr(dx), K, None, 0, B, K, N, L.ptr(ws),
-                                          ws.numel(), st), "linear_dgrad")
+            L.check(L.fn("lshm_linear_dgrad", ctx.bf16)(L.ptr(dz), N, L.ptr(w), L.ptr(dx), K, None, 0, B, K, N,
+                                                        L.ptr(ws), ws.numel(), st), "linear_dgrad")
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             dw = torch.empty_like(w)
             db = torch.empty(N, device=x.device, dtype=torch.float32) if ctx.has_bias else None
-            L.check(lib.lshm_linear_wgrad(L.ptr(x), K, L.ptr(dz), N, L.ptr(dw), L.ptr(db), B, K, N, L.ptr(ws),
-                                          ws.numel(), st), "linear_wgrad")
-        return dx, dw, db, None
+            L.check(L.fn("lshm_linear_wgrad", ctx.bf16)(L.ptr(x), K, L.ptr(dz), N, L.ptr(dw), L.ptr(db), B, K, N,
+                                                        L.ptr(ws), ws.numel(), st), "linear_wgrad")
+        return dx, dw, db, None, None
 
 
-def linear_act(x, w, b, act: bool):
-    return _LinearAct.apply(x, w, b, act)
+def linear_act(x, w, b, act: bool, bf16: bool = False):
+    return _LinearAct.apply(x, w, b, act, bf16)
 
 
+@_on_tensor_device
 def uv_harmonics(scales: torch.Tensor, uv: torch.Tensor) -> torch.Tensor:
     """kron(scales, uv) -> cat(sin, cos) (src/lofar_models.py:60-62).  Not differentiated:
     uv are data and the scales are a plain attribute upstream."""
@@ -179,6 +201,7 @@ class _KHMLoss(torch.autograd.Function):
     """Kmeans.forward (src/lofar_models.py:199-209): loss and both gradients in one fused pass."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, X, M, p, eps):
         L.require_device(X, M)
         X = X.contiguous()
@@ -203,6 +226,7 @@ class _KHMLoss(torch.autograd.Function):
         return (loss[0] * inv).to(torch.float32)
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g):
         dX, dM = ctx.saved_tensors
         return (g * dX if ctx.needs_input_grad[0] else None,
@@ -217,6 +241,7 @@ class _ClusterSim(torch.autograd.Function):
     """Kmeans.cluster_similarity (src/lofar_models.py:214-229)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, M, eps):
         L.require_device(M)
         M = M.contiguous()
@@ -229,6 +254,7 @@ class _ClusterSim(torch.autograd.Function):
         return loss[0].to(torch.float32)
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g):
         (dM,) = ctx.saved_tensors
         return g * dM, None
@@ -242,6 +268,7 @@ class _AugLoss(torch.autograd.Function):
     """augmented_loss(mu, batch_per_bline, batch_size) (src/kharmonic_lofar.py:97-110); shape (1,)."""
 
     @staticmethod
+    @_on_tensor_device
     def forward(ctx, Z, bpb, batch_size):
         L.require_device(Z)
         Z = Z.contiguous()
@@ -255,6 +282,7 @@ class _AugLoss(torch.autograd.Function):
         return loss[:1].to(torch.float32)
 
     @staticmethod
+    @_on_tensor_device
     def backward(ctx, g):
         (dZ,) = ctx.saved_tensors
         return g.reshape(()) * dZ, None, None
@@ -264,6 +292,7 @@ def augmented_loss(mu, batch_per_bline, batch_size):
     return _AugLoss.apply(mu, batch_per_bline, batch_size)
 
 
+@_on_tensor_device
 def khm_offline_partials(X, M, p, eps=EPS_KHM):
     """Numerator (K,D) and denominator (K) of Zhang's recursion (intent of
     Kmeans.offline_update, src/lofar_models.py:231-261)."""
@@ -282,6 +311,7 @@ def khm_offline_partials(X, M, p, eps=EPS_KHM):
     return num, den
 
 
+@_on_tensor_device
 def khm_mean_distances(X, M, p):
     """dist[k] = mean_n ||X_n - M_k||^p (src/evaluate_clustering.py:111-115)."""
     L.require_device(X, M)
@@ -298,6 +328,7 @@ def khm_mean_distances(X, M, p):
     return dist
 
 
+@_on_tensor_device
 def fft_features(r: torch.Tensor, clamp: float = 10.0) -> torch.Tensor:
     """fftn(dim=(2,3), ortho) -> fftshift -> cat(real, imag) -> clamp (Demo.ipynb:169-175)."""
     L.require_device(r)

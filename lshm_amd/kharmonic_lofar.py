@@ -29,6 +29,13 @@ GROUPS = ("net", "netT", "netF", "mod")
 TERM_NAMES = ("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica", "total")
 
 
+def format_terms(terms, epoch: int, i: int, admm: int, use_rica: bool = True) -> str:
+    """The reference's log line (src/kharmonic_lofar.py:176-181): ``'%d %d %d' + ' %f' * n`` with the columns
+    epoch, i, admm, loss0, loss1, loss2, loss3, kdist, aug, sim and, with RICA, the RICA penalty (8 / 7 values)."""
+    cols = [terms[k] for k in TERM_NAMES[:7]] + ([terms["rica"]] if use_rica else [])
+    return ("%d %d %d " % (epoch, i, admm)) + " ".join("%f" % v for v in cols)
+
+
 @dataclass
 class TrainConfig:
     """Script constants of src/kharmonic_lofar.py:25-57,92 (defaults identical)."""
@@ -59,9 +66,13 @@ class TrainConfig:
     reuse_forward: bool = False
     # "bf16": the GEMM-shaped kernels (conv2-5 / tconv0-3, their weight gradients, the dense layers) round
     # their operands to bf16 and multiply on the bf16 matrix cores, fp32 accumulation; storage, the outer
-    # layers, losses and Adam stay fp32 (BASELINE.json configs[2]).  Process-wide switch of the library
-    # (lshm_set_matrix_precision): the last trainer constructed decides.
+    # layers, losses and Adam stay fp32 (BASELINE.json configs[2]).  A property of this trainer's engine
+    # (lshm_step_config.precision): other trainers / modules in the process are unaffected.
     matrix_precision: str = "fp32"
+    # The multiplier update that closes iteration k and the reconstruction terms that open iteration k+1 read
+    # the same seven image-sized arrays; True (default): they share one pass (the closure forward itself is
+    # still recomputed, as upstream does) -- identical results, one 0.67 GB pass less per iteration.
+    share_recon_pass: bool = True
 
 
 class KHarmonicTrainer:
@@ -73,8 +84,9 @@ class KHarmonicTrainer:
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise RuntimeError("KHarmonicTrainer needs a HIP device; there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.lib = L.load()
-        self.lib.lshm_set_matrix_precision(1 if cfg.matrix_precision == "bf16" else 0)
         self.pg = process_group
         self.world = 1
         if process_group is not None:
@@ -94,9 +106,13 @@ class KHarmonicTrainer:
         for i, s in enumerate(cfg.harmonic_scales):
             sc.scales[i] = s
         sc.world = self.world
+        sc.precision = L.PRECISION_BF16_OPERANDS if cfg.matrix_precision == "bf16" else L.PRECISION_F32
         self._sc = sc
         h = C.c_void_p()
-        L.check(self.lib.lshm_engine_create(C.byref(sc), C.byref(h)), "engine_create")
+        # the engine's side stream and events are created on the device that is current now, and every
+        # launch of this trainer goes to that device whatever the caller's current device is
+        with L.on_device(self.device):
+            L.check(self.lib.lshm_engine_create(C.byref(sc), C.byref(h)), "engine_create")
         self._h = h
         n = self.lib.lshm_engine_param_count(h)
         self.nparams = n
@@ -126,6 +142,11 @@ class KHarmonicTrainer:
         self.y = [torch.zeros(self.x.numel(), device=dev) for _ in range(3)]
         self._graph = None
         self._saved_forward = False  # the workspace holds the forward of the current params / x / uv
+        self._recon_ready = False    # ... and the reconstruction terms of the next closure (share_recon_pass)
+        self._opt_generation = 0     # bumped by set_train_groups: optimisers built before it are stale
+
+    def _stream(self):
+        return L.stream(self.device)
 
     def __del__(self):
         try:
@@ -144,23 +165,46 @@ class KHarmonicTrainer:
         return (self.params if flat is None else flat)[off:off + n].view(shape)
 
     def set_train_groups(self, groups: Iterable[str]):
+        """Choose the parameter groups the optimiser updates (upstream edits ``params`` at :86-90 and builds a
+        new optimiser).  Same semantics here: a parameter outside the selection never changes, and the
+        optimiser state starts afresh (Adam moments and step count zeroed; LBFGS optimisers made before this
+        call refuse to step -- call make_lbfgs again)."""
         groups = tuple(groups)
         for g in groups:
             if g not in GROUPS:
                 raise ValueError(f"unknown parameter group {g!r}")
         self.train_groups = groups
+        # contiguous arena ranges of the selected groups (tensors of a group are adjacent: net, netT, netF, mod)
+        ranges = []
+        for name, (off, shape) in sorted(self.layout.items(), key=lambda kv: kv[1][0]):
+            if name.split(".", 1)[0] not in groups:
+                continue
+            n = 1
+            for d in shape:
+                n *= d
+            end = off + (n + 3) // 4 * 4
+            if ranges and ranges[-1][1] == off:
+                ranges[-1][1] = end
+            else:
+                ranges.append([off, end])
+        self._ranges = [(a, min(b, self.nparams)) for a, b in ranges]
+        if hasattr(self, "exp_avg"):
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            self.step_count.zero_()
+        self._opt_generation = getattr(self, "_opt_generation", 0) + 1
         if set(groups) == set(GROUPS):
             self._mask = None
             return
         m = torch.zeros(self.nparams, device=self.device)
-        for name in self.layout:
-            if name.split(".", 1)[0] in groups:
-                self.view(name, m).fill_(1.0)
+        for a, b in self._ranges:
+            m[a:b] = 1.0
         self._mask = m
 
     def load_state_dicts(self, net=None, netT=None, netF=None, mod=None):
         """Accepts the reference's four state_dicts (keys 'conv0.weight' ... / 'M')."""
         self._saved_forward = False
+        self._recon_ready = False
         with torch.no_grad():
             for prefix, sd in (("net", net), ("netT", netT), ("netF", netF), ("mod", mod)):
                 if sd is None:
@@ -212,46 +256,61 @@ class KHarmonicTrainer:
         for t in self.y:
             t.zero_()
         self._saved_forward = False
+        self._recon_ready = False
 
     def invalidate_forward(self):
-        """Call after changing parameters or inputs behind the trainer's back (e.g. through ``view``) when
-        ``reuse_forward`` is on: the next iteration recomputes its closure forward."""
+        """Call after changing parameters, inputs or multipliers behind the trainer's back (e.g. through
+        ``view``): the next iteration recomputes its closure forward and its reconstruction terms."""
         self._saved_forward = False
+        self._recon_ready = False
 
     # ------------------------------------------------------------------ one iteration
     def _closure_fwd_bwd(self):
         P = L.ptr
-        if self.cfg.reuse_forward and self._saved_forward and self._graph is None:
-            L.check(self.lib.lshm_engine_backward_saved(
-                self._h, P(self.params), P(self.grads), P(self.x), P(self.y[0]), P(self.y[1]), P(self.y[2]),
-                P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_backward_saved")
-        else:
-            L.check(self.lib.lshm_engine_forward_backward(
-                self._h, P(self.params), P(self.grads), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]),
-                P(self.y[2]), P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_forward_backward")
-        self._saved_forward = False  # whatever follows (optimiser, line search) moves the parameters
-        if self.world > 1:
-            from .dist import allreduce_closure
-            allreduce_closure(self.grads, self.terms, self.pg)
-        if self._mask is not None:
-            self.grads.mul_(self._mask)
+        with L.on_device(self.device):
+            if self.cfg.reuse_forward and self._saved_forward and self._graph is None:
+                L.check(self.lib.lshm_engine_backward_saved(
+                    self._h, P(self.params), P(self.grads), P(self.x), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+                    P(self.terms), P(self.ws), self.ws_floats, self._stream()), "engine_backward_saved")
+            else:
+                flags = L.STEP_RECON_READY if (self._recon_ready and self._saved_forward) else 0
+                L.check(self.lib.lshm_engine_forward_backward_ex(
+                    self._h, P(self.params), P(self.grads), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]),
+                    P(self.y[2]), P(self.terms), P(self.ws), self.ws_floats, flags, self._stream()),
+                    "engine_forward_backward")
+            self._saved_forward = False  # whatever follows (optimiser, line search) moves the parameters
+            self._recon_ready = False
+            if self.world > 1:
+                from .dist import allreduce_closure
+                allreduce_closure(self.grads, self.terms, self.pg)
+            if self._mask is not None:
+                self.grads.mul_(self._mask)
 
     def _adam(self):
+        """torch.optim.Adam over the selected groups only (frozen ranges are not touched at all: a parameter
+        outside the optimiser's list never moves upstream, src/kharmonic_lofar.py:86-92)."""
         c = self.cfg
-        self.step_count.add_(1)
         P = L.ptr
-        L.check(self.lib.lshm_adam_step_flat(P(self.params), P(self.grads), P(self.exp_avg), P(self.exp_avg_sq),
-                                             self.nparams, c.lr, c.betas[0], c.betas[1], c.adam_eps,
-                                             P(self.step_count), 0, 1.0, L.stream()), "adam")
+        with L.on_device(self.device):
+            self.step_count.add_(1)
+            for a, b in self._ranges:
+                L.check(self.lib.lshm_adam_step_flat(P(self.params[a:b]), P(self.grads[a:b]), P(self.exp_avg[a:b]),
+                                                     P(self.exp_avg_sq[a:b]), b - a, c.lr, c.betas[0], c.betas[1],
+                                                     c.adam_eps, P(self.step_count), 0, 1.0, self._stream()), "adam")
 
-    def _multipliers(self):
+    def _multipliers(self, prepare_next: Optional[bool] = None):
+        """No-grad forward + y_k += rho r_k (src/kharmonic_lofar.py:187-202).  prepare_next: the same pass also
+        leaves the reconstruction terms of the next closure (default: cfg.share_recon_pass / reuse_forward)."""
         P = L.ptr
-        # with reuse_forward the same pass also prepares the reconstruction terms of the next closure
-        fn = (self.lib.lshm_engine_multiplier_update_next if self.cfg.reuse_forward and self._graph is None
-              else self.lib.lshm_engine_multiplier_update)
-        L.check(fn(self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
-                   P(self.ws), self.ws_floats, L.stream()), "engine_multiplier_update")
+        if prepare_next is None:
+            prepare_next = (self.cfg.share_recon_pass or self.cfg.reuse_forward)
+        prepare_next = bool(prepare_next) and self._graph is None
+        fn = self.lib.lshm_engine_multiplier_update_next if prepare_next else self.lib.lshm_engine_multiplier_update
+        with L.on_device(self.device):
+            L.check(fn(self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+                       P(self.ws), self.ws_floats, self._stream()), "engine_multiplier_update")
         self._saved_forward = True  # forward of the parameters the next closure will see
+        self._recon_ready = prepare_next
 
     def _step_impl(self):
         self._closure_fwd_bwd()
@@ -262,24 +321,34 @@ class KHarmonicTrainer:
         """Capture one iteration in a HIP graph (state is restored afterwards; a replayed iteration
         always recomputes its closure forward)."""
         self._saved_forward = False
-        snap = [t.clone() for t in (self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y)]
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):
-                self._step_impl()
-        torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._step_impl()
-        for t, v in zip((self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y), snap):
-            t.copy_(v)
-        self._graph = g
+        self._recon_ready = False
+        with L.on_device(self.device):
+            snap = [t.clone() for t in (self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y)]
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(warmup):
+                    self._step_impl()
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            self._graph = g          # a captured iteration never relies on state left by an earlier call
+            try:
+                self._saved_forward = self._recon_ready = False
+                with torch.cuda.graph(g):
+                    self._step_impl()
+            except Exception:
+                self._graph = None
+                raise
+            finally:
+                for t, v in zip((self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y), snap):
+                    t.copy_(v)
+                self._saved_forward = self._recon_ready = False
 
     def step(self):
         """One ADMM iteration.  Loss terms of the closure stay on the device (``read_terms``)."""
         if self._graph is not None:
             self._graph.replay()
+            self._saved_forward = self._recon_ready = False
         else:
             self._step_impl()
 
@@ -290,8 +359,12 @@ class KHarmonicTrainer:
         from .lbfgsnew import LBFGSNew
         self._flat_param = torch.nn.Parameter(self.params, requires_grad=True)
         self._flat_param.grad = self.grads
-        return LBFGSNew([self._flat_param], history_size=history_size, max_iter=max_iter,
-                        line_search_fn=line_search_fn, batch_mode=batch_mode, **kw)
+        opt = LBFGSNew([self._flat_param], history_size=history_size, max_iter=max_iter,
+                       line_search_fn=line_search_fn, batch_mode=batch_mode, **kw)
+        # frozen groups enter as zero gradient coordinates; curvature pairs gathered under another selection
+        # would move them, so an optimiser is tied to the selection it was made under
+        opt._lshm_generation = self._opt_generation
+        return opt
 
     def lbfgs_closure(self):
         """Closure protocol of the upstream script (:132-182): gradients only when autograd is enabled
@@ -300,20 +373,25 @@ class KHarmonicTrainer:
             self._closure_fwd_bwd()
         else:
             self._saved_forward = False  # trial point of the line search
+            self._recon_ready = False
             P = L.ptr
-            L.check(self.lib.lshm_engine_forward_loss(
-                self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
-                P(self.terms), P(self.ws), self.ws_floats, L.stream()), "engine_forward_loss")
-            if self.world > 1:
-                import torch.distributed as dist
-                dist.all_reduce(self.terms, group=self.pg)
+            with L.on_device(self.device):
+                L.check(self.lib.lshm_engine_forward_loss(
+                    self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+                    P(self.terms), P(self.ws), self.ws_floats, self._stream()), "engine_forward_loss")
+                if self.world > 1:
+                    import torch.distributed as dist
+                    dist.all_reduce(self.terms, group=self.pg)
         return self.terms[8]
 
     def step_lbfgs(self, opt):
         """One ADMM iteration with the LBFGS update instead of Adam."""
+        if getattr(opt, "_lshm_generation", self._opt_generation) != self._opt_generation:
+            raise RuntimeError("this LBFGS optimiser was made before set_train_groups(); call make_lbfgs() again")
         if self._flat_param.grad is not self.grads:
             self._flat_param.grad = self.grads
-        opt.step(self.lbfgs_closure)
+        with L.on_device(self.device):
+            opt.step(self.lbfgs_closure)
         self._multipliers()
 
     def closure_only(self):
@@ -321,15 +399,16 @@ class KHarmonicTrainer:
         self._closure_fwd_bwd()
 
     def read_terms(self) -> Dict[str, float]:
-        """The reference's log line (src/kharmonic_lofar.py:176-181) as a dict: one
-        device->host copy of nine doubles."""
-        t = self.terms[:9].cpu().tolist()
-        return dict(zip(TERM_NAMES, t))
+        """The reference's log line (src/kharmonic_lofar.py:176-181) as a dict: one device->host copy of ten
+        doubles.  ``nonfinite`` counts the logged terms that are NaN or infinite (job-wide under data
+        parallelism): the cheap divergence check upstream leaves to the reader of the log (README.md:29)."""
+        t = self.terms[:10].cpu().tolist()
+        d = dict(zip(TERM_NAMES, t[:9]))
+        d["nonfinite"] = t[9]
+        return d
 
     def format_log(self, epoch: int, i: int, admm: int) -> str:
-        t = self.read_terms()
-        cols = [t[k] for k in TERM_NAMES[:7]] + ([t["rica"]] if self.cfg.use_rica else [])
-        return ("%d %d %d " % (epoch, i, admm)) + " ".join("%f" % v for v in cols)
+        return format_terms(self.read_terms(), epoch, i, admm, self.cfg.use_rica)
 
     # ------------------------------------------------------------------ inference helper
     def encode(self, want_recon: bool = False):
@@ -339,7 +418,9 @@ class KHarmonicTrainer:
         Mu = torch.empty((self.B, c.L + 2 * c.Lt), device=self.device)
         outs = [torch.empty_like(self.x) for _ in range(3)] if want_recon else [None] * 3
         P = L.ptr
-        L.check(self.lib.lshm_engine_encode(self._h, P(self.params), P(self.x), P(self.uv), P(Mu), P(outs[0]),
-                                            P(outs[1]), P(outs[2]), P(self.ws), self.ws_floats, L.stream()),
-                "engine_encode")
+        self._recon_ready = False
+        with L.on_device(self.device):
+            L.check(self.lib.lshm_engine_encode(self._h, P(self.params), P(self.x), P(self.uv), P(Mu), P(outs[0]),
+                                                P(outs[1]), P(outs[2]), P(self.ws), self.ws_floats, self._stream()),
+                    "engine_encode")
         return (Mu, *outs) if want_recon else Mu

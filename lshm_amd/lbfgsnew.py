@@ -54,21 +54,25 @@ class _HipVec:
 
     def dot(self, a, b) -> float:
         L = self.L
-        L.check(self.lib.lshm_dot_flat(L.ptr(a), L.ptr(b), a.numel(), L.ptr(self.out), L.ptr(self.ws), L.stream()))
+        with L.on_device(a.device):
+            L.check(self.lib.lshm_dot_flat(L.ptr(a), L.ptr(b), a.numel(), L.ptr(self.out), L.ptr(self.ws), L.stream(a.device)))
         return float(self.out.item())
 
     def asum(self, a) -> float:
         L = self.L
-        L.check(self.lib.lshm_asum_flat(L.ptr(a), a.numel(), L.ptr(self.out), L.ptr(self.ws), L.stream()))
+        with L.on_device(a.device):
+            L.check(self.lib.lshm_asum_flat(L.ptr(a), a.numel(), L.ptr(self.out), L.ptr(self.ws), L.stream(a.device)))
         return float(self.out.item())
 
     def axpy(self, y, alpha, x):
         L = self.L
-        L.check(self.lib.lshm_axpy_flat(L.ptr(y), L.ptr(x), float(alpha), y.numel(), L.stream()))
+        with L.on_device(y.device):
+            L.check(self.lib.lshm_axpy_flat(L.ptr(y), L.ptr(x), float(alpha), y.numel(), L.stream(y.device)))
 
     def scale(self, x, alpha):
         L = self.L
-        L.check(self.lib.lshm_scale_flat(L.ptr(x), float(alpha), x.numel(), L.stream()))
+        with L.on_device(x.device):
+            L.check(self.lib.lshm_scale_flat(L.ptr(x), float(alpha), x.numel(), L.stream(x.device)))
 
 
 class LBFGSNew(Optimizer):

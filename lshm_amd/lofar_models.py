@@ -23,6 +23,9 @@ class _CascadeAE(nn.Module):
     """Shared body of the 2-D and 1-D autoencoders (they differ only in the conv flavour)."""
 
     _ndim = 2
+    # extension: "bf16" rounds the operands of this module's GEMM-shaped layers to bf16 (fp32 accumulation and
+    # storage); a per-module attribute, passed per call to the kernels -- nothing process-wide
+    matrix_precision = "fp32"
 
     def __init__(self, latent_dim=128, channels=3, harmonic_scales=None, rica=False):
         super().__init__()
@@ -55,9 +58,8 @@ class _CascadeAE(nn.Module):
             setattr(self, f"tconv{i}", tconv(widths[6 - i], widths[5 - i]))
 
     # -- helpers ---------------------------------------------------------
-    @staticmethod
-    def _lin(layer, x, act=True):
-        return Fh.linear_act(x, layer.weight, layer.bias, act)
+    def _lin(self, layer, x, act=True):
+        return Fh.linear_act(x, layer.weight, layer.bias, act, self.matrix_precision == "bf16")
 
     def _harmonics(self, uv):
         return Fh.uv_harmonics(self.harmonic_scales, uv)
@@ -76,7 +78,7 @@ class _CascadeAE(nn.Module):
         h = x
         for i in range(6):
             layer = getattr(self, f"conv{i}")
-            h = Fh.conv_act(h, layer.weight, layer.bias, self._kinds[0], True)
+            h = Fh.conv_act(h, layer.weight, layer.bias, self._kinds[0], True, self.matrix_precision == "bf16")
         h = torch.flatten(h, start_dim=1)
         u = self._lin(self.fcuv1, uv)
         return self._lin(self.fc1, torch.cat((h, u), dim=1))
@@ -87,7 +89,7 @@ class _CascadeAE(nn.Module):
         h = torch.reshape(h, (-1,) + self._bottleneck)
         for i in range(6):
             layer = getattr(self, f"tconv{i}")
-            h = Fh.conv_act(h, layer.weight, layer.bias, self._kinds[1], i < 5)
+            h = Fh.conv_act(h, layer.weight, layer.bias, self._kinds[1], i < 5, self.matrix_precision == "bf16")
         return h
 
 

@@ -46,9 +46,10 @@ def patches_from_visibilities(vis: torch.Tensor, scale: torch.Tensor, patch_size
     y = torch.empty((px * py * nb, 4, P, P), device=vis.device, dtype=torch.float32)
     ms = torch.empty(2, device=vis.device, dtype=torch.float64)
     ws = torch.empty(lib.lshm_patches_workspace_floats(), device=vis.device, dtype=torch.float32)
-    L.check(lib.lshm_patches_from_vis(L.ptr(vis), L.ptr(scale), nb, ntime, nfreq, P, float(clamp),
-                                      int(normalize_data), L.ptr(y), L.ptr(ms), L.ptr(ws), L.stream()),
-            "patches_from_vis")
+    with L.on_device(vis.device):
+        L.check(lib.lshm_patches_from_vis(L.ptr(vis), L.ptr(scale), nb, ntime, nfreq, P, float(clamp),
+                                          int(normalize_data), L.ptr(y), L.ptr(ms), L.ptr(ws), L.stream()),
+                "patches_from_vis")
     return px, py, y, ms
 
 

@@ -30,7 +30,10 @@ class RicaDictionary:
     the hyper-parameters ``lambda1`` (:43), ``eta`` (:44)."""
 
     def __init__(self, L: int, M: int = 256, lambda1: float = 0.1, eta: float = 0.1,
-                 device: str = "cuda", A: Optional[torch.Tensor] = None):
+                 device: str = "cuda", A: Optional[torch.Tensor] = None, matrix_precision: str = "fp32"):
+        if matrix_precision not in ("fp32", "bf16"):
+            raise ValueError("matrix_precision must be 'fp32' or 'bf16'")
+        self.bf16 = matrix_precision == "bf16"  # operands of this object's GEMMs rounded to bf16 (per call)
         self.lib = L_.load()
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -72,9 +75,10 @@ class RicaDictionary:
             if St.grad is None:
                 St.grad = torch.empty_like(St)
             grad = St.grad
-        L_.check(self.lib.lshm_rica_loss_grad(L_.ptr(Xt), L_.ptr(self.A), L_.ptr(St), B, self.L, self.M,
-                                              self.lambda1, L_.ptr(self._loss), L_.ptr(grad), L_.ptr(ws),
-                                              ws.numel(), L_.stream()), "rica_loss_grad")
+        with L_.on_device(self.device):
+            L_.check(L_.fn("lshm_rica_loss_grad", self.bf16)(L_.ptr(Xt), L_.ptr(self.A), L_.ptr(St), B, self.L, self.M,
+                                                             self.lambda1, L_.ptr(self._loss), L_.ptr(grad), L_.ptr(ws),
+                                                             ws.numel(), L_.stream()), "rica_loss_grad")
         return self._loss[0].clone()
 
     def closure_for(self, St: torch.Tensor):
@@ -106,9 +110,10 @@ class RicaDictionary:
         Xt = self._Xt
         B = Xt.shape[0]
         ws = self._workspace(B)
-        L_.check(self.lib.lshm_rica_update_dictionary(L_.ptr(Xt), L_.ptr(self.A), L_.ptr(St), B, self.L, self.M,
-                                                      self.eta, L_.ptr(self._norm), L_.ptr(ws), ws.numel(),
-                                                      L_.stream()), "rica_update_dictionary")
+        with L_.on_device(self.device):
+            L_.check(L_.fn("lshm_rica_update_dictionary", self.bf16)(L_.ptr(Xt), L_.ptr(self.A), L_.ptr(St), B, self.L,
+                                                                     self.M, self.eta, L_.ptr(self._norm), L_.ptr(ws),
+                                                                     ws.numel(), L_.stream()), "rica_update_dictionary")
         return math.sqrt(float(self._norm[0])) / B
 
     def iteration(self, x: torch.Tensor, S0: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, float, float]:

@@ -121,10 +121,17 @@ def test_tuning_table_roundtrip_without_device():
     buf = C.create_string_buffer(n)
     lib.lshm_tuning_export(buf, n)
     assert buf.value.decode().splitlines() == ["0 16384 48 384 1 1 10", "3 262144 12 32 1 2 9", "6 16 784 256 1 1 8"]
+    # a fourth, optional field carries the operand precision the entry was measured with
+    assert lib.lshm_tuning_import(b"6 16 784 256 1 1 12 1\n") == 1
+    n = lib.lshm_tuning_export(None, 0)
+    buf = C.create_string_buffer(n)
+    lib.lshm_tuning_export(buf, n)
+    assert "6 16 784 256 1 1 12 1" in buf.value.decode().splitlines()
     lib.lshm_set_tuning(1, -1)
     with open(_lib.TUNE_FILE, "rb") as f:
         table = f.read()
     assert lib.lshm_tuning_import(table) == len(table.decode().strip().splitlines())
+    lib.lshm_set_tuning(0, -1)  # back to the default: table, then static heuristic, no timing launches
 
 
 def test_header_is_plain_c():
@@ -145,3 +152,15 @@ def test_header_is_plain_c():
         inc = os.path.join(root, "include")
         subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, src], check=True)
         subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", "-I", inc, src], check=True)
+
+
+def test_log_line_columns_without_device():
+    """src/kharmonic_lofar.py:176-181: '%d %d %d' then loss0 loss1 loss2 loss3 kdist aug sim [rica], '%f' each."""
+    from lshm_amd.kharmonic_lofar import TERM_NAMES, format_terms
+    t = {k: float(i + 1) / 8 for i, k in enumerate(TERM_NAMES)}
+    assert format_terms(t, 1, 2, 3, True) == "1 2 3 " + " ".join("%f" % ((i + 1) / 8) for i in range(8))
+    assert format_terms(t, 1, 2, 3, False) == "1 2 3 " + " ".join("%f" % ((i + 1) / 8) for i in range(7))
+    # upstream's own format strings
+    vals = tuple((i + 1) / 8 for i in range(8))
+    assert format_terms(t, 1, 2, 3, True) == "%d %d %d %f %f %f %f %f %f %f %f" % ((1, 2, 3) + vals)
+    assert format_terms(t, 1, 2, 3, False) == "%d %d %d %f %f %f %f %f %f %f" % ((1, 2, 3) + vals[:7])

@@ -35,13 +35,13 @@ def test_conv_layer_fwd_bwd_vs_golden(kind, i):
     _check_conv_layer(kind, i)
 
 
-@pytest.mark.parametrize("cfg", range(16))
+@pytest.mark.parametrize("cfg", range(22))
 def test_every_gemm_tile_configuration(cfg):
-    """The implicit-GEMM launcher autotunes over 16 (M tile, K chunk, split-K / K-over-wavefronts) configurations; pin each
+    """The implicit-GEMM launcher chooses among 22 (M tile, K chunk, split-K / K-over-wavefronts) configurations; pin each
     one in turn so that whichever the tuner picks on a given box has been checked against the goldens."""
     from lshm_amd import _lib
     lib = _lib.load()
-    lib.lshm_set_tuning(1, cfg)
+    lib.lshm_set_tuning(0, cfg)
     try:
         for kind in KINDS:
             for i in (1, 3, 5):
@@ -49,7 +49,7 @@ def test_every_gemm_tile_configuration(cfg):
         test_linear_vs_torch(5, 784, 224, True)
         test_linear_vs_torch(64, 32, 768, False)
     finally:
-        lib.lshm_set_tuning(1, -1)
+        lib.lshm_set_tuning(0, -1)
 
 
 def _check_conv_layer(kind, i):
@@ -472,9 +472,9 @@ def _bf16_round(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 3, 6, 9, 12, 13, 14, 15])
+@pytest.mark.parametrize("cfg", [-1, 0, 3, 6, 9, 12, 13, 14, 15, 16, 19, 20])
 def test_bf16_matrix_operands(cfg):
-    """lshm_set_matrix_precision(1), BASELINE configs[2]: the GEMM-shaped kernels round their operands to bf16
+    """The `_bf16` entry points, BASELINE configs[2]: the GEMM-shaped kernels round their operands to bf16
     (nearest even) and accumulate in fp32.  Checked against fp64 products of the bf16-rounded operands
     (that is the exact result up to fp32 summation), tight, and against the fp32 result, loose -- and the
     difference from the fp32 result must be visible, i.e. the switch really reached the kernel."""
@@ -487,26 +487,25 @@ def test_bf16_matrix_operands(cfg):
     b = O.closed_form((N,), "bf:b", 0.1, 0.53).to(DEV)
     gy = O.closed_form((B, N), "bf:gy", 1.0, 0.91).to(DEV)
 
-    def run():
+    def run(bf16=False):
         xs, ws, bs = (t.clone().requires_grad_(True) for t in (x, w, b))
-        y = Fh.linear_act(xs, ws, bs, False)
+        y = Fh.linear_act(xs, ws, bs, False, bf16)
         (y * gy).sum().backward()
         return y.detach(), xs.grad, ws.grad, bs.grad
     y32, dx32, dw32, db32 = run()
-    lib.lshm_set_tuning(1, cfg)
-    lib.lshm_set_matrix_precision(1)
+    lib.lshm_set_tuning(0, cfg)
     try:
-        assert lib.lshm_get_matrix_precision() == 1
-        y16, dx16, dw16, db16 = run()
+        y16, dx16, dw16, db16 = run(True)
         # a convolution through the same template: conv2d layer 3 (24 -> 48 channels at 16 x 16)
         xc = O.closed_form((2, 24, 16, 16), "bf:xc", 1.0, 0.2113).to(DEV)
         wc = O.closed_form((48, 24, 4, 4), "bf:wc", (3.0 / 384) ** 0.5).to(DEV)
         bc = O.closed_form((48,), "bf:bc", 0.05).to(DEV)
-        yc16 = Fh.conv_act(xc, wc, bc, KINDS["conv2d"], False)
+        yc16 = Fh.conv_act(xc, wc, bc, KINDS["conv2d"], False, True)
+        yc32 = Fh.conv_act(xc, wc, bc, KINDS["conv2d"], False)   # the precision is per call: fp32 right after
     finally:
-        lib.lshm_set_matrix_precision(0)
-        lib.lshm_set_tuning(1, -1)
-    assert lib.lshm_get_matrix_precision() == 0
+        lib.lshm_set_tuning(0, -1)
+    assert rel_err(yc32, torch.nn.functional.conv2d(xc.double().cpu(), wc.double().cpu(), bc.double().cpu(),
+                                                    stride=2, padding=1)) < 1e-6
     xd, wd, gd = _bf16_round(x).double().cpu(), _bf16_round(w).double().cpu(), _bf16_round(gy).double().cpu()
     assert rel_err(y16, xd @ wd.t() + b.double().cpu()) < 5e-6
     assert rel_err(dx16, gd @ wd) < 5e-6

@@ -88,22 +88,17 @@ def test_full_size_properties():
 
 
 def test_closure_with_bf16_matrix_operands():
-    """lshm_set_matrix_precision(1) also covers the dictionary GEMMs: loss and code gradient within bf16
+    """RicaDictionary(matrix_precision="bf16") runs the dictionary GEMMs on bf16 operands: loss and code gradient within bf16
     accuracy of the fp32 oracle, the 1-norm sub-gradient untouched."""
     from lshm_amd import _lib
     from lshm_amd.rica_lofar import RicaDictionary
     L, M, B = 4 * 16 * 16, 32, 24
     X, A, S0 = O.rica_closed_form(L, M, B)
     want_l, want_g = O.rica_loss_grad(X.double(), A.double(), S0.double(), 0.1)
-    rd = RicaDictionary(L, M, lambda1=0.1, eta=0.1, device=DEV, A=A)
+    rd = RicaDictionary(L, M, lambda1=0.1, eta=0.1, device=DEV, A=A, matrix_precision="bf16")
     rd.set_minibatch(X.t().contiguous())
     St = S0.t().contiguous().to(DEV).requires_grad_(True)
-    lib = _lib.load()
-    lib.lshm_set_matrix_precision(1)
-    try:
-        got = float(rd.loss(St, True))
-    finally:
-        lib.lshm_set_matrix_precision(0)
+    got = float(rd.loss(St, True))
     assert abs(got - float(want_l)) <= 2e-2 * float(want_l)
     g = St.grad.t().cpu().double()
     assert 1e-6 < float((g - want_g).norm() / want_g.norm()) < 2e-2

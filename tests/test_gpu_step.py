@@ -380,16 +380,15 @@ def test_reuse_forward_is_bitwise_the_same_trajectory():
 def test_bf16_matrix_precision_step_vs_fp32_oracle():
     """BASELINE configs[2] (TrainConfig.matrix_precision='bf16'): bf16 operands in the GEMM-shaped layers.
     Gate of SURVEY 8(c): total loss within rtol 2e-2 of the fp32 reference; here also every logged term, the
-    gradients (3e-2 of the whole vector's norm) and three Adam iterations; and the fp32 mode is restored for later tests."""
-    from lshm_amd import KHarmonicTrainer, TrainConfig, _lib
+    gradients (3e-2 of the whole vector's norm) and three Adam iterations."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
     B, K, bpb, bs = 4, 5, 2, 2
     ocfg = O.StepConfig(K=K, bpb=bpb, batch_size=bs)
     params, M = O.make_params(ocfg)
     x, uv = O.closed_form_inputs(B, 4)
-    try:
+    if True:
         tr = KHarmonicTrainer(TrainConfig(Kc=K, matrix_precision="bf16"), batch=B, batch_per_bline=bpb, default_batch=bs,
                               device=DEV)
-        assert _lib.load().lshm_get_matrix_precision() == 1
         tr.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
         tr.new_minibatch(x.to(DEV), uv.to(DEV))
         tr.closure_only()
@@ -420,5 +419,183 @@ def test_bf16_matrix_precision_step_vs_fp32_oracle():
         t = tr.read_terms()
         for n, ref in zip(("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica"), ref_terms):
             assert abs(t[n] - ref) <= 2e-2 * abs(ref) + 1e-7, n
+
+
+def test_precision_is_per_engine_not_per_process():
+    """Two trainers of different matrix precision in one process do not influence each other: the fp32
+    trainer's step is bit-identical whether or not a bf16 trainer was built and stepped in between
+    (lshm_step_config.precision; there is no process-wide switch)."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    x, uv = O.closed_form_inputs(4, 4)
+
+    def fp32_run(with_bf16_neighbour):
+        tr = KHarmonicTrainer(TrainConfig(Kc=5), batch=4, batch_per_bline=2, default_batch=2, device=DEV)
+        tr.init_parameters(seed=5)
+        tr.new_minibatch(x.to(DEV), uv.to(DEV))
+        other = None
+        if with_bf16_neighbour:
+            other = KHarmonicTrainer(TrainConfig(Kc=5, matrix_precision="bf16"), batch=4, batch_per_bline=2,
+                                     default_batch=2, device=DEV)
+            other.init_parameters(seed=5)
+            other.new_minibatch(x.to(DEV), uv.to(DEV))
+        for _ in range(2):
+            tr.step()
+            if other is not None:
+                other.step()
+        torch.cuda.synchronize()
+        return tr.params.clone(), (other.params.clone() if other is not None else None)
+    a, _ = fp32_run(False)
+    b, o = fp32_run(True)
+    assert torch.equal(a, b)
+    assert not torch.equal(b, o)  # and the bf16 neighbour really ran in bf16
+
+
+def test_shared_reconstruction_pass_is_bitwise_the_same_trajectory():
+    """TrainConfig.share_recon_pass (default): the multiplier update of iteration k also leaves the
+    reconstruction terms of iteration k+1 (one pass over the seven image-sized arrays instead of two);
+    the forward is still recomputed.  Same parameters, multipliers, Adam moments and logged terms, bit for
+    bit, as with two separate passes -- across a new minibatch and a parameter reload too."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    out = []
+    for share in (False, True):
+        tr = KHarmonicTrainer(TrainConfig(Kc=5, share_recon_pass=share), batch=4, batch_per_bline=2, default_batch=2,
+                              device=DEV)
+        tr.init_parameters(seed=3)
+        x, uv = O.closed_form_inputs(4, 4)
+        tr.new_minibatch(x.to(DEV), uv.to(DEV))
+        terms = []
+        for it in range(4):
+            tr.step()
+            terms.append(tr.terms[:10].clone())
+        tr.new_minibatch((0.5 * x).to(DEV), uv.to(DEV))
+        for it in range(2):
+            tr.step()
+            terms.append(tr.terms[:10].clone())
+        sd = tr.state_dicts()
+        tr.load_state_dicts(sd["net"], sd["netT"], sd["netF"], sd["mod"])  # invalidates what the last pass left
+        tr.y[0].mul_(0.5)
+        tr.invalidate_forward()
+        tr.step()
+        terms.append(tr.terms[:10].clone())
+        out.append((tr.params.clone(), [t.clone() for t in tr.y], tr.exp_avg.clone(), torch.stack(terms)))
+    a, b = out
+    assert torch.equal(a[0], b[0])
+    assert all(torch.equal(p, q) for p, q in zip(a[1], b[1]))
+    assert torch.equal(a[2], b[2])
+    assert torch.equal(a[3], b[3])
+
+
+def test_switching_train_groups_keeps_frozen_tensors_bit_identical():
+    """README.md:27-30 alternates the parameter groups by hand; upstream does it by building a new optimiser
+    over another parameter list, so a tensor outside the list never moves and the optimiser state starts
+    afresh.  Switch groups mid-run: everything frozen stays bit-identical over several steps (stale Adam
+    moments must not leak), the trained group moves, and its first step after the switch equals the first
+    step of a fresh Adam."""
+    tr, *_ = _trainer(4, 4, 2, 2, groups=("net",))
+    for _ in range(3):
+        tr.step()
+    snap = {n: tr.view(n).clone() for n in tr.layout}
+    tr.set_train_groups(("netT", "mod"))
+    assert float(tr.exp_avg.abs().sum()) == 0.0 and int(tr.step_count.item()) == 0
+    for _ in range(3):
+        tr.step()
+    for n in tr.layout:
+        moved = not torch.equal(snap[n], tr.view(n))
+        assert moved == (n.startswith("netT.") or n == "mod.M"), n
+    # first step after a switch == lr * sign(g) (bias-corrected Adam with zero moments), for every trained element
+    snap = {n: tr.view(n).clone() for n in tr.layout}
+    tr.set_train_groups(("netF",))
+    tr.step()
+    d = tr.view("netF.fc1.weight") - snap["netF.fc1.weight"]
+    g = tr.view("netF.fc1.weight", tr.grads)
+    big = g.abs() > 1e-6 * g.abs().max()
+    assert torch.allclose(d[big], -tr.cfg.lr * torch.sign(g[big]), rtol=1e-3, atol=0)
+    lb = tr.make_lbfgs()
+    tr.set_train_groups(("net",))
+    with pytest.raises(RuntimeError):
+        tr.step_lbfgs(lb)
+
+
+def test_nonfinite_flag_and_log_line():
+    """terms[9] counts the logged terms that are NaN / infinite (cheap failure detection in the loss
+    reduction); the log line has upstream's column order and arity (src/kharmonic_lofar.py:176-181)."""
+    tr, *_ = _trainer(4, 4, 2, 2)
+    tr.step()
+    t = tr.read_terms()
+    assert t["nonfinite"] == 0.0
+    line = tr.format_log(2, 17, 5).split()
+    assert line[:3] == ["2", "17", "5"] and len(line) == 3 + 8
+    want = [t[k] for k in ("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica")]
+    assert [float(v) for v in line[3:]] == [float("%f" % v) for v in want]
+    tr2, *_ = _trainer(4, 4, 2, 2, rica=False)
+    tr2.closure_only()
+    assert len(tr2.format_log(0, 0, 0).split()) == 3 + 7
+    tr.view("mod.M")[0, 0] = float("nan")
+    tr.invalidate_forward()
+    tr.closure_only()
+    t = tr.read_terms()
+    assert t["nonfinite"] >= 1.0 and t["kdist"] != t["kdist"]
+
+
+def test_checkpoint_files_roundtrip_into_the_modules(tmp_path):
+    """src/kharmonic_lofar.py:210-222 writes net.model / khm.model / netT.model / netF.model as
+    {'model_state_dict': sd}; :67-79 loads them with map_location and load_state_dict.  Files written by the
+    trainer load into the drop-in modules that way, and back into a second trainer, bit for bit."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    from lshm_amd.lofar_models import AutoEncoder1DCNN, AutoEncoderCNN2, Kmeans
+    tr, *_ = _trainer(4, 4, 2, 2)
+    tr.step()
+    tr.save_checkpoints(str(tmp_path))
+    hs = torch.tensor(O.DEFAULT_SCALES)
+    net, netT, netF = AutoEncoderCNN2(224, 4, hs, True), AutoEncoder1DCNN(16, 4, hs, True), AutoEncoder1DCNN(16, 4, hs, True)
+    mod = Kmeans(256, 4, 4)
+    mydevice = torch.device("cpu")
+    for m, f in ((net, "net.model"), (mod, "khm.model"), (netT, "netT.model"), (netF, "netF.model")):
+        checkpoint = torch.load(str(tmp_path / f), map_location=mydevice)
+        res = m.load_state_dict(checkpoint["model_state_dict"])
+        assert not res.missing_keys and not res.unexpected_keys
+        m.train()
+    tr2 = KHarmonicTrainer(TrainConfig(Kc=4), batch=4, batch_per_bline=2, default_batch=2, device=DEV)
+    tr2.load_state_dicts(net.state_dict(), netT.state_dict(), netF.state_dict(), mod.state_dict())
+    assert torch.equal(tr.params, tr2.params)
+
+
+def test_capture_is_refused_in_fork_mode():
+    """LSHM_FORK=1 nests stream forks, and ending a capture of that topology crashes hipStreamEndCapture
+    (ROCm 7.2): the engine refuses a capturing stream in that mode instead (LSHM_ERR_UNSUPPORTED)."""
+    import os
+    os.environ["LSHM_FORK"] = "1"
+    try:
+        tr, *_ = _trainer(4, 4, 2, 2)  # the engine reads the switch when it is created
     finally:
-        _lib.load().lshm_set_matrix_precision(0)
+        os.environ.pop("LSHM_FORK", None)
+    tr.step()  # eager launches work in fork mode
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="capture"):
+        with torch.cuda.graph(g, stream=s):
+            tr.terms.add_(0.0)     # something harmless in the graph, then the refused call
+            tr._closure_fwd_bwd()
+    torch.cuda.synchronize()
+    tr.step()                       # the engine is still usable afterwards
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.params).all()
+
+
+@pytest.mark.skipif(torch.cuda.is_available() and torch.cuda.device_count() < 2, reason="needs two devices")
+def test_trainer_on_a_device_that_is_not_current():
+    """Every launch of a trainer goes to its own device whatever the caller's current device is."""
+    torch.cuda.set_device(0)
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    x, uv = O.closed_form_inputs(4, 4)
+    outs = []
+    for d in ("cuda:0", "cuda:1"):
+        tr = KHarmonicTrainer(TrainConfig(Kc=5), batch=4, batch_per_bline=2, default_batch=2, device=d)
+        tr.init_parameters(seed=5)
+        tr.new_minibatch(x.to(d), uv.to(d))
+        tr.step()
+        torch.cuda.synchronize(d)
+        outs.append(tr.params.cpu())
+    assert torch.cuda.current_device() == 0 and torch.equal(outs[0], outs[1])
