@@ -22,6 +22,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <type_traits>
 
 #include "kernels.h"
 
@@ -51,6 +52,22 @@ __device__ __forceinline__ unsigned bf16_bits(float v) {  // round to nearest ev
   const unsigned u = __float_as_uint(v);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
+// Operands are fetched with raw buffer loads: one uniform resource per tensor (base pointer in SGPRs), a
+// 32-bit byte offset per element and a scalar offset that steps through K.  An element that does not
+// exist (padding, rows / columns past the edge) gets the offset kNoElem, which is beyond the resource's
+// extent: the hardware returns 0 for it -- no predicates, no exec-mask branches, no 64-bit address
+// arithmetic in the K loop (they were ~70 of its ~85 instructions per 8 matrix instructions).  Tensors are
+// therefore limited to 4 GiB each (checked where the problems are built).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned kNoElem = 0xFFFFFFFFu;
+__device__ __forceinline__ rsrc_t make_rsrc(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ unsigned elem_off(bool ok, long elems) { return ok ? (unsigned)(elems << 2) : kNoElem; }
+
 template <class P, int BM, int BN, int BK, int KW = 0, bool BF = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   const int grp = blockIdx.z / pp.zper;
@@ -109,13 +126,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   const int wk = KW ? wave / WM : 0;  // which share of the k-blocks
 
   float ra[NA], rb[NB];
-  // "fast" operands are affine in the K-chunk index: element i of this thread sits at
-  // base + off[i] + chunk * step, with tap decode and bounds tests done once, before the K loop
-  int aoff[NA], boff[NB];
-  unsigned avalid = 0, bvalid = 0;
-  const float* abase = nullptr;
-  const float* bbase = nullptr;
-  long astep = 0, bstep = 0;
+  // "fast" operands are affine in the K-chunk index: element i of this thread sits at byte offset
+  // voff[i] + chunk * step of its tensor, with tap decode and bounds tests done once, before the K loop
+  const rsrc_t a_rs = make_rsrc(P::a_tensor(p)), b_rs = make_rsrc(P::b_tensor(p));
+  unsigned avoff[NA], bvoff[NB];
+  unsigned asoff = 0, bsoff = 0, astep = 0, bstep = 0;  // scalar byte offsets of the current chunk / per chunk
   typename P::FastA fa;
   typename P::FastB fb;
   // k (within the chunk) of element e of group g: 16 (g / 4) + (g % 4) + 4 e   (bf16: ... + 4 (g % 4) + e)
@@ -123,20 +138,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   if constexpr (P::A_M_FAST) {
     static_assert(NT % BM == 0 && A_GROUPS % NT == 0, "every thread stages whole groups of one row");
     fa = P::a_fast(p, m0 + t % BM, zg);
+    const long arel = P::a_base(p, fa) - P::a_tensor(p);
 #pragma unroll
     for (int j = 0; j < NGA; ++j) {
       const int g = t / BM + j * (NT / BM);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bool ok;
-        P::a_affine(p, fa, m0 + t % BM, kmap(g, e), zg, aoff[4 * j + e], ok);
-        avalid |= (unsigned)ok << (4 * j + e);
+        int off;
+        P::a_affine(p, fa, m0 + t % BM, kmap(g, e), zg, off, ok);
+        avoff[4 * j + e] = elem_off(ok, arel + off);
       }
     }
-    astep = P::a_step(p, BK);
-    abase = P::a_base(p, fa) + (long)(kbeg / BK) * astep;
+    astep = (unsigned)(P::a_step(p, BK) << 2);
+    asoff = (unsigned)(kbeg / BK) * astep;
   }
   if constexpr (P::B_N_FAST) {
+    const long brel = P::b_base(p) - P::b_tensor(p);
 #pragma unroll
     for (int j = 0; j < NGB; ++j) {
       const int G = t + j * NT;
@@ -144,15 +162,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         bool ok;
-        P::b_affine(p, P::b_fast(p, n0 + n, zg), n0 + n, kmap(g, e), zg, boff[4 * j + e], ok);
-        bvalid |= (unsigned)(ok && G < B_GROUPS) << (4 * j + e);
+        int off;
+        P::b_affine(p, P::b_fast(p, n0 + n, zg), n0 + n, kmap(g, e), zg, off, ok);
+        bvoff[4 * j + e] = elem_off(ok && G < B_GROUPS, brel + off);
       }
     }
-    bstep = P::b_step(p, BK);
-    bbase = P::b_base(p) + (long)(kbeg / BK) * bstep;
+    bstep = (unsigned)(P::b_step(p, BK) << 2);
+    bsoff = (unsigned)(kbeg / BK) * bstep;
   }
-  // global -> registers for the chunk starting at k0 (issued one chunk ahead of its use)
-  auto fetch = [&](int k0) {
+  // global -> registers for the chunk starting at k0 (issued one chunk ahead of its use); TAIL: the chunk is
+  // cut short by the end of K (only possible in the last chunk of a K that is not a multiple of BK)
+  auto fetch_t = [&](int k0, auto tail) {
+    constexpr bool TAIL = decltype(tail)::value;
     const int krem = kend - k0;  // elements of this chunk that exist
     if constexpr (P::A_M_FAST) {
 #pragma unroll
@@ -160,17 +181,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
         const int g = t / BM + j * (NT / BM);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int i = 4 * j + e, kl = kmap(g, e);
-          ra[i] = ((avalid >> i) & 1u) && kl < krem ? abase[aoff[i]] : 0.f;
+          const int i = 4 * j + e;
+          // (an element past the end of K must not be touched at all: its address may lie outside the tensor)
+          ra[i] = buf_ld(a_rs, (!TAIL || kmap(g, e) < krem) ? avoff[i] : kNoElem, asoff);
         }
       }
-      abase += astep;
+      asoff += astep;
     } else {
       const int k = k0 + t % BK;
-      if (k < kend) fa = P::a_fast(p, k, zg);
+      const bool kok = !TAIL || k < kend;
+      fa = P::a_fast(p, kok ? k : kbeg, zg);
 #pragma unroll
-      for (int i = 0; i < NA; ++i)
-        ra[i] = (k < kend) ? P::a_load(p, fa, m0 + t / BK + i * (NT / BK), k, zg) : 0.f;
+      for (int i = 0; i < NA; ++i) {
+        const unsigned vo = P::a_voff(p, fa, m0 + t / BK + i * (NT / BK), k, zg);
+        ra[i] = buf_ld(a_rs, kok ? vo : kNoElem, 0u);
+      }
     }
     if constexpr (P::B_N_FAST) {
 #pragma unroll
@@ -178,20 +203,26 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
         const int g = (t + j * NT) / BN;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int i = 4 * j + e, kl = kmap(g, e);
-          rb[i] = ((bvalid >> i) & 1u) && kl < krem ? bbase[boff[i]] : 0.f;
+          const int i = 4 * j + e;
+          rb[i] = buf_ld(b_rs, (!TAIL || kmap(g, e) < krem) ? bvoff[i] : kNoElem, bsoff);
         }
       }
-      bbase += bstep;
+      bsoff += bstep;
     } else {
       const int k = k0 + t % BK;
-      if (k < kend) fb = P::b_fast(p, k, zg);
+      const bool kok = !TAIL || k < kend;
+      fb = P::b_fast(p, kok ? k : kbeg, zg);
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         const int nl = t / BK + i * (NT / BK);
-        rb[i] = (nl < BN && k < kend) ? P::b_load(p, fb, k, n0 + nl, zg) : 0.f;
+        const unsigned vo = P::b_voff(p, fb, k, n0 + nl, zg);
+        rb[i] = buf_ld(b_rs, (nl < BN && kok) ? vo : kNoElem, 0u);
       }
     }
+  };
+  auto fetch = [&](int k0) {
+    if (kend - k0 >= BK) fetch_t(k0, std::false_type{});
+    else fetch_t(k0, std::true_type{});
   };
   // position of this thread's k (k-fast operands) inside the image of one row
   const int kf = t % BK;
@@ -400,12 +431,8 @@ struct Conv2dFwd {
     f.ix0 = 2 * ox - 1;
     return f;
   }
-  __device__ static float a_load(const Params& p, const FastA& f, int, int k, int) {
-    if (!f.base) return 0.f;
-    const int ci = k >> 4, iy = f.iy0 + ((k >> 2) & 3), ix = f.ix0 + (k & 3);
-    if ((unsigned)iy >= (unsigned)p.H || (unsigned)ix >= (unsigned)p.W) return 0.f;
-    return f.base[(ci * p.H + iy) * p.W + ix];
-  }
+  __device__ static const float* a_tensor(const Params& p) { return p.x; }
+  __device__ static const float* b_tensor(const Params& p) { return p.w; }
   // element (m, k = kl + chunk*BK): offset = (ci*H + iy)*W + ix, ci = kl/16 + chunk*BK/16
   __device__ static void a_affine(const Params& p, const FastA& f, int, int kl, int, int& off, bool& ok) {
     const int iy = f.iy0 + ((kl >> 2) & 3), ix = f.ix0 + (kl & 3);
@@ -415,8 +442,8 @@ struct Conv2dFwd {
   __device__ static long a_step(const Params& p, int bk) { return (long)(bk / 16) * p.H * p.W; }
   __device__ static const float* a_base(const Params& p, const FastA& f) { return f.base ? f.base : p.x; }
   __device__ static FastB b_fast(const Params&, int k, int) { return FastB{k}; }
-  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
-    return n < p.N ? p.w[n * p.K + k] : 0.f;
+  __device__ static unsigned b_voff(const Params& p, const FastB&, int k, int n, int) {
+    return elem_off(n < p.N, (long)n * p.K + k);
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (m >= p.M || n >= p.N) return;
@@ -457,13 +484,8 @@ struct Conv2dDgrad {
     f.base = p.s + (long)b * p.s_bs;
     return f;
   }
-  __device__ static float a_load(const Params& p, const FastA& f, int, int k, int z) {
-    if (!f.base) return 0.f;
-    const int cs = k >> 2, tt = (k >> 1) & 1, u = k & 1;
-    const int iy = f.mm + (z >> 1) - tt, ix = f.nn + (z & 1) - u;
-    if ((unsigned)iy >= (unsigned)p.Hs || (unsigned)ix >= (unsigned)p.Ws) return 0.f;
-    return f.base[(cs * p.Hs + iy) * p.Ws + ix];
-  }
+  __device__ static const float* a_tensor(const Params& p) { return p.s; }
+  __device__ static const float* b_tensor(const Params& p) { return p.w; }
   __device__ static void a_affine(const Params& p, const FastA& f, int, int kl, int z, int& off, bool& ok) {
     const int iy = f.mm + (z >> 1) - ((kl >> 1) & 1), ix = f.nn + (z & 1) - (kl & 1);
     ok = f.base && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
@@ -479,12 +501,6 @@ struct Conv2dDgrad {
   __device__ static long b_step(const Params& p, int bk) { return (long)(bk / 4) * p.Cb * 16; }
   __device__ static const float* b_base(const Params& p) { return p.w; }
   __device__ static FastB b_fast(const Params&, int n, int) { return FastB{n}; }
-  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int z) {
-    if (n >= p.N) return 0.f;
-    const int cs = k >> 2, tt = (k >> 1) & 1, u = k & 1;
-    const int ky = 2 * tt + 1 - (z >> 1), kx = 2 * u + 1 - (z & 1);
-    return p.w[((cs * p.Cb + n) * 4 + ky) * 4 + kx];
-  }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int z) {
     if (n >= p.N) return;
     const int hw = p.Hs * p.Ws;
@@ -513,28 +529,29 @@ struct Conv2dWgrad {
   static constexpr bool A_M_FAST = false, B_N_FAST = false;
   static constexpr int ID = 2;  // stable key of the tuning cache
   using Params = Conv2dWgradParams;
-  struct FastA { const float* base; };
-  struct FastB { const float* base; int iy0, ix0; };
+  struct FastA { long off; };                 // element offset of (image, position) inside `s`
+  struct FastB { long off; int iy0, ix0; };   // element offset of the image inside `big`, window origin
+  __device__ static const float* a_tensor(const Params& p) { return p.s; }
+  __device__ static const float* b_tensor(const Params& p) { return p.big; }
   __device__ static FastA a_fast(const Params& p, int k, int) {
     int r;
     const int b = divmod(udiv(p.Hs * p.Ws), k, r);
-    return FastA{p.s + (long)b * p.s_bs + r};
+    return FastA{(long)b * p.s_bs + r};
   }
-  __device__ static float a_load(const Params& p, const FastA& f, int m, int, int) {
-    return m < p.M ? f.base[m * p.Hs * p.Ws] : 0.f;
+  __device__ static unsigned a_voff(const Params& p, const FastA& f, int m, int, int) {
+    return elem_off(m < p.M, f.off + (long)m * p.Hs * p.Ws);
   }
   __device__ static FastB b_fast(const Params& p, int k, int) {
     int r, ox;
     const int b = divmod(udiv(p.Hs * p.Ws), k, r);
     const int oy = divmod(udiv(p.Ws), r, ox);
-    return FastB{p.big + (long)b * p.big_bs, 2 * oy - 1, 2 * ox - 1};
+    return FastB{(long)b * p.big_bs, 2 * oy - 1, 2 * ox - 1};
   }
-  __device__ static float b_load(const Params& p, const FastB& f, int, int n, int) {
-    if (n >= p.N) return 0.f;
+  __device__ static unsigned b_voff(const Params& p, const FastB& f, int, int n, int) {
     const int cb = n >> 4, iy = f.iy0 + ((n >> 2) & 3), ix = f.ix0 + (n & 3);
     const int Hb = 2 * p.Hs, Wb = 2 * p.Ws;
-    if ((unsigned)iy >= (unsigned)Hb || (unsigned)ix >= (unsigned)Wb) return 0.f;
-    return f.base[(cb * Hb + iy) * Wb + ix];
+    const bool ok = n < p.N && (unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb;
+    return elem_off(ok, f.off + (long)(cb * Hb + iy) * Wb + ix);
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;
@@ -571,15 +588,11 @@ struct Conv1dFwd {
   }
   __device__ static long a_step(const Params& p, int bk) { return (long)(bk / 4) * p.L; }
   __device__ static const float* a_base(const Params& p, const FastA& f) { return f.base ? f.base : p.x; }
-  __device__ static float a_load(const Params& p, const FastA& f, int, int k, int) {
-    if (!f.base) return 0.f;
-    const int ci = k >> 2, pos = f.j0 + (k & 3);
-    if ((unsigned)pos >= (unsigned)p.L) return 0.f;
-    return f.base[ci * p.L + pos];
-  }
+  __device__ static const float* a_tensor(const Params& p) { return p.x; }
+  __device__ static const float* b_tensor(const Params& p) { return p.w; }
   __device__ static FastB b_fast(const Params&, int k, int) { return FastB{k}; }
-  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
-    return n < p.N ? p.w[n * p.K + k] : 0.f;
+  __device__ static unsigned b_voff(const Params& p, const FastB&, int k, int n, int) {
+    return elem_off(n < p.N, (long)n * p.K + k);
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (m >= p.M || n >= p.N) return;
@@ -628,13 +641,9 @@ struct Conv1dDgrad {
   }
   __device__ static long b_step(const Params& p, int bk) { return (long)bk * p.N; }
   __device__ static const float* b_base(const Params& p) { return p.w; }
-  __device__ static float a_load(const Params& p, const FastA& f, int, int k, int) {
-    return f.base ? f.base[k * p.Ls] : 0.f;
-  }
+  __device__ static const float* a_tensor(const Params& p) { return p.s; }
+  __device__ static const float* b_tensor(const Params& p) { return p.w; }
   __device__ static FastB b_fast(const Params&, int n, int) { return FastB{n}; }
-  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
-    return n < p.N ? p.w[k * p.N + n] : 0.f;
-  }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;
     const int cb = n >> 2, tt = n & 3;
@@ -666,26 +675,26 @@ struct Conv1dWgrad {
   static constexpr bool A_M_FAST = false, B_N_FAST = false;
   static constexpr int ID = 5;  // stable key of the tuning cache
   using Params = Conv1dWgradParams;
-  struct FastA { const float* base; };
-  struct FastB { const float* base; int pos0; };
+  struct FastA { long off; };
+  struct FastB { long off; int pos0; };
+  __device__ static const float* a_tensor(const Params& p) { return p.s; }
+  __device__ static const float* b_tensor(const Params& p) { return p.big; }
   __device__ static FastA a_fast(const Params& p, int k, int) {
     int i;
     const int b = divmod(udiv(p.Ls), k, i);
-    return FastA{p.s + (long)b * p.s_bs + i};
+    return FastA{(long)b * p.s_bs + i};
   }
-  __device__ static float a_load(const Params& p, const FastA& f, int m, int, int) {
-    return m < p.M ? f.base[m * p.Ls] : 0.f;
+  __device__ static unsigned a_voff(const Params& p, const FastA& f, int m, int, int) {
+    return elem_off(m < p.M, f.off + (long)m * p.Ls);
   }
   __device__ static FastB b_fast(const Params& p, int k, int) {
     int i;
     const int b = divmod(udiv(p.Ls), k, i);
-    return FastB{p.big + (long)b * p.big_bs, 4 * i - p.pad};
+    return FastB{(long)b * p.big_bs, 4 * i - p.pad};
   }
-  __device__ static float b_load(const Params& p, const FastB& f, int, int n, int) {
-    if (n >= p.N) return 0.f;
+  __device__ static unsigned b_voff(const Params& p, const FastB& f, int, int n, int) {
     const int cb = n >> 2, pos = f.pos0 + (n & 3);
-    if ((unsigned)pos >= (unsigned)p.Lb) return 0.f;
-    return f.base[cb * p.Lb + pos];
+    return elem_off(n < p.N && (unsigned)pos < (unsigned)p.Lb, f.off + (long)cb * p.Lb + pos);
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;
@@ -724,11 +733,13 @@ struct Strided {
   }
   __device__ static long b_step(const Params& p, int bk) { return (long)bk * p.sbk; }
   __device__ static const float* b_base(const Params& p) { return p.b; }
-  __device__ static float a_load(const Params& p, const FastA&, int m, int k, int) {
-    return m < p.M ? p.a[(long)m * p.sam + (long)k * p.sak] : 0.f;
+  __device__ static const float* a_tensor(const Params& p) { return p.a; }
+  __device__ static const float* b_tensor(const Params& p) { return p.b; }
+  __device__ static unsigned a_voff(const Params& p, const FastA&, int m, int k, int) {
+    return elem_off(m < p.M, (long)m * p.sam + (long)k * p.sak);
   }
-  __device__ static float b_load(const Params& p, const FastB&, int k, int n, int) {
-    return n < p.N ? p.b[(long)k * p.sbk + (long)n * p.sbn] : 0.f;
+  __device__ static unsigned b_voff(const Params& p, const FastB&, int k, int n, int) {
+    return elem_off(n < p.N, (long)k * p.sbk + (long)n * p.sbn);
   }
   __device__ static void store(const Params& p, int m, int n, f32x4 v, int) {
     if (n >= p.N) return;

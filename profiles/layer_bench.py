@@ -50,11 +50,14 @@ def layer(kind, Cin, Cout, Hin, Win):
     print(f"kind{kind} {Cin:3d}->{Cout:3d} in {Hin}x{Win:<6d} fwd {f:7.1f}us ({nb/f/1e6:6.2f} TB/s, {fl/f/1e6:6.1f} TF)  dgrad {d:7.1f}us  wgrad {g:7.1f}us")
 
 
-for i in range(6):
-    layer(0, CH[i], CH[i + 1], 128 >> i, 128 >> i)
-for i in range(6):
-    layer(1, CH[6 - i], CH[5 - i], 2 << i, 2 << i)
-for i in range(6):
-    layer(2, CH[i], CH[i + 1], 1, 16384 >> (2 * i))
-for i in range(6):
-    layer(3, CH[6 - i], CH[5 - i], 1, 4 << (2 * i))
+# optional filter: layer_bench.py B [kind [index]]
+only_kind = int(sys.argv[2]) if len(sys.argv) > 2 else None
+only_idx = int(sys.argv[3]) if len(sys.argv) > 3 else None
+for kind in range(4):
+    for i in range(6):
+        if (only_kind is not None and kind != only_kind) or (only_idx is not None and i != only_idx):
+            continue
+        if kind == 0: layer(0, CH[i], CH[i + 1], 128 >> i, 128 >> i)
+        elif kind == 1: layer(1, CH[6 - i], CH[5 - i], 2 << i, 2 << i)
+        elif kind == 2: layer(2, CH[i], CH[i + 1], 1, 16384 >> (2 * i))
+        else: layer(3, CH[6 - i], CH[5 - i], 1, 4 << (2 * i))

@@ -508,8 +508,9 @@ def test_switching_train_groups_keeps_frozen_tensors_bit_identical():
     tr.step()
     d = tr.view("netF.fc1.weight") - snap["netF.fc1.weight"]
     g = tr.view("netF.fc1.weight", tr.grads)
-    big = g.abs() > 1e-6 * g.abs().max()
-    assert torch.allclose(d[big], -tr.cfg.lr * torch.sign(g[big]), rtol=1e-3, atol=0)
+    big = g.abs() > 1e-4            # |g| >> Adam's eps (1e-8): the update is -lr g / (|g| + eps)
+    assert int(big.sum()) > 100
+    assert torch.allclose(d[big], -tr.cfg.lr * torch.sign(g[big]), rtol=2e-3, atol=0)
     lb = tr.make_lbfgs()
     tr.set_train_groups(("net",))
     with pytest.raises(RuntimeError):
