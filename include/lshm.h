@@ -39,6 +39,7 @@ extern "C" {
 #define LSHM_ERR_ARG (-1)
 #define LSHM_ERR_WORKSPACE (-2)
 #define LSHM_ERR_UNSUPPORTED (-3)
+#define LSHM_ERR_COMM (-4)
 
 /* convolution flavours of the autoencoders */
 #define LSHM_CONV2D_K4S2P1 0  /* nn.Conv2d(..,4,stride=2,padding=1)          src/lofar_models.py:31-41 */
@@ -236,6 +237,39 @@ int lshm_patches_from_vis(const int8_t* vis, const float* scale, int nb, int nti
                           float clampv, int normalize, float* y, double* mean_std, float* workspace,
                           lshm_stream_t stream);
 
+/* ---- data-parallel collectives: RCCL over xGMI, one rank per GPU, on the caller's stream.
+ * The reference is single-process (no torch.distributed, NCCL or MPI call sites); under data
+ * parallelism the quantities its one process consumes whole -- the gradients behind loss.backward()
+ * (src/kharmonic_lofar.py:175), the logged terms (:176-181) and the centroid numerator / denominator of
+ * Kmeans.offline_update (src/lofar_models.py:240-260) -- are SUM all-reduced over ranks instead.
+ * RCCL is bound at run time (dlopen): lshm_comm_available() says whether this process has it.
+ * Bootstrap: one rank calls lshm_comm_unique_id and ships the 128 bytes to the others by any means (the
+ * host side uses torch.distributed's store); every rank then calls lshm_comm_init with the HIP device it
+ * will use current. */
+#define LSHM_COMM_ID_BYTES 128
+typedef struct lshm_comm lshm_comm;
+int lshm_comm_available(void);
+int lshm_comm_unique_id(char* id128);
+int lshm_comm_init(const char* id128, int rank, int world, lshm_comm** out);
+void lshm_comm_destroy(lshm_comm* c);
+int lshm_comm_rank(const lshm_comm* c);
+int lshm_comm_world(const lshm_comm* c);
+/* in place: buf[0..n) (float) and tail[0..ntail) (double) become their sums over ranks; one fused launch
+ * (the flat gradient arena and the loss-term vector of one closure; either may be empty) */
+int lshm_comm_allreduce_flat(lshm_comm* c, float* buf, size_t n, double* tail, size_t ntail,
+                             lshm_stream_t stream);
+
+/* The same with num_channels 4 or 8 (8: real / imaginary parts of all four polarisations, :101-111) and
+ * with the un-normalised moments exposed: moments[3] (device doubles, may be NULL) = [sum, sum of squares,
+ * count] of this call's clamped values.  Upstream normalises by the mean / std of the WHOLE minibatch
+ * (:190-193); ranks of a data-parallel job call this with normalize = 0, SUM all-reduce the three doubles
+ * and finish with lshm_patches_normalize, which reproduces the single-process global-batch statistics. */
+int lshm_patches_from_vis_ex(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int patch,
+                             int num_channels, float clampv, int normalize, float* y, double* mean_std,
+                             double* moments, float* workspace, lshm_stream_t stream);
+/* y[0..n) = (y - mean) / std, mean and unbiased std from moments = [sum, sum of squares, count] */
+int lshm_patches_normalize(float* y, long n, const double* moments, lshm_stream_t stream);
+
 /* ---- fused training-step engine (one ADMM iteration)            src/kharmonic_lofar.py:131-202 */
 typedef struct lshm_engine lshm_engine;
 typedef struct lshm_step_config {
@@ -260,6 +294,12 @@ int lshm_engine_param_lookup(const lshm_engine* e, const char* name, long* offse
 int lshm_engine_param_name(const lshm_engine* e, int index, char* buf, int buflen, long* offset,
                            long* numel, int* ndim, long* shape /* >= 4 */);
 size_t lshm_engine_workspace_floats(const lshm_engine* e);
+/* Attach a communicator (NULL detaches): the closures then return GLOBAL gradients and terms, i.e.
+ * lshm_engine_forward_backward[_ex] / lshm_engine_backward_saved sum-all-reduce [grads | terms] and
+ * lshm_engine_forward_loss the terms, inside the call: the gradients of the two 1-D autoencoders go as soon
+ * as their backward is complete, on a stream of their own beside the 2-D autoencoder's backward; the rest
+ * follows the last weight gradient.  The communicator's world size must equal lshm_step_config.world. */
+int lshm_engine_set_comm(lshm_engine* e, lshm_comm* comm);
 /* closure forward + backward: fills grads (same layout as params) and terms[16] (double, device):
  * [0..7] = loss0, loss1, loss2, loss3, kdist, aug, sim, rica (already weighted, as logged upstream),
  * [8] = total, [9] = how many of [0..7] are NaN or infinite (0 = healthy; sums over ranks like the rest).  With world > 1 the loss terms / gradients are this rank's share (sum over ranks = global). */

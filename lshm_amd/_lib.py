@@ -97,7 +97,18 @@ _SIGNATURES = {
     "lshm_patches_workspace_floats": (c_size_t, []),
     "lshm_patches_from_vis": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p]),
+    "lshm_patches_from_vis_ex": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lshm_patches_normalize": (c_int, [c_void_p, c_long, c_void_p, c_void_p]),
     "lshm_fft2_ortho_shift_cat_clamp": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "lshm_comm_available": (c_int, []),
+    "lshm_comm_unique_id": (c_int, [C.c_char_p]),
+    "lshm_comm_init": (c_int, [C.c_char_p, c_int, c_int, C.POINTER(c_void_p)]),
+    "lshm_comm_destroy": (None, [c_void_p]),
+    "lshm_comm_rank": (c_int, [c_void_p]),
+    "lshm_comm_world": (c_int, [c_void_p]),
+    "lshm_comm_allreduce_flat": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
+    "lshm_engine_set_comm": (c_int, [c_void_p, c_void_p]),
     "lshm_engine_create": (c_int, [C.POINTER(StepConfig), C.POINTER(c_void_p)]),
     "lshm_engine_destroy": (None, [c_void_p]),
     "lshm_engine_param_count": (c_long, [c_void_p]),

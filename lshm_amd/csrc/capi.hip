@@ -239,7 +239,21 @@ int lshm_patches_from_vis(const int8_t* vis, const float* scale, int nb, int nti
                           float clampv, int normalize, float* y, double* mean_std, float* ws, lshm_stream_t s) {
   REQUIRE(vis && scale && y && mean_std && ws && nb > 0 && ntime > 0 && nfreq > 0, "patches_from_vis: bad argument");
   REQUIRE(patch > 0 && patch % 2 == 0, "patches_from_vis: patch size must be even");
-  return patches_from_vis(vis, scale, nb, ntime, nfreq, patch, clampv, normalize, y, mean_std, ws, ST(s));
+  return patches_from_vis(vis, scale, nb, ntime, nfreq, patch, 4, clampv, normalize, y, mean_std, nullptr, ws, ST(s));
+}
+int lshm_patches_from_vis_ex(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int patch,
+                             int num_channels, float clampv, int normalize, float* y, double* mean_std,
+                             double* moments, float* ws, lshm_stream_t s) {
+  REQUIRE(vis && scale && y && mean_std && ws && nb > 0 && ntime > 0 && nfreq > 0, "patches_from_vis: bad argument");
+  REQUIRE(patch > 0 && patch % 2 == 0, "patches_from_vis: patch size must be even");
+  REQUIRE(num_channels == 4 || num_channels == 8, "patches_from_vis: num_channels is 4 or 8 (src/lofar_tools.py:70)");
+  return patches_from_vis(vis, scale, nb, ntime, nfreq, patch, num_channels, clampv, normalize, y, mean_std, moments,
+                          ws, ST(s));
+}
+int lshm_patches_normalize(float* y, long n, const double* moments, lshm_stream_t s) {
+  REQUIRE(y && moments && n >= 0, "patches_normalize: bad argument");
+  if (n == 0) return LSHM_OK;
+  return patches_normalize_moments(y, n, moments, ST(s));
 }
 
 int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv, lshm_stream_t s) {

@@ -88,6 +88,10 @@ struct lshm_engine {
   size_t part_floats;
   size_t ws_floats;
   int device;      // HIP device current at creation (-1: none); the side stream and the events live there
+  // data parallelism inside the engine (lshm_engine_set_comm): the closures all-reduce their own results
+  lshm_comm* comm = nullptr;
+  hipStream_t cstream = nullptr;  // the early bucket (netT / netF gradients) runs here, beside the 2-D backward
+  long off1d = 0;                 // arena offset of the first netT tensor: [0, off1d) net, [off1d, Moff) netT+netF
 };
 
 namespace lshm {
@@ -261,6 +265,10 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   GradJobs jobs;
   jobs.scratch = ws + e->lane[ln].o_defer;
   jobs.cap = e->defer_floats;
+  // the six dense layers' weight gradients (twelve for a pair) go as one launch once the last of their
+  // gradients exists, instead of six latency-bound 5-10 us launches
+  static const bool batch_dense = getenv("LSHM_DENSE_WGRAD_SEPARATE") == nullptr;
+  jobs.batch_dense = batch_dense;
   // Weight gradients need only dz and the saved input of their layer, and nothing waits for them
   // before the optimizer: with a side stream they form a second chain beside the data-gradient
   // chain, each link waiting for "dz is ready" on `st`; `st` itself never waits (the caller joins
@@ -311,6 +319,8 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   LinWgradIO lw[2];
   LinDgradIO ld[2];
   auto wgrad = [&](long ldx, long lddz, int K, int N) {
+    if (jobs.batch_dense)  // only parked here (no launch, no event): grad_jobs_launch_dense runs them all
+      return linear_wgrad(lw[0], ldx, lddz, B, K, N, nullptr, 0, wst, G > 1 ? &lw[1] : nullptr, &jobs);
     pending.push_back([&, ldx, lddz, K, N, w0 = lw[0], w1 = lw[1]]() {
       return linear_wgrad(w0, ldx, lddz, B, K, N, nullptr, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
     });
@@ -356,6 +366,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   if ((rc = wgrad(hd, 768 + hd, hd, hd))) return rc;
   // the decoder's and the dense layers' closing sums go now (side stream, behind their producers): the
   // tail after the last weight gradient then only has the encoder's
+  pending.push_back([&]() { return grad_jobs_launch_dense(jobs, wst); });
   if ((rc = release(true))) return rc;
   if (side && (rc = grad_jobs_finish(jobs, wst))) return rc;
   // ---- encoder
@@ -566,7 +577,8 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   hipLaunchKernelGGL(finalize_terms_kernel, dim3(1), dim3(64), 0, st, scal, terms, n_global, (double)c.rho,
                      (double)c.alpha * inv_count, c.rica, rica_part, LOGCOSH3_BLOCKS * 3);
   if ((rc = check_launch("finalize_terms"))) return rc;
-  if (!grd) return LSHM_OK;
+  if (!grd)  // gradient-free closure (line search): every rank needs the global loss to take the same branch
+    return e->comm ? comm_allreduce_segments(e->comm, nullptr, nullptr, 0, terms, 10, st) : LSHM_OK;
   // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
   hipStream_t wgs = (e->pair_mode && e->side_ok && e->side_wgrad) ? e->wstream : nullptr;
   {
@@ -591,6 +603,20 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
       }
     }
   }
+  bool early_bucket = false;
+  if (e->comm && wgs && e->cstream) {
+    // netT / netF are done once their closing sums have run on the weight-gradient stream: their 1.9 MB go
+    // now, on a stream of their own, while the 2-D autoencoder's backward runs
+    hipEvent_t ev = e->take_event();
+    if (hipEventRecord(ev, wgs) != hipSuccess || hipStreamWaitEvent(e->cstream, ev, 0) != hipSuccess) {
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
+    float* seg[1] = {grd + e->off1d};
+    const size_t nseg[1] = {(size_t)(e->Moff - e->off1d)};
+    if ((rc = comm_allreduce_segments(e->comm, seg, nseg, 1, nullptr, 0, e->cstream))) return rc;
+    early_bucket = true;
+  }
   if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st))) return rc;
   {
     const int i0[1] = {0};
@@ -604,6 +630,26 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     if (hipEventRecord(evj, wgs) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
       set_last_error("engine: stream join failed");
       return LSHM_ERR_ARG;
+    }
+  }
+  if (e->comm) {
+    // the rest of the arena (net, mod.M; everything if no early bucket went) and the ten loss doubles: one group
+    float* seg[2];
+    size_t nseg[2];
+    int ns = 0;
+    if (early_bucket) {
+      seg[ns] = grd; nseg[ns++] = (size_t)e->off1d;
+      seg[ns] = grd + e->Moff; nseg[ns++] = (size_t)(e->nparams - e->Moff);
+    } else {
+      seg[ns] = grd; nseg[ns++] = (size_t)e->nparams;
+    }
+    if ((rc = comm_allreduce_segments(e->comm, seg, nseg, ns, terms, 10, st))) return rc;
+    if (early_bucket) {
+      hipEvent_t evc = e->take_event();
+      if (hipEventRecord(evc, e->cstream) != hipSuccess || hipStreamWaitEvent(st, evc, 0) != hipSuccess) {
+        set_last_error("engine: stream join failed");
+        return LSHM_ERR_ARG;
+      }
     }
   }
   return LSHM_OK;
@@ -672,6 +718,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   plan_ae(e, 0, "net", 2, cfg->L, 0, cur);
   plan_ae(e, 1, "netT", 1, cfg->Lt, cfg->L, cur);
   plan_ae(e, 2, "netF", 1, cfg->Lt, cfg->L + cfg->Lt, cur);
+  e->off1d = e->ae[1].cw[0];
   e->Moff = add_param(e, "mod.M", {cfg->K, e->D});
   e->o_scales = take(cur, 8);
   e->o_uvh = take(cur, (size_t)B * e->hdim);
@@ -773,6 +820,7 @@ void lshm_engine_destroy(lshm_engine* e) {
   if (!e) return;
   if (e->side_ok) {
     EngineCall scope(e);
+    if (e->cstream) (void)hipStreamDestroy(e->cstream);
     (void)hipStreamDestroy(e->wstream);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   }
@@ -809,6 +857,22 @@ int lshm_engine_param_name(const lshm_engine* e, int index, char* buf, int bufle
 }
 
 size_t lshm_engine_workspace_floats(const lshm_engine* e) { return e ? e->ws_floats : 0; }
+
+int lshm_engine_set_comm(lshm_engine* e, lshm_comm* comm) {
+  if (!e) { set_last_error("engine_set_comm: null engine"); return LSHM_ERR_ARG; }
+  if (comm && comm_world(comm) != e->cfg.world) {
+    set_last_error("engine_set_comm: the communicator's world size differs from lshm_step_config.world");
+    return LSHM_ERR_ARG;
+  }
+  EngineCall scope(e);
+  if (comm && !e->cstream && e->side_ok &&
+      hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    e->cstream = nullptr;  // no early bucket then: one group after the last weight gradient
+  }
+  e->comm = comm;
+  return LSHM_OK;
+}
 
 #define ENGINE_CHECK(cond, msg)     \
   do {                              \

@@ -68,11 +68,10 @@ __device__ __forceinline__ float buf_ld(rsrc_t r, unsigned voff, unsigned soff) 
 }
 __device__ __forceinline__ unsigned elem_off(bool ok, long elems) { return ok ? (unsigned)(elems << 2) : kNoElem; }
 
-template <class P, int BM, int BN, int BK, int KW = 0, bool BF = false>
-__global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
-  const int grp = blockIdx.z / pp.zper;
-  const int zblk = blockIdx.z - grp * pp.zper;
-  const typename P::Params p = pp.p[grp];  // by value: the fields live in SGPRs instead of being re-read from the kernarg segment inside the K loop
+// One output tile (block column bx, block row by, z-block zblk) of problem p.
+// p by value: the fields live in SGPRs instead of being re-read from the kernarg segment inside the K loop
+template <class P, int BM, int BN, int BK, int KW, bool BF>
+__device__ __forceinline__ void igemm_tile(const typename P::Params p, const int bx, const int by, const int zblk) {
   constexpr int NT = 256;
   static_assert(KW == 0 || ((KW == 2 || KW == 4) && BM * KW == 64), "KW wavefronts per 16-row tile");
   static_assert(BK % 16 == 0 && (KW == 0 || BK / 16 >= KW), "K chunks are whole 16-wide k-blocks");
@@ -106,7 +105,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int lm = lane & 15, lk = lane >> 4;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bx * BM, n0 = by * BN;
   // grid.z = zgroup (e.g. output parity of the transposed conv) x K split
   const int splits = p.sk.splits;
   const int zg = zblk / splits, split = zblk - zg * splits;
@@ -353,6 +352,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
 #pragma unroll
     for (int j = 0; j < TN; ++j)
       P::store(p, m0 + wm0 + 16 * i + 4 * lk, n0 + 16 * j + lm, acc[i][j], zg);
+}
+
+template <class P, int BM, int BN, int BK, int KW = 0, bool BF = false>
+__global__ __launch_bounds__(256) void igemm_kernel(const Pair<P> pp) {
+  const int grp = blockIdx.z / pp.zper;
+  const int zblk = blockIdx.z - grp * pp.zper;
+  igemm_tile<P, BM, BN, BK, KW, BF>(pp.p[grp], blockIdx.x, blockIdx.y, zblk);
+}
+
+// Several independent problems of one policy in ONE launch (the weight gradients of the six dense layers of an
+// autoencoder, times two for the netT / netF pair): each is a 5-10 us launch on its own, latency-bound, and
+// nothing orders them among themselves.  Tiles are numbered consecutively over the problems.
+constexpr int kMaxBatch = 12;
+template <class P>
+struct Batch {
+  typename P::Params p[kMaxBatch];
+  int first[kMaxBatch + 1];  // first tile of problem g; first[n] = all tiles
+  int mt[kMaxBatch], nt[kMaxBatch];
+  int n;
+};
+template <class P, int BM, int BN, int BK, int KW = 0, bool BF = false>
+__global__ __launch_bounds__(256) void igemm_batch_kernel(const Batch<P> bp) {
+  const int bid = blockIdx.x;
+  int g = 0;
+  for (int i = 1; i < bp.n; ++i) g += bid >= bp.first[i] ? 1 : 0;
+  const int local = bid - bp.first[g];
+  const int mt = bp.mt[g], nt = bp.nt[g];
+  const int bx = local % mt, r = local / mt;
+  igemm_tile<P, BM, BN, BK, KW, BF>(bp.p[g], bx, r % nt, r / nt);
 }
 
 // Second stage of a split-K launch: sums the partial slabs in a fixed order (bitwise
@@ -1027,6 +1055,38 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
             best >= 12 ? 64 : (best & 2) ? 32 : 16, best >= 12 ? 1 - (best & 1) : best >> 2,
             best_ms * 1000.f / reps);
   return launch_idx<P>(best, p, p1, M, N, Z, ws, wsf, st, defer);  // candidates ran their combine in place
+}
+
+// Weight gradients of dense layers, dW[N_out, K_in] = dz^T x, as one launch (16-row tiles, K over the four
+// wavefronts, no split over workgroups: K is the batch size).
+int strided_gemm_batch_mm(const StridedGemmParams* probs, int n, hipStream_t st) {
+  using P = Strided<true, true>;
+  constexpr int BM = 16, BN = 64, BK = 64, KW = 4;
+  for (int base = 0; base < n; base += kMaxBatch) {
+    const int cnt = n - base < kMaxBatch ? n - base : kMaxBatch;
+    Batch<P> bp;
+    int tiles = 0;
+    for (int g = 0; g < kMaxBatch; ++g) {
+      bp.p[g] = probs[base + (g < cnt ? g : 0)];
+      bp.p[g].sk.partial = nullptr;
+      bp.p[g].sk.splits = 1;
+      bp.p[g].sk.kchunk = (bp.p[g].K + BK - 1) / BK * BK;
+      bp.first[g] = tiles;
+      bp.mt[g] = cdiv(bp.p[g].M, BM);
+      bp.nt[g] = cdiv(bp.p[g].N, BN);
+      if (g < cnt) tiles += bp.mt[g] * bp.nt[g];
+    }
+    bp.first[kMaxBatch] = tiles;
+    for (int g = cnt; g < kMaxBatch; ++g) bp.first[g] = tiles;
+    bp.n = cnt;
+    if (t_matrix_bf16)
+      hipLaunchKernelGGL((igemm_batch_kernel<P, BM, BN, BK, KW, true>), dim3(tiles), dim3(256), 0, st, bp);
+    else
+      hipLaunchKernelGGL((igemm_batch_kernel<P, BM, BN, BK, KW, false>), dim3(tiles), dim3(256), 0, st, bp);
+    const int rc = check_launch("igemm_batch");
+    if (rc) return rc;
+  }
+  return LSHM_OK;
 }
 
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {

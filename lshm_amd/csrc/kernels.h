@@ -7,6 +7,14 @@
 
 namespace lshm {
 
+// ---- collectives (comm.hip; RCCL bound at run time)
+}  // namespace lshm
+struct lshm_comm;
+namespace lshm {
+int comm_allreduce_segments(lshm_comm* c, float* const* bufs, const size_t* ns, int nseg, double* tail, size_t ntail,
+                            hipStream_t st);
+int comm_world(const lshm_comm* c);
+
 // ---- implicit-GEMM problem descriptors (igemm.hip) -------------------------
 struct SplitK { float* partial; int splits; int kchunk; };  // filled in by the launcher
 struct Conv2dFwdParams {   // y = act(conv2d_k4s2p1(x, w) + bias) [* elu'(dact)]
@@ -88,6 +96,8 @@ struct ChanJob {    // partial[chunk*C + c] = sum over a chunk of {dz[b, c, :]} 
 struct GradJobs {
   std::vector<ChanJob> chan;
   std::vector<SumJob> sums;
+  std::vector<StridedGemmParams> dense;  // dense-layer weight gradients waiting for their one shared launch
+  bool batch_dense = false;              // linear_wgrad parks its GEMM here instead of launching it
   float* scratch = nullptr;
   size_t cap = 0, used = 0;
   float* take(size_t n) {
@@ -101,6 +111,7 @@ struct GradJobs {
   bool add_channel_sum(const float* dz, long bs, int B, int C, long HW, float* db, int accumulate);
 };
 int grad_jobs_finish(GradJobs& jobs, hipStream_t st);
+int grad_jobs_launch_dense(GradJobs& jobs, hipStream_t st);  // the parked dense weight gradients, one launch
 
 // ws / wsf: optional split-K scratch (null: never split)
 // p1 (optional): a second problem of identical shape run in the same launch (ws is split in two)
@@ -115,6 +126,8 @@ int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t 
 // defer (weight-gradient problems only): a split launch leaves its slabs in ws and queues the combine
 int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
                  hipStream_t st, const StridedGemmParams* p1 = nullptr, GradJobs* defer = nullptr);
+// n independent m-fast x n-fast problems without bias / activation / split-K (dense weight gradients) in one launch
+int strided_gemm_batch_mm(const StridedGemmParams* probs, int n, hipStream_t st);
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups);
 // streaming kernels for the outer 1-D layers (conv1d_stream.hip); conv1d_fwd / conv1d_dgrad use them when they apply
 bool conv1d_stream_supported(const Conv1dFwdParams& p);
@@ -296,8 +309,9 @@ int aug_loss_fwd_bwd(const float* Z, long ldz, int rows, int D, int bpb, int bat
 
 // ---- LOFAR minibatch patch pipeline (patches.hip) -----------------------------
 size_t patches_workspace_floats();
-int patches_from_vis(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int P, float clampv,
-                     int normalize, float* y, double* mean_std, float* ws, hipStream_t st);
+int patches_from_vis(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int P, int NC, float clampv,
+                     int normalize, float* y, double* mean_std, double* moments, float* ws, hipStream_t st);
+int patches_normalize_moments(float* y, long n, const double* moments, hipStream_t st);
 
 // ---- batched 2D FFT feature op (fft.hip) ------------------------------------
 int fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv,

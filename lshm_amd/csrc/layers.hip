@@ -334,9 +334,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
   __syncthreads();
   if (part == 0 && n < N) db[n] = (red[nl] + red[64 + nl]) + (red[128 + nl] + red[192 + nl]);
 }
+int grad_jobs_launch_dense(GradJobs& jobs, hipStream_t st) {
+  if (jobs.dense.empty()) return LSHM_OK;
+  const int rc = strided_gemm_batch_mm(jobs.dense.data(), (int)jobs.dense.size(), st);
+  jobs.dense.clear();
+  return rc;
+}
 int linear_wgrad(const LinWgradIO& io, long ldx, long lddz, int B, int K, int N, float* ws, size_t wsf,
                  hipStream_t st, const LinWgradIO* io2, GradJobs* defer) {
-  if (defer) {
+  if (defer && !defer->batch_dense) {
     wsf = (igemm_workspace_floats(N, K, B, 1) + 16) * (io2 ? 2 : 1);
     ws = defer->take(wsf);
     if (!ws) { set_last_error("linear wgrad: deferred scratch exhausted"); return LSHM_ERR_WORKSPACE; }
@@ -344,7 +350,15 @@ int linear_wgrad(const LinWgradIO& io, long ldx, long lddz, int B, int K, int N,
   StridedGemmParams p{io.dz, io.x, nullptr, io.dw, nullptr, 1, lddz, ldx, 1, K, 1, 0, 0, 0, N, K, B, {},
                       nullptr, 0, 0};
   int rc;
-  if (io2) {
+  if (defer && defer->batch_dense) {  // launched together with the other dense layers (grad_jobs_launch_dense)
+    defer->dense.push_back(p);
+    if (io2) {
+      StridedGemmParams q = p;
+      q.a = io2->dz; q.b = io2->x; q.c = io2->dw;
+      defer->dense.push_back(q);
+    }
+    rc = LSHM_OK;
+  } else if (io2) {
     StridedGemmParams q = p;
     q.a = io2->dz; q.b = io2->x; q.c = io2->dw;
     rc = strided_gemm(p, true, true, ws, wsf, st, &q, defer);

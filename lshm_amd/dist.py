@@ -39,6 +39,52 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     return rank, world, local, dist.group.WORLD
 
 
+class Communicator:
+    """RCCL communicator behind the C ABI (``lshm_comm_*``): collectives are enqueued on the caller's HIP
+    stream by the library itself, so an engine can run them inside its closure, overlapped with the tail of
+    the backward (``KHarmonicTrainer(process_group=...)`` attaches one when the group's backend is nccl).
+    The 128-byte unique id travels through ``torch.distributed`` (any backend)."""
+
+    def __init__(self, group=None, device: Optional[torch.device] = None):
+        import ctypes as C
+        from . import _lib as L
+        self.lib = L.load()
+        if not self.lib.lshm_comm_available():
+            raise RuntimeError("RCCL is not available in this process")
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        buf = C.create_string_buffer(128)
+        if self.rank == 0:
+            L.check(self.lib.lshm_comm_unique_id(buf), "comm_unique_id")
+        box = [buf.raw]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        h = C.c_void_p()
+        with L.on_device(self.device):
+            L.check(self.lib.lshm_comm_init(box[0], self.rank, self.world, C.byref(h)), "comm_init")
+        self.handle = h
+
+    def allreduce_flat(self, buf: Optional[torch.Tensor], tail: Optional[torch.Tensor] = None):
+        """In place SUM over ranks of a float32 buffer and / or a float64 tail, one fused launch."""
+        from . import _lib as L
+        with L.on_device(self.device):
+            L.check(self.lib.lshm_comm_allreduce_flat(self.handle, L.ptr(buf), 0 if buf is None else buf.numel(),
+                                                      L.ptr(tail), 0 if tail is None else tail.numel(),
+                                                      L.stream(self.device)), "comm_allreduce_flat")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lshm_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def allreduce_closure(grads: torch.Tensor, terms: torch.Tensor, group=None) -> None:
     """The two collectives of one closure: SUM over ranks of the flat gradient arena (which
     includes dM of the K-harmonic term) and of the loss-term vector."""

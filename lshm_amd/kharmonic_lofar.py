@@ -18,6 +18,7 @@ closure (``torch.distributed``, backend ``nccl`` == RCCL on ROCm).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Dict, Iterable, Optional, Sequence, Tuple
 
@@ -140,6 +141,17 @@ class KHarmonicTrainer:
         self.x = torch.zeros(img, device=dev)
         self.uv = torch.zeros((self.B, 2), device=dev)
         self.y = [torch.zeros(self.x.numel(), device=dev) for _ in range(3)]
+        # data parallelism: with an nccl (= RCCL) group the collectives run inside the engine's closure, on its
+        # own streams (lshm_engine_set_comm); other backends (gloo in the CPU-rehearsal tests) and
+        # LSHM_DP_TORCH=1 go through torch.distributed after the closure
+        self._comm = None
+        if self.world > 1 and os.environ.get("LSHM_DP_TORCH") != "1":
+            import torch.distributed as dist
+            if dist.get_backend(process_group) == "nccl" and self.lib.lshm_comm_available():
+                from .dist import Communicator
+                self._comm = Communicator(process_group, self.device)
+                with L.on_device(self.device):
+                    L.check(self.lib.lshm_engine_set_comm(self._h, self._comm.handle), "engine_set_comm")
         self._graph = None
         self._saved_forward = False  # the workspace holds the forward of the current params / x / uv
         self._recon_ready = False    # ... and the reconstruction terms of the next closure (share_recon_pass)
@@ -153,6 +165,8 @@ class KHarmonicTrainer:
             if getattr(self, "_h", None):
                 self.lib.lshm_engine_destroy(self._h)
                 self._h = None
+            if getattr(self, "_comm", None) is not None:
+                self._comm.close()
         except Exception:
             pass
 
@@ -280,7 +294,7 @@ class KHarmonicTrainer:
                     "engine_forward_backward")
             self._saved_forward = False  # whatever follows (optimiser, line search) moves the parameters
             self._recon_ready = False
-            if self.world > 1:
+            if self.world > 1 and self._comm is None:
                 from .dist import allreduce_closure
                 allreduce_closure(self.grads, self.terms, self.pg)
             if self._mask is not None:
@@ -379,7 +393,7 @@ class KHarmonicTrainer:
                 L.check(self.lib.lshm_engine_forward_loss(
                     self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
                     P(self.terms), P(self.ws), self.ws_floats, self._stream()), "engine_forward_loss")
-                if self.world > 1:
+                if self.world > 1 and self._comm is None:
                     import torch.distributed as dist
                     dist.all_reduce(self.terms, group=self.pg)
         return self.terms[8]

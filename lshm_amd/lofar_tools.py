@@ -29,9 +29,13 @@ def torch_fftshift(real, imag):
 
 
 def patches_from_visibilities(vis: torch.Tensor, scale: torch.Tensor, patch_size: int = 128,
-                              normalize_data: bool = False, clamp: float = 1e3):
+                              normalize_data: bool = False, clamp: float = 1e3, num_channels: int = 4,
+                              process_group=None):
     """vis (nb, ntime, nfreq, 4, 2) int8 and scale (nb, nfreq, 4) fp32, both on the device ->
-    (patchx, patchy, y (patchx*patchy*nb, 4, P, P), mean, std)."""
+    (patchx, patchy, y (patchx*patchy*nb, num_channels, P, P), [mean, std] as a device tensor).
+    process_group: data-parallel job whose ranks each hold some baselines of ONE minibatch -- the
+    normalisation then uses the moments of the whole minibatch (sum, sum of squares and count are
+    all-reduced), exactly what the single process of upstream computes at :190-193."""
     if not vis.is_cuda or vis.dtype != torch.int8:
         raise RuntimeError("vis must be an int8 tensor on a HIP device")
     L.require_device(scale)
@@ -42,14 +46,28 @@ def patches_from_visibilities(vis: torch.Tensor, scale: torch.Tensor, patch_size
     P = patch_size
     T, F = max(ntime, P), max(nfreq, P)
     px, py = (T - P) // (P // 2) + 1, (F - P) // (P // 2) + 1
+    if num_channels not in (4, 8):
+        raise AssertionError("num_channels==4 or num_channels==8")  # upstream :70
     lib = L.load()
-    y = torch.empty((px * py * nb, 4, P, P), device=vis.device, dtype=torch.float32)
+    y = torch.empty((px * py * nb, num_channels, P, P), device=vis.device, dtype=torch.float32)
     ms = torch.empty(2, device=vis.device, dtype=torch.float64)
+    mom = torch.empty(3, device=vis.device, dtype=torch.float64)
     ws = torch.empty(lib.lshm_patches_workspace_floats(), device=vis.device, dtype=torch.float32)
+    world = 1
+    if process_group is not None:
+        import torch.distributed as dist
+        world = dist.get_world_size(process_group)
+    local_norm = bool(normalize_data) and world == 1
     with L.on_device(vis.device):
-        L.check(lib.lshm_patches_from_vis(L.ptr(vis), L.ptr(scale), nb, ntime, nfreq, P, float(clamp),
-                                          int(normalize_data), L.ptr(y), L.ptr(ms), L.ptr(ws), L.stream()),
+        L.check(lib.lshm_patches_from_vis_ex(L.ptr(vis), L.ptr(scale), nb, ntime, nfreq, P, num_channels, float(clamp),
+                                             int(local_norm), L.ptr(y), L.ptr(ms), L.ptr(mom), L.ptr(ws), L.stream()),
                 "patches_from_vis")
+        if normalize_data and world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(mom, op=dist.ReduceOp.SUM, group=process_group)   # [sum, sum of squares, count]
+            L.check(lib.lshm_patches_normalize(L.ptr(y), y.numel(), L.ptr(mom), L.stream()), "patches_normalize")
+            mean = mom[0] / mom[2]
+            ms = torch.stack((mean, ((mom[1] - mom[2] * mean * mean) / (mom[2] - 1)).clamp_min(0).sqrt()))
     return px, py, y, ms
 
 
@@ -70,14 +88,12 @@ def uv_wavelengths(xyz: np.ndarray, baselines: np.ndarray, sel: np.ndarray, star
     return uv
 
 
-def minibatch_from_sap(sap, info, batch_size=2, patch_size=32, normalize_data=False, num_channels=4,
-                       uvdist=False, device="cuda", baselinelist=None):
+def minibatch_from_sap(sap, info, batch_size=2, patch_size=32, normalize_data=False, num_channels=8,
+                       uvdist=False, device="cuda", baselinelist=None, process_group=None):
     """get_data_minibatch on an already opened SAP group (h5py group or a dict of numpy arrays with the
     keys 'visibilities', 'visibility_scale_factors', 'central_frequencies', 'baselines',
     'antenna_locations'/'XYZ'; info['start_time'][0] bytes).  Baselines are drawn with
     np.random.randint exactly as upstream (:88) unless given.  Returns (patchx, patchy, y[, uv1])."""
-    if num_channels != 4:
-        raise NotImplementedError("the training path uses num_channels=4 (XX, YY real/imag)")
     g, h = sap["visibilities"], sap["visibility_scale_factors"]
     nbase = g.shape[0]
     if baselinelist is None:
@@ -86,7 +102,8 @@ def minibatch_from_sap(sap, info, batch_size=2, patch_size=32, normalize_data=Fa
     vis = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(g[int(b)]) for b in baselinelist]))).to(device)
     sc = torch.from_numpy(np.ascontiguousarray(np.stack([np.asarray(h[int(b)]) for b in baselinelist]),
                                                dtype=np.float32)).to(device)
-    px, py, y, _ = patches_from_visibilities(vis, sc, patch_size, normalize_data)
+    px, py, y, _ = patches_from_visibilities(vis, sc, patch_size, normalize_data, num_channels=num_channels,
+                                             process_group=process_group)
     if not uvdist:
         return px, py, y
     frq = np.asarray(sap["central_frequencies"])

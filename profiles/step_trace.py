@@ -8,7 +8,9 @@ files = glob.glob(d + "/*kernel_trace.csv") + glob.glob(d + "/*/*kernel_trace.cs
 rows = list(csv.DictReader(open(files[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
-mu = [i for i, r in enumerate(rows) if 'multiplier_update_kernel' in r['Kernel_Name']]
+mu = [i for i, r in enumerate(rows) if 'multiplier_update_kernel' in r['Kernel_Name'] or 'recon_kernel<true' in r['Kernel_Name']]
+if 'recon_kernel<true' in rows[mu[-1]]['Kernel_Name']:  # the shared pass is followed by its 7-way sum
+    mu = [i + 1 for i in mu]
 # a step = everything after the previous multiplier_update up to and including this one
 end = mu[-1] + 1
 start = mu[-2] + 1

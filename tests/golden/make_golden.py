@@ -217,15 +217,16 @@ def main():
     fake.File = lambda filename, mode="r": {"measurement": {"saps": {"0": sap}, "info": info}}
     lt.h5py = fake
     g8 = {}
-    for normalize in (False, True):
-        np.random.seed(123)
-        px, py, yy8, uv8 = lt.get_data_minibatch(["synthetic.h5"], ["0"], batch_size=3, patch_size=128,
-                                                  normalize_data=normalize, num_channels=4, uvdist=True)
-        tag = "norm" if normalize else "raw"
-        g8[f"{tag}/patchxy"] = np.array([px, py])
-        put(g8, f"{tag}/y", yy8)
-        g8[f"{tag}/y_first"] = yy8[0, :, 60:64, 60:64].numpy().copy()
-        g8[f"{tag}/uv"] = uv8.numpy().copy()
+    for nchan, suffix in ((4, ""), (8, "8")):  # 8: the reference's default, all four polarisations (:101-111)
+        for normalize in (False, True):
+            np.random.seed(123)
+            px, py, yy8, uv8 = lt.get_data_minibatch(["synthetic.h5"], ["0"], batch_size=3, patch_size=128,
+                                                      normalize_data=normalize, num_channels=nchan, uvdist=True)
+            tag = ("norm" if normalize else "raw") + suffix
+            g8[f"{tag}/patchxy"] = np.array([px, py])
+            put(g8, f"{tag}/y", yy8)
+            g8[f"{tag}/y_first"] = yy8[0, :, 60:64, 60:64].numpy().copy()
+            g8[f"{tag}/uv"] = uv8.numpy().copy()
     np.savez_compressed(os.path.join(HERE, "minibatch.npz"), **g8)
 
     # ---------------- (4) full closure + 3 Adam steps ---------------------
