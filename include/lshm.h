@@ -156,6 +156,12 @@ int lshm_khm_mean_distances(const float* X, long ldx, const float* M, int N, int
                             float* dist, float* workspace, size_t workspace_floats,
                             lshm_stream_t stream);
 
+/* epilogues of that distance vector (K <= 64), either output may be NULL:
+ * argmin[0] (device int) = index of the smallest distance, the cluster id of a baseline
+ *                          (torch.min(dist.view(Kc,1),0), src/evaluate_clustering.py:116-119);
+ * prob[K] = softmax(-dist / mean(dist)), the node labels of src/train_graph_stat.py:206-210 */
+int lshm_khm_assign(const float* dist, int K, int* argmin, float* prob, lshm_stream_t stream);
+
 /* ---- Kmeans.cluster_similarity                                  src/lofar_models.py:214-229 */
 int lshm_cluster_sim_fwd_bwd(const float* M, int K, int D, float eps, float gscale, double* loss,
                              float* dM, int accumulate, lshm_stream_t stream);

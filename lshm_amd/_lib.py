@@ -73,6 +73,7 @@ _SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lshm_khm_mean_distances": (c_int, [c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                         c_void_p, c_size_t, c_void_p]),
+    "lshm_khm_assign": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "lshm_cluster_sim_fwd_bwd": (c_int, [c_void_p, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_int,
                                          c_void_p]),
     "lshm_aug_loss_fwd_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_int, c_int, c_float, c_void_p,

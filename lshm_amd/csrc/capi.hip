@@ -152,6 +152,10 @@ int lshm_khm_mean_distances(const float* X, long ldx, const float* M, int N, int
   REQUIRE(dist, "khm_mean_distances: null output");
   return khm_mean_distances(X, ldx, M, N, D, K, p, dist, ws, wsf, ST(s));
 }
+int lshm_khm_assign(const float* dist, int K, int* argmin, float* prob, lshm_stream_t s) {
+  REQUIRE(dist && (argmin || prob), "khm_assign: null pointer");
+  return dist_epilogue(dist, K, argmin, prob, ST(s));
+}
 int lshm_cluster_sim_fwd_bwd(const float* M, int K, int D, float eps, float gscale, double* loss,
                              float* dM, int accumulate, lshm_stream_t s) {
   return cluster_sim_fwd_bwd(M, K, D, eps, gscale, loss, dM, accumulate, ST(s));

@@ -307,6 +307,8 @@ int aug_loss_fwd_bwd(const float* Z, long ldz, int rows, int D, int bpb, int bat
                      float gscale, double* loss, float* dZ, long lddz, int accumulate,
                      hipStream_t st);
 
+int dist_epilogue(const float* dist, int K, int* argmin, float* prob, hipStream_t st);
+
 // ---- LOFAR minibatch patch pipeline (patches.hip) -----------------------------
 size_t patches_workspace_floats();
 int patches_from_vis(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int P, int NC, float clampv,

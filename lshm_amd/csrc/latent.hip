@@ -231,4 +231,40 @@ int aug_loss_fwd_bwd(const float* Z, long ldz, int rows, int D, int bpb, int bat
   return check_launch("aug_loss_sum");
 }
 
+// Epilogues of the per-baseline distance vector (the downstream consumers of Kmeans' distances):
+//   argmin[0] = index of the smallest dist (first one on ties: torch.min, src/evaluate_clustering.py:116-119)
+//   prob[k]   = softmax_k(-dist[k] / mean(dist))   (src/train_graph_stat.py:206-210)
+// K <= 64: one wavefront, lane k holds dist[k].
+__global__ __launch_bounds__(64) void dist_epilogue_kernel(const float* __restrict__ dist, int K, int* __restrict__ argmin,
+                                                           float* __restrict__ prob) {
+  const int k = threadIdx.x;
+  const float d = k < K ? dist[k] : 0.f;
+  const float mean = wave_sum(d) / (float)K;
+  // arg-min with the lowest index winning ties; a NaN distance never wins (as torch.min would propagate NaN,
+  // the caller sees it in dist itself)
+  float bv = k < K ? d : __builtin_inff();
+  int bi = k < K ? k : 0x7fffffff;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const float ov = __shfl_xor(bv, off, 64);
+    const int oi = __shfl_xor(bi, off, 64);
+    if (ov < bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  if (argmin && k == 0) argmin[0] = bi;
+  if (prob) {
+    const float z = k < K ? -d / mean : -__builtin_inff();
+    float zmax = z;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) zmax = fmaxf(zmax, __shfl_xor(zmax, off, 64));
+    const float e = k < K ? expf(z - zmax) : 0.f;
+    const float tot = wave_sum(e);
+    if (k < K) prob[k] = e / tot;
+  }
+}
+int dist_epilogue(const float* dist, int K, int* argmin, float* prob, hipStream_t st) {
+  if (!dist || K < 1 || K > 64) { set_last_error("dist_epilogue: K must be 1..64"); return LSHM_ERR_ARG; }
+  hipLaunchKernelGGL(dist_epilogue_kernel, dim3(1), dim3(64), 0, st, dist, K, argmin, prob);
+  return check_launch("dist_epilogue");
+}
+
 }  // namespace lshm

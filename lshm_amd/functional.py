@@ -329,6 +329,19 @@ def khm_mean_distances(X, M, p):
 
 
 @_on_tensor_device
+def khm_assign(dist: torch.Tensor):
+    """(argmin index (0-dim int64 tensor), softmax(-dist / dist.mean())) of a distance vector (K <= 64):
+    the cluster id of src/evaluate_clustering.py:116-119 and the soft labels of src/train_graph_stat.py:206-210."""
+    L.require_device(dist)
+    dist = dist.detach().contiguous()
+    K = dist.numel()
+    idx = torch.empty(1, device=dist.device, dtype=torch.int32)
+    prob = torch.empty(K, device=dist.device, dtype=torch.float32)
+    L.check(L.load().lshm_khm_assign(L.ptr(dist), K, L.ptr(idx), L.ptr(prob), L.stream()), "khm_assign")
+    return idx[0].to(torch.int64), prob
+
+
+@_on_tensor_device
 def fft_features(r: torch.Tensor, clamp: float = 10.0) -> torch.Tensor:
     """fftn(dim=(2,3), ortho) -> fftshift -> cat(real, imag) -> clamp (Demo.ipynb:169-175)."""
     L.require_device(r)

@@ -144,3 +144,11 @@ class Kmeans(nn.Module):
         """dist[k] = mean_n ||X_n - M_k||^p, the per-baseline statistic of
         src/evaluate_clustering.py:111-115."""
         return Fh.khm_mean_distances(X, self.M, self.p)
+
+    def assign(self, X):
+        """(dist (K,), cluster id, soft labels) of the patches X of ONE baseline: dist as mean_distances,
+        id = argmin_k dist (src/evaluate_clustering.py:111-119), labels = softmax(-dist / dist.mean())
+        (src/train_graph_stat.py:206-210)."""
+        dist = self.mean_distances(X)
+        idx, prob = Fh.khm_assign(dist)
+        return dist, idx, prob

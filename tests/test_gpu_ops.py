@@ -215,6 +215,35 @@ def test_khm_ragged_sizes_and_offline_partials():
         assert rel_err(dist, dref) < 1e-5
 
 
+@pytest.mark.parametrize("K", [1, 4, 10, 37, 64])
+def test_distance_epilogues_argmin_and_softmax(K):
+    """Cluster id = torch.min over the mean distances (src/evaluate_clustering.py:111-119) and the soft labels
+    softmax(-dist / dist.mean()) (src/train_graph_stat.py:206-210), written here with upstream's own torch
+    expressions on the CPU."""
+    from lshm_amd.lofar_models import Kmeans
+    D, p, N = 256, 4, 9
+    X = 0.8 * O.closed_form((N, D), "asg:X", 1.0, 0.4142) + 0.3
+    M = 0.5 + 0.5 * O.closed_form((K, D), f"asg:M{K}", 1.0, 0.618)
+    mod = Kmeans(latent_dim=D, K=K, p=p)
+    mod.load_state_dict({"M": M})
+    mod = mod.to(DEV)
+    dist, idx, prob = mod.assign(X.to(DEV))
+    dref = torch.zeros(K, dtype=torch.float64)
+    for ck in range(K):
+        for cn in range(N):
+            dref[ck] = dref[ck] + torch.sum(torch.pow(torch.linalg.norm(X[cn, :].double() - M[ck, :].double(), 2), p))
+    dref = dref / N
+    (values, indices) = torch.min(dref.view(K, 1), 0)
+    assert rel_err(dist, dref) < 1e-5
+    assert int(idx) == int(indices[0])
+    assert rel_err(prob, torch.softmax(-dref / dref.mean(), 0)) < 1e-5 and abs(float(prob.sum()) - 1.0) < 1e-6
+    # ties: the first index wins, as torch.min does
+    Fh = _F()
+    tie = torch.full((K,), 2.0, device=DEV)
+    i2, p2 = Fh.khm_assign(tie)
+    assert int(i2) == 0 and rel_err(p2, torch.full((K,), 1.0 / K)) < 1e-6
+
+
 def test_kmeans_module_offline_update_and_state_dict():
     from lshm_amd.lofar_models import Kmeans
     mod = Kmeans(latent_dim=256, K=10, p=4)

@@ -234,11 +234,11 @@ def test_step_with_k64_clusters():
 # ---------------------------------------------------------------------------------------------
 # full-size (BASELINE.json configs[1]: B=256, K=10) checks through size-independent properties
 # ---------------------------------------------------------------------------------------------
-def _full_trainer(world=1, batch=256, bs=None):
+def _full_trainer(world=1, batch=256, bs=None, K=10, precision="fp32"):
     from lshm_amd import KHarmonicTrainer, TrainConfig
     import ctypes as C
     from lshm_amd import _lib as L
-    tr = KHarmonicTrainer(TrainConfig(Kc=10), batch=batch, batch_per_bline=8,
+    tr = KHarmonicTrainer(TrainConfig(Kc=K, matrix_precision=precision), batch=batch, batch_per_bline=8,
                           default_batch=bs if bs is not None else batch // 8, device=DEV)
     if world != 1:
         tr._sc.world = world
@@ -250,15 +250,18 @@ def _full_trainer(world=1, batch=256, bs=None):
     return tr
 
 
-def test_full_size_step_is_bitwise_reproducible_and_finite():
+@pytest.mark.parametrize("K,precision", [(10, "fp32"), (64, "fp32"), (10, "bf16")],
+                         ids=["K10", "K64-config5", "bf16-config3"])
+def test_full_size_step_is_bitwise_reproducible_and_finite(K, precision):
     """Deterministic reductions everywhere (no float atomics): two runs of 3 iterations at
-    B=256 give bit-identical parameters, multipliers and loss terms."""
+    B=256 give bit-identical parameters, multipliers and loss terms -- at K=10 (configs[1]), at config 5's
+    K=64 and with configs[2]'s bf16 matrix operands."""
     g = torch.Generator().manual_seed(7)
     x = torch.randn(256, 4, 128, 128, generator=g)
     uv = 1000.0 * torch.randn(256, 2, generator=g)
     outs = []
     for _ in range(2):
-        tr = _full_trainer()
+        tr = _full_trainer(K=K, precision=precision)
         tr.new_minibatch(x.to(DEV), uv.to(DEV))
         for _ in range(3):
             tr.step()
@@ -297,14 +300,18 @@ def test_full_size_two_stream_schedule_equals_single_stream():
         assert torch.equal(a, b)
 
 
-def test_full_size_batch_additivity():
+@pytest.mark.parametrize("K,precision,tol", [(10, "fp32", 5e-5), (64, "fp32", 5e-5), (10, "bf16", 5e-5)],
+                         ids=["K10", "K64-config5", "bf16-config3"])
+def test_full_size_batch_additivity(K, precision, tol):
     """Every loss term is a batch mean (or batch independent): the world=2 shares of the two
-    half-batches of a B=256 minibatch sum to the B=256 result (gradients and the 9 terms)."""
+    half-batches of a B=256 minibatch sum to the B=256 result (gradients and the 9 terms).  The property does
+    not depend on the operand precision: with bf16 operands each patch's contribution is rounded the same way
+    in the half and in the full batch."""
     g = torch.Generator().manual_seed(11)
     x = torch.randn(256, 4, 128, 128, generator=g)
     uv = 1000.0 * torch.randn(256, 2, generator=g)
     y = [0.01 * torch.randn(x.numel(), generator=g) for _ in range(3)]
-    full = _full_trainer()
+    full = _full_trainer(K=K, precision=precision)
     full.new_minibatch(x.to(DEV), uv.to(DEV))
     for k in range(3):
         full.y[k].copy_(y[k].to(DEV))
@@ -312,7 +319,7 @@ def test_full_size_batch_additivity():
     gsum = torch.zeros_like(full.grads)
     tsum = torch.zeros(9, device=DEV, dtype=torch.float64)
     for r in range(2):
-        half = _full_trainer(world=2, batch=128, bs=16)
+        half = _full_trainer(world=2, batch=128, bs=16, K=K, precision=precision)
         half.params.copy_(full.params)
         sl = slice(r * 128, (r + 1) * 128)
         half.new_minibatch(x[sl].to(DEV), uv[sl].to(DEV))
@@ -322,7 +329,7 @@ def test_full_size_batch_additivity():
         gsum += half.grads
         tsum += half.terms[:9]
         del half
-    assert rel_err(gsum, full.grads) < 5e-5
+    assert rel_err(gsum, full.grads) < tol
     np.testing.assert_allclose(tsum.cpu().numpy(), full.terms[:9].cpu().numpy(), rtol=5e-6)
 
 
@@ -600,3 +607,49 @@ def test_trainer_on_a_device_that_is_not_current():
         torch.cuda.synchronize(d)
         outs.append(tr.params.cpu())
     assert torch.cuda.current_device() == 0 and torch.equal(outs[0], outs[1])
+
+
+def test_config5_composition_loader_k64_lbfgs():
+    """BASELINE.json configs[4] composed once: the loader's minibatch (int8 visibilities of a synthetic SAP ->
+    3 x 3 overlapping 128-patches per baseline, normalised, u,v in wavelengths) -> new_minibatch -> one ADMM
+    iteration with LBFGSNew(history 7, line search, batch mode) at K=64 clusters, bpb=9 -- against the same
+    optimiser class driven by the CPU oracle on the same tensors."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    from lshm_amd.lbfgsnew import LBFGSNew
+    from lshm_amd.lofar_tools import minibatch_from_sap
+    from tests.h5_fixture import make_sap
+    sap, info = make_sap(nbase=4, ntime=256, nfreq=256)
+    px, py, xb, uvb = minibatch_from_sap(sap, info, batch_size=2, patch_size=128, normalize_data=True, num_channels=4,
+                                         uvdist=True, baselinelist=[1, 3])
+    assert (px, py) == (3, 3) and xb.shape == (18, 4, 128, 128) and uvb.shape == (18, 2)
+    K, bpb, bs = 64, px * py, 2
+    ocfg = O.StepConfig(K=K, bpb=bpb, batch_size=bs)
+    params, M = O.make_params(ocfg)
+    tr = KHarmonicTrainer(TrainConfig(Kc=K), batch=18, batch_per_bline=bpb, default_batch=bs, device=DEV)
+    tr.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
+    tr.new_minibatch(xb, uvb)
+    opt = tr.make_lbfgs(history_size=7, max_iter=2, line_search_fn=True, batch_mode=True)
+    tr.step_lbfgs(opt)
+    t = tr.read_terms()
+    assert t["nonfinite"] == 0.0
+    x, uv = xb.cpu(), uvb.cpu()
+    leaves = O.flat_leaves(params, M)
+    for l in leaves:
+        l.requires_grad_(True)
+    y = [torch.zeros(x.numel()) for _ in range(3)]
+    oopt = LBFGSNew(leaves, history_size=7, max_iter=2, line_search_fn=True, batch_mode=True)
+
+    def closure():
+        if torch.is_grad_enabled():
+            oopt.zero_grad()
+        total, _ = O.closure_losses(params, M, x, uv, y, ocfg)
+        if total.requires_grad:
+            total.backward()
+        return total
+    oopt.step(closure)
+    names = [f"{g}.{k}" for g in O.GROUPS for k in params[g]] + ["mod.M"]
+    for n, l in zip(names, leaves):
+        assert rel_err(tr.view(n), l.detach()) < 5e-4, n
+    y_new = O.multiplier_update(params, x, uv, y, ocfg)
+    for k in range(3):
+        assert rel_err(tr.y[k], y_new[k]) < 2e-3
