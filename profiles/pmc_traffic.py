@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""HBM traffic per launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected separately,
-as MI355X_MICROARCH.md prescribes).  gfx950 correction: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
-Usage: pmc_traffic.py FETCH_DIR WRITE_DIR OUT.json"""
+"""HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, as
+MI355X_MICROARCH.md prescribes).  gfx950 correction: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024.
+
+Every profiled command gets a label and its kernels are keyed "<kernel> @<label>", so a kernel that runs at two
+shapes (the K-harmonic kernel: B=256 inside the step, N=2^20 in the roofline demonstration) is never averaged
+across them.  The label `step` (bench.py --no-roofline ...) also yields the traffic of one whole ADMM iteration:
+all bytes of the run divided by its number of iterations (= adam_kernel launches).
+
+Usage: pmc_traffic.py OUT.json LABEL:FETCH_DIR:WRITE_DIR [LABEL:FETCH_DIR:WRITE_DIR ...]"""
 import csv, glob, json, sys
 from collections import defaultdict
 
@@ -17,29 +23,23 @@ def collect(d, counter):
     return acc
 
 
-fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
-ALGO = {  # algorithmic bytes per launch at B=256
-    "tconv1d_stream_kernel<8, 4, false>": 201326592,
-    "conv1d_stream_kernel<4, 8, true>": 201326592,
-    "tconv2d_direct_kernel<8, 4, 4, 64>": 100663296,
-    "conv2d_direct_kernel<4, 8, 4, 64>": 100663296,
-    "conv2d_wgrad_direct_kernel<8, 4, 4, 64>": 100663296,
-    "conv1d_wgrad_direct_kernel<8, 4, 256>": 201326592,
-    "recon_kernel": 671088640,
-    "multiplier_update_kernel": 671088640,
-}
-out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of "
-                 "`python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline` on MI355X; per-launch averages; gfx950 "
-                 "correction traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B (MI355X_MICROARCH.md HBM section)",
+out = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes per labelled command on "
+                 "MI355X; per-launch averages; gfx950 correction traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024 B "
+                 "(MI355X_MICROARCH.md, HBM section)",
        "kernels": {}}
-for k in sorted(set(fetch) & set(write)):
-    if "at::" in k:
-        continue
-    f, w = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k])
-    e = {"launches": len(fetch[k]), "FETCH_SIZE_KB": round(f), "WRITE_SIZE_KB": round(w),
-         "traffic_bytes_per_launch": int((2 * f + w) * 1024)}
-    if k in ALGO:
-        e["algorithmic_bytes_per_launch"] = ALGO[k]
-    out["kernels"][k] = e
-json.dump(out, open(sys.argv[3], "w"), indent=1)
-print(f"{len(out['kernels'])} kernels -> {sys.argv[3]}")
+for spec in sys.argv[2:]:
+    label, fdir, wdir = spec.split(":")
+    fetch, write = collect(fdir, "FETCH_SIZE"), collect(wdir, "WRITE_SIZE")
+    tot = 0.0
+    for k in sorted(set(fetch) & set(write)):
+        f, w = sum(fetch[k]) / len(fetch[k]), sum(write[k]) / len(write[k])
+        if "at::" not in k and "rocclr" not in k:
+            out["kernels"][f"{k} @{label}"] = {"launches": len(fetch[k]), "FETCH_SIZE_KB": round(f), "WRITE_SIZE_KB": round(w),
+                                               "traffic_bytes_per_launch": int((2 * f + w) * 1024)}
+        tot += (2 * sum(fetch[k]) * len(write[k]) / len(fetch[k]) + sum(write[k])) * 1024 if k in write else 0.0
+    if label == "step":
+        nsteps = len(fetch.get("adam_kernel", [])) or 1
+        out["step"] = {"iterations": nsteps, "traffic_bytes": int(tot / nsteps),
+                       "note": "every launch of the run (warm-up included) / adam_kernel launches"}
+json.dump(out, open(sys.argv[1], "w"), indent=1)
+print(f"{len(out['kernels'])} kernel entries -> {sys.argv[1]}")
