@@ -377,20 +377,29 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
   // bias_from: 0 none, 1 bias gradient = sum of `small` (conv layer), 2 = sum of `big` (transposed conv);
   // every element passes through this thread's registers on its way to LDS, and a thread always stages
   // the same channel, so the sums cost one add per float4
-  constexpr int SLAB = CS * CB * 16 + 16;
+  constexpr int MT = (CS + 15) / 16;      // m-tiles: 24 small channels (conv2 / tconv3) take two
+  constexpr int BPAD = ((CS > CB ? CS : CB) + 15) / 16 * 16;  // bias slots behind the weight slab
+  constexpr int SLAB = CS * CB * 16 + BPAD;
   constexpr int TP = TH * TW;             // positions per tile
   constexpr int LDS_S = TP + 2;           // small-tile row stride: == 2 (mod 32) -> conflict-free A reads
   constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
   constexpr int NT = CB;                  // one n-tile (16 taps) per big channel
-  __shared__ float stile[16 * LDS_S];
-  __shared__ float patch[CB * PH * PW];
+  // one buffer: [small tile | big patch] while the tiles are walked, then the combine image(s)
+  constexpr int CPITCH = CB * 16 + 4;  // combine row pitch: the 4 row groups of a lane quad land 16 banks apart
+  constexpr int TILE_FLOATS = 16 * MT * LDS_S + CB * PH * PW;
+  constexpr int COMB_FLOATS = MT > 1 ? 4 * CS * CPITCH : 0;
+  __shared__ float smem_w[TILE_FLOATS > COMB_FLOATS ? TILE_FLOATS : COMB_FLOATS];
+  float* stile = smem_w;
+  float* patch = smem_w + 16 * MT * LDS_S;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lm = lane & 15, lk = lane >> 4;
-  for (int i = t; i < 16 * LDS_S; i += 256) stile[i] = 0.f;  // rows >= CS stay zero
+  for (int i = t; i < 16 * MT * LDS_S; i += 256) stile[i] = 0.f;  // rows >= CS stay zero
 
-  f32x4 acc[NT];
+  f32x4 acc[MT][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr int NQS = (CS * TH * (TW / 4) + 255) / 256;      // float4 of the small tile per thread
   constexpr int NQB = (CB * PH * (2 * TW / 4) + 255) / 256;  // float4 of the big patch per thread
   float bs_small[NQS], bs_big[NQB];
@@ -452,31 +461,57 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
     for (int s = wave; s < TP / 4; s += 4) {
       const int p = 4 * s + lk;
       const int oy = p / TW, ox = p - oy * TW;
-      const float a = stile[lm * LDS_S + p];
+      float a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = stile[(16 * mt + lm) * LDS_S + p];
       const int boff = (2 * oy + ky) * PW + 2 * ox + kx;
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, patch[j * PH * PW + boff], acc[j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) {
+        const float bv = patch[j * PH * PW + boff];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv, acc[mt][j], 0, 0, 0);
+      }
     }
   }
   // ---- combine the 4 waves (fixed order) and write this workgroup's slab [CS][CB*16]
   __syncthreads();
-  // the patch is dead now: reuse it as the 4 x 16 x (N+1) combine buffer
-  static_assert(CB * PH * PW >= 4 * 16 * (CB * 16 + 1), "combine buffer must fit in the patch");
-  float (*comb)[16][CB * 16 + 1] = reinterpret_cast<float (*)[16][CB * 16 + 1]>(patch);
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) comb[wave][4 * lk + r][16 * j + lm] = acc[j][r];
-  __syncthreads();
   float* out = partial + (size_t)blockIdx.x * SLAB;
-  for (int i = t; i < CS * CB * 16; i += 256) {
-    const int m = i / (CB * 16), n = i - m * (CB * 16);
-    out[i] = (comb[0][m][n] + comb[1][m][n]) + (comb[2][m][n] + comb[3][m][n]);
+  if constexpr (MT == 1) {
+    // the patch is dead now: reuse it as the 4 x 16 x (N+1) combine buffer
+    static_assert(MT > 1 || CB * PH * PW >= 4 * 16 * (CB * 16 + 1), "combine buffer must fit in the patch");
+    float (*comb)[16][CB * 16 + 1] = reinterpret_cast<float (*)[16][CB * 16 + 1]>(patch);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) comb[wave][4 * lk + r][16 * j + lm] = acc[0][j][r];
+    __syncthreads();
+    for (int i = t; i < CS * CB * 16; i += 256) {
+      const int m = i / (CB * 16), n = i - m * (CB * 16);
+      out[i] = (comb[0][m][n] + comb[1][m][n]) + (comb[2][m][n] + comb[3][m][n]);
+    }
+  } else {
+    // every wavefront leaves its partial image [CS][CB*16] (independent stores: a read-modify-write chain through
+    // LDS costs ~150 cycles per element), then all threads add the four in wavefront order
+    float* comb = smem_w + wave * CS * CPITCH;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * mt + 4 * lk + r;
+          if (row < CS) comb[row * CPITCH + 16 * j + lm] = acc[mt][j][r];
+        }
+    __syncthreads();
+    for (int i = t; i < CS * CB * 16; i += 256) {
+      const int m = i / (CB * 16), n = i - m * (CB * 16);
+      const float* c0 = smem_w + m * CPITCH + n;
+      out[i] = (c0[0] + c0[CS * CPITCH]) + (c0[2 * CS * CPITCH] + c0[3 * CS * CPITCH]);
+    }
   }
   // ---- bias partials: per-thread sums -> per-channel workgroup sums (fixed order), slab[CS*CB*16 + c]
   __syncthreads();
-  float* bred = patch;  // [16 channels][4 waves]
+  float* bred = patch;  // [BPAD channels][4 waves]
   if (bias_from) {
     const int nch = bias_from == 1 ? CS : CB;
     for (int c = 0; c < nch; ++c) {
@@ -499,7 +534,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
     }
   }
   __syncthreads();
-  if (t < 16) {
+  if (t < BPAD) {
     const int nch = bias_from == 1 ? CS : bias_from == 2 ? CB : 0;
     out[CS * CB * 16 + t] = t < nch ? (bred[t * 4] + bred[t * 4 + 1]) + (bred[t * 4 + 2] + bred[t * 4 + 3]) : 0.f;
   }
@@ -508,9 +543,13 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
 bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws) {
   if (Cs == 8 && Cb == 4) return Hs % 4 == 0 && Ws % 64 == 0;
   if (Cs == 12 && Cb == 8) return Hs % 8 == 0 && Ws % 32 == 0;
+  if (Cs == 24 && Cb == 12) return Hs % 8 == 0 && Ws % 16 == 0;  // conv2 / tconv3: K = B*Hs*Ws >> M, N
   return false;
 }
-size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)768 * (Cs * Cb * 16 + 16); }
+static int wgrad_bias_pad(int Cs, int Cb) { return ((Cs > Cb ? Cs : Cb) + 15) / 16 * 16; }
+size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) {
+  return (size_t)768 * (Cs * Cb * 16 + wgrad_bias_pad(Cs, Cb));
+}
 
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
@@ -528,13 +567,18 @@ int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
     grid = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<12, 8, 8, 32>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
                        big_bs, ws, Hs, Ws, ntiles, bias_from);
+  } else if (Cs == 24 && Cb == 12) {
+    const int ntiles = (Ws / 16) * (Hs / 8) * B;
+    grid = ntiles < 768 ? ntiles : 768;
+    hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<24, 12, 8, 16>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
+                       big_bs, ws, Hs, Ws, ntiles, bias_from);
   } else {
     set_last_error("conv2d_wgrad_direct: unsupported shape");
     return LSHM_ERR_UNSUPPORTED;
   }
   int rc = check_launch("conv2d_wgrad_direct");
   if (rc) return rc;
-  const int nw = Cs * Cb * 16, slab = nw + 16;
+  const int nw = Cs * Cb * 16, slab = nw + wgrad_bias_pad(Cs, Cb);
   const int nbias = bias_from == 1 ? Cs : Cb;
   if (defer) {
     defer->sums.push_back(SumJob{ws, dw, slab, nw, grid, 0, 0, 0, 0, accumulate, 0});
@@ -831,6 +875,198 @@ namespace lshm {
 // :141-142), bias gradient fused: launcher around conv1d_wgrad_stream_kernel (conv1d_stream.hip); one
 // slab of Cs*Cb*4 + 16 floats per workgroup, summed here or queued on the backward's job list.
 // ----------------------------------------------------------------------------------------------
+// ----------------------------------------------------------------------------------------------
+// k4 s4 weight gradient of the MID 1-D layers (conv2 / tconv3: 24 small, 12 big channels; conv3 / tconv2:
+// 48 / 24), bias gradient fused:   dW[cs, cb, t] = sum_{b,j} small[b,cs,j] * big[b,cb,4j-pad+t]
+// GEMM view: M = Cs, N = Cb*4 (an n-tile = 4 big channels x 4 taps), K = every position of the batch --
+// a tiny output over a huge K, which the implicit-GEMM template serves badly (30-45 us per pair at B=256).
+// A workgroup walks tiles of TP positions: the small tile [Cs][TP] and the matching big segment [Cb][4 TP]
+// are staged once in LDS with float4 loads, each wavefront takes every 4th group of 4 positions, fragments
+// are read straight out of the images; accumulators stay in registers across all tiles of the (persistent)
+// workgroup; the four wavefronts then add into one image in a fixed order.  One slab per workgroup.
+// ----------------------------------------------------------------------------------------------
+template <int CS, int CB, int TP>
+__global__ __launch_bounds__(256) void conv1d_wgrad_mid_kernel(const float* __restrict__ small0,
+                                                               const float* __restrict__ small1, long s_bs,
+                                                               const float* __restrict__ big0,
+                                                               const float* __restrict__ big1, long big_bs,
+                                                               float* __restrict__ partial0,
+                                                               float* __restrict__ partial1, int Ls, int Lb, int pad,
+                                                               int bias_from, int ntiles) {
+  const float* small = blockIdx.y ? small1 : small0;
+  const float* big = blockIdx.y ? big1 : big0;
+  float* partial = blockIdx.y ? partial1 : partial0;
+  constexpr int MT = (CS + 15) / 16, NT = CB / 4;
+  constexpr int NW = CS * CB * 4;
+  constexpr int BPAD = ((CS > CB ? CS : CB) + 15) / 16 * 16;
+  constexpr int SLAB = NW + BPAD;
+  constexpr int LDS_S = TP + 2;        // == 2 (mod 32): the 16 rows x 4 positions of an A fragment hit 32 banks
+  constexpr int BP = 4 * TP + 8;       // big row pitch, == 8 (mod 32): 4 channels x 4 taps x 2 positions conflict-free
+  static_assert(CB % 4 == 0 && TP % 64 == 0, "tile shape");
+  constexpr int CPITCH = CB * 4 + 4;   // combine row pitch (see the 2-D kernel)
+  constexpr int TILE_FLOATS = 16 * MT * LDS_S + CB * BP, COMB_FLOATS = 4 * CS * CPITCH;
+  __shared__ float smem_w[TILE_FLOATS > COMB_FLOATS ? TILE_FLOATS : COMB_FLOATS];
+  float* stile = smem_w;
+  float* bimg = smem_w + 16 * MT * LDS_S;  // bimg[cb][1 + i] = big[cb][4 j0 + i]; [0] = element before
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lm = lane & 15, lk = lane >> 4;
+  for (int i = t; i < 16 * MT * LDS_S; i += 256) stile[i] = 0.f;  // rows >= CS stay zero
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NQS = (CS * (TP / 4) + 255) / 256, NQB = (CB * TP + 255) / 256;
+  float bs_small[NQS], bs_big[NQB];
+#pragma unroll
+  for (int q = 0; q < NQS; ++q) bs_small[q] = 0.f;
+#pragma unroll
+  for (int q = 0; q < NQB; ++q) bs_big[q] = 0.f;
+  const int tiles_per = Ls / TP;
+  // lane (lm, lk) of a B fragment: big channel 4 jt + (lm >> 2), tap lm & 3, position 4 s + lk
+  const int bofs = (lm >> 2) * BP + (lm & 3) + 1 - pad;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * TP;
+    const float* sb = small + (long)b * s_bs + j0;
+    const float* bb = big + (long)b * big_bs + 4L * j0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQS; ++q) {
+      const int i = t + 256 * q;
+      if (i < CS * (TP / 4)) {
+        const int c4 = i % (TP / 4), cs = i / (TP / 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (long)cs * Ls + 4 * c4);
+        float* d = &stile[cs * LDS_S + 4 * c4];
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        bs_small[q] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+      const int i = t + 256 * q;
+      if (i < CB * TP) {
+        const int c4 = i % TP, cb = i / TP;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bb + (long)cb * Lb + 4 * c4);
+        float* d = &bimg[cb * BP + 1 + 4 * c4];
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        bs_big[q] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+    if (t < CB)  // the element before the segment (pad = 1: tap 0 of the first position; zero at the row start)
+      bimg[t * BP] = (pad && j0 > 0) ? bb[(long)t * Lb - 1] : 0.f;
+    __syncthreads();
+#pragma unroll 4
+    for (int s = wave; s < TP / 4; s += 4) {
+      const int p = 4 * s + lk;
+      float a[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = stile[(16 * mt + lm) * LDS_S + p];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float bv = bimg[4 * j * BP + bofs + 4 * p];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt], bv, acc[mt][j], 0, 0, 0);
+      }
+    }
+  }
+  // ---- every wavefront leaves its partial image [CS][CB*4] (lane: rows 4 lk .. + 3, column 16 j + lm =
+  // (cb = 4 j + lm / 4) * 4 + tap), then all threads add the four in wavefront order
+  __syncthreads();
+  float* comb = smem_w + wave * CS * CPITCH;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mt + 4 * lk + r;
+        if (row < CS) comb[row * CPITCH + 16 * j + lm] = acc[mt][j][r];
+      }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * SLAB;
+  for (int i = t; i < NW; i += 256) {
+    const int m = i / (CB * 4), n = i - m * (CB * 4);
+    const float* c0 = smem_w + m * CPITCH + n;
+    out[i] = (c0[0] + c0[CS * CPITCH]) + (c0[2 * CS * CPITCH] + c0[3 * CS * CPITCH]);
+  }
+  __syncthreads();
+  // ---- bias partials: a thread always stages the same channel (tile-invariant index -> channel map)
+  float* bred = bimg;  // [BPAD channels][4 waves]
+  if (bias_from) {
+    const int nch = bias_from == 1 ? CS : CB;
+    for (int c = 0; c < nch; ++c) {
+      float v = 0.f;
+      if (bias_from == 1) {
+#pragma unroll
+        for (int q = 0; q < NQS; ++q) {
+          const int i = t + 256 * q;
+          if (i < CS * (TP / 4) && i / (TP / 4) == c) v += bs_small[q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < NQB; ++q) {
+          const int i = t + 256 * q;
+          if (i < CB * TP && i / TP == c) v += bs_big[q];
+        }
+      }
+      v = wave_sum(v);
+      if (lane == 0) bred[c * 4 + wave] = v;
+    }
+  }
+  __syncthreads();
+  if (t < BPAD) {
+    const int nch = bias_from == 1 ? CS : bias_from == 2 ? CB : 0;
+    out[NW + t] = t < nch ? (bred[t * 4] + bred[t * 4 + 1]) + (bred[t * 4 + 2] + bred[t * 4 + 3]) : 0.f;
+  }
+}
+
+bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
+                                const float* small, const float* big) {
+  const bool shape = (Cs == 24 && Cb == 12 && Ls % 128 == 0) || (Cs == 48 && Cb == 24 && Ls % 64 == 0);
+  return shape && Lb == 4 * Ls && (pad == 0 || pad == 1) && !(bias_from == 2 && pad != 0) && s_bs % 4 == 0 &&
+         big_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(small) & 15) == 0 && (reinterpret_cast<uintptr_t>(big) & 15) == 0;
+}
+size_t conv1d_wgrad_mid_workspace_floats(int Cs, int Cb) { return (size_t)1024 * (Cs * Cb * 4 + wgrad_bias_pad(Cs, Cb)); }
+
+// second problem (small2, big2, dw2, db2) optional: both run in one launch; the closing sums are queued on `defer`
+// (or run in place without it)
+int conv1d_wgrad_mid(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db, int bias_from,
+                     int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws, size_t wsf, int accumulate,
+                     hipStream_t st, const float* small2, const float* big2, float* dw2, float* db2, GradJobs* defer) {
+  const int G = small2 ? 2 : 1;
+  if (wsf < G * conv1d_wgrad_mid_workspace_floats(Cs, Cb)) { set_last_error("conv1d_wgrad_mid: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  if (!db) bias_from = 0;
+  float* ws2 = ws + conv1d_wgrad_mid_workspace_floats(Cs, Cb);
+  const int nw = Cs * Cb * 4, slab = nw + wgrad_bias_pad(Cs, Cb);
+  const int TP = Cs == 24 ? 128 : 64;
+  const int ntiles = (Ls / TP) * B;
+  int grid = ntiles < 1024 / G ? ntiles : 1024 / G;
+  if (grid < 1) grid = 1;
+  const dim3 g(grid, G);
+  if (Cs == 24)
+    hipLaunchKernelGGL((conv1d_wgrad_mid_kernel<24, 12, 128>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs,
+                       ws, ws2, Ls, Lb, pad, bias_from, ntiles);
+  else
+    hipLaunchKernelGGL((conv1d_wgrad_mid_kernel<48, 24, 64>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs,
+                       ws, ws2, Ls, Lb, pad, bias_from, ntiles);
+  int rc = check_launch("conv1d_wgrad_mid");
+  if (rc) return rc;
+  const int nbias = bias_from == 1 ? Cs : Cb;
+  for (int q = 0; q < G; ++q) {
+    const float* part = q ? ws2 : ws;
+    float* dwq = q ? dw2 : dw;
+    float* dbq = q ? db2 : db;
+    if (defer) {
+      defer->sums.push_back(SumJob{part, dwq, slab, nw, grid, 0, 0, 0, 0, accumulate, 0});
+      if (bias_from) defer->sums.push_back(SumJob{part + nw, dbq, slab, nbias, grid, 0, 0, 0, 0, accumulate, 0});
+    } else {
+      if ((rc = reduce_partials_strided(part, slab, dwq, nw, grid, accumulate, st))) return rc;
+      if (bias_from && (rc = reduce_partials_strided(part + nw, slab, dbq, nbias, grid, accumulate, st))) return rc;
+    }
+  }
+  return LSHM_OK;
+}
+
 bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls) {
   return ((Cs == 8 && Cb == 4) || (Cs == 12 && Cb == 8)) && Ls % 64 == 0;
 }

@@ -191,7 +191,8 @@ static void plan_ae(lshm_engine* e, int idx, const char* prefix, int ndim, int L
 // launch (G == 2: netT and netF).  idx[] = AE indices, input[] = their input tensors.
 static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* prm, const float* const* input,
                       float* ws, int ln, hipStream_t st,  // ln: scratch lane of problem 0
-                      const std::function<int()>* after_latent = nullptr) {  // called once the latents are enqueued
+                      const std::function<int()>* after_latent = nullptr,  // called once the latents are enqueued
+                      bool skip_output = false) {  // the reconstruction itself is not needed (only the saved activations)
   const lshm_step_config& c = e->cfg;
   const AEPlan& a0 = e->ae[idx[0]];
   const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
@@ -233,7 +234,7 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
   for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat3, prm + A(g).fc3w, prm + A(g).fc3b, ws + A(g).d0};
   if ((rc = lin(L + hd, 768, L + hd, 768, 0))) return rc;
   for (int g = 0; g < G; ++g) in[g] = ws + A(g).d0;
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < (skip_output ? 5 : 6); ++i) {
     ConvFwdIO io[2];
     for (int g = 0; g < G; ++g) {
       out[g] = (i < 5) ? ws + A(g).dact[i] : ws + A(g).out;
@@ -417,8 +418,11 @@ __global__ void finalize_terms_kernel(const double* __restrict__ scal, double* _
   terms[9] = (double)bad;
 }
 
+// skip_1d_output: the outputs of netT / netF are only consumed by the reconstruction pass; when that pass has
+// already been made for this forward (LSHM_STEP_RECON_READY) their last decoder layer is not run
 static int three_forward(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws,
-                         hipStream_t st, const std::function<int()>* after_latents = nullptr) {
+                         hipStream_t st, const std::function<int()>* after_latents = nullptr,
+                         bool skip_1d_output = false) {
   const lshm_step_config& c = e->cfg;
   int rc;
   e->recon_ready = false;  // a new forward: whatever reconstruction terms the workspace held are stale
@@ -444,7 +448,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   const int i12[2] = {1, 2};
   const float* in12[2] = {ws + e->o_row, ws + e->o_col};
   if (e->pair_mode || !e->side_ok)  // every launch carries both problems
-    return ae_forward(e, 2, i12, prm, in12, ws, 0, st, after_latents);
+    return ae_forward(e, 2, i12, prm, in12, ws, 0, st, after_latents, skip_1d_output);
   // or: two streams side by side (LSHM_FORK=1; no faster than paired launches since the reductions are deferred)
   hipEvent_t evf = e->take_event();
   if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(e->wstream, evf, 0) != hipSuccess) {
@@ -542,11 +546,11 @@ static int start_similarity(lshm_engine* e, const float* prm, float* grd, float*
   return LSHM_OK;
 }
 static int forward_with_latent_losses(lshm_engine* e, const float* prm, float* grd, const float* x, const float* uv,
-                                      float* ws, hipStream_t st) {
+                                      float* ws, hipStream_t st, bool skip_1d_output = false) {
   int rc0 = start_similarity(e, prm, grd, ws, st);
   if (rc0) return rc0;
   const std::function<int()> hook = [&]() -> int { return start_latent_losses(e, prm, grd, ws, st); };
-  return three_forward(e, prm, x, uv, ws, st, &hook);
+  return three_forward(e, prm, x, uv, ws, st, &hook, skip_1d_output);
 }
 
 // reconstruction losses, loss terms and (when grd != null) every gradient, after forward_with_latent_losses
@@ -893,7 +897,9 @@ int lshm_engine_forward_backward_ex(lshm_engine* e, const float* params, float* 
   // the forward below is recomputed either way; only the reconstruction pass can be the one the preceding
   // lshm_engine_multiplier_update_next already made with the same inputs
   const bool recon_done = (flags & LSHM_STEP_RECON_READY) && e->recon_ready;
-  int rc = forward_with_latent_losses(e, params, grads, x, uv, ws, st);
+  // ... and with it done, nothing reads the reconstructions of netT / netF (the workspace keeps the identical
+  // ones of the preceding no-grad forward)
+  int rc = forward_with_latent_losses(e, params, grads, x, uv, ws, st, recon_done);
   if (rc) return rc;
   return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st, recon_done);
 }

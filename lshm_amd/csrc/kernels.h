@@ -171,6 +171,14 @@ int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
                         int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
                         hipStream_t st, GradJobs* defer = nullptr);
 
+// LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
+bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
+                                const float* small, const float* big);
+size_t conv1d_wgrad_mid_workspace_floats(int Cs, int Cb);
+int conv1d_wgrad_mid(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db, int bias_from,
+                     int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws, size_t wsf, int accumulate,
+                     hipStream_t st, const float* small2 = nullptr, const float* big2 = nullptr, float* dw2 = nullptr,
+                     float* db2 = nullptr, GradJobs* defer = nullptr);
 bool conv1d_wgrad_direct_supported(int Cs, int Cb, int Ls);
 size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb);
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,

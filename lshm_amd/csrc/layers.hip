@@ -6,6 +6,8 @@
 // cover forward, dgrad and wgrad of both.  Every function accepts a second
 // pointer bundle: two independent problems of identical shape (the row- and
 // column-vectorised 1-D autoencoders) then share each launch.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace lshm {
@@ -74,6 +76,8 @@ size_t conv_workspace_floats(const ConvLayer& L) {
   } else {
     const size_t d1 = conv1d_wgrad_direct_workspace_floats(w.M, w.N / 4);
     if (d1 > a) a = d1;
+    const size_t d3 = conv1d_wgrad_mid_workspace_floats(w.M, w.N / 4);
+    if (d3 > a) a = d3;
   }
   return a + BIAS_WS_FLOATS + 16;
 }
@@ -253,6 +257,14 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
                                  Cb, Ls, Lb, tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st,
                                  io2 ? small_of(*io2) : nullptr, io2 ? big_of(*io2) : nullptr,
                                  io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr, defer);
+    static const bool use_mid = getenv("LSHM_WGRAD_MID_OFF") == nullptr;
+    if (use_mid && gemm_wsf >= G * conv1d_wgrad_mid_workspace_floats(Cs, Cb) &&
+        conv1d_wgrad_mid_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(io), big_of(io)) &&
+        (!io2 || conv1d_wgrad_mid_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(*io2),
+                                            big_of(*io2))))
+      return conv1d_wgrad_mid(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.B, Cs, Cb, Ls, Lb,
+                              tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st, io2 ? small_of(*io2) : nullptr,
+                              io2 ? big_of(*io2) : nullptr, io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr, defer);
     Conv1dWgradParams p{small_of(io), big_of(io), io.dw, L.B, Cs, Ls, Cb, Lb, tr ? 0 : 1, s_bs, big_bs,
                         g.M, g.N, g.K, accumulate, {}};
     if (io2) {

@@ -122,6 +122,9 @@ class KHarmonicTrainer:
         self.grads = torch.zeros(n, device=dev)
         self.exp_avg = torch.zeros(n, device=dev)
         self.exp_avg_sq = torch.zeros(n, device=dev)
+        # Adam's step number: a host integer for eager launches (passed by value, no extra kernel); a captured
+        # graph needs it on the device (incremented by a node of the graph), see capture_graph
+        self.adam_steps = 0
         self.step_count = torch.zeros(1, device=dev, dtype=torch.int32)
         self.ws_floats = self.lib.lshm_engine_workspace_floats(h)
         self.ws = torch.empty(self.ws_floats, device=dev)
@@ -206,6 +209,7 @@ class KHarmonicTrainer:
             self.exp_avg.zero_()
             self.exp_avg_sq.zero_()
             self.step_count.zero_()
+            self.adam_steps = 0
         self._opt_generation = getattr(self, "_opt_generation", 0) + 1
         if set(groups) == set(GROUPS):
             self._mask = None
@@ -306,11 +310,16 @@ class KHarmonicTrainer:
         c = self.cfg
         P = L.ptr
         with L.on_device(self.device):
-            self.step_count.add_(1)
+            in_graph = self._graph is not None
+            if in_graph:
+                self.step_count.add_(1)
+            else:
+                self.adam_steps += 1
             for a, b in self._ranges:
                 L.check(self.lib.lshm_adam_step_flat(P(self.params[a:b]), P(self.grads[a:b]), P(self.exp_avg[a:b]),
                                                      P(self.exp_avg_sq[a:b]), b - a, c.lr, c.betas[0], c.betas[1],
-                                                     c.adam_eps, P(self.step_count), 0, 1.0, self._stream()), "adam")
+                                                     c.adam_eps, P(self.step_count) if in_graph else None,
+                                                     self.adam_steps, 1.0, self._stream()), "adam")
 
     def _multipliers(self, prepare_next: Optional[bool] = None):
         """No-grad forward + y_k += rho r_k (src/kharmonic_lofar.py:187-202).  prepare_next: the same pass also
@@ -337,7 +346,9 @@ class KHarmonicTrainer:
         self._saved_forward = False
         self._recon_ready = False
         with L.on_device(self.device):
+            self.step_count.fill_(self.adam_steps)
             snap = [t.clone() for t in (self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y)]
+            host_steps = self.adam_steps
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -356,12 +367,14 @@ class KHarmonicTrainer:
             finally:
                 for t, v in zip((self.params, self.exp_avg, self.exp_avg_sq, self.step_count, *self.y), snap):
                     t.copy_(v)
+                self.adam_steps = host_steps
                 self._saved_forward = self._recon_ready = False
 
     def step(self):
         """One ADMM iteration.  Loss terms of the closure stay on the device (``read_terms``)."""
         if self._graph is not None:
             self._graph.replay()
+            self.adam_steps += 1
             self._saved_forward = self._recon_ready = False
         else:
             self._step_impl()
