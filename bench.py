@@ -51,7 +51,10 @@ def parse():
     ap.add_argument("--no-lbfgs", action="store_true", help="skip the extra LBFGS-iteration timing")
     ap.add_argument("--no-rica", action="store_true", help="skip the dictionary-learning (rica_lofar) timing")
     ap.add_argument("--bf16", action="store_true",
-                    help="BASELINE configs[2]: bf16 operands on the matrix cores for the GEMM-shaped layers (fp32 accumulate, fp32 storage)")
+                    help="BASELINE configs[2]: bf16 operands on the matrix cores for the GEMM-shaped layers and bf16 storage of "
+                         "the image-sized activations / gradients of the outer layers and glue passes (fp32 accumulate)")
+    ap.add_argument("--bf16-operands-only", action="store_true",
+                    help="with --bf16: keep every tensor in HBM fp32 (round the GEMM operands only)")
     ap.add_argument("--only-khm", action="store_true", help="time only the K-harmonic kernel (dev aid)")
     return ap.parse_args()
 
@@ -494,7 +497,8 @@ def main():
         return
     from lshm_amd import KHarmonicTrainer, TrainConfig
     B = args.batch
-    cfg = TrainConfig(Kc=args.K, matrix_precision="bf16" if args.bf16 else "fp32")
+    cfg = TrainConfig(Kc=args.K, matrix_precision="bf16" if args.bf16 else "fp32",
+                      activation_storage="bf16" if (args.bf16 and not args.bf16_operands_only) else "fp32")
     tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=args.bpb, default_batch=B // args.bpb, device=dev,
                           process_group=pg)
     tr.init_parameters(seed=0)  # identical replicas on every rank
@@ -582,9 +586,9 @@ def main():
     out = {"metric": "spectrogram-patches/sec per training step (AE+FFT+k-harmonic), 1/2/4/8 GPU",
            "value": round(value, 1), "unit": "patches/s", "n_gpus": world, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "bf16 matrix operands, f32 accumulate/storage" if args.bf16 else "f32", "data": "synthetic",
+           "vs_baseline": None, "dtype": ("bf16" if not args.bf16_operands_only else "bf16 matrix operands, f32 storage") if args.bf16 else "f32", "data": "synthetic",
            "config": {"workload": f"1xMI355X-per-rank: (B={B},4,128,128) synthetic patches, 2D+1D AE + K={args.K} "
-                                  f"k-harmonic, fp32 (BASELINE.json configs[1]); one ADMM iteration = closure "
+                                  f"k-harmonic, {'bf16 storage + bf16 MFMA conv path, f32 accumulate (BASELINE.json configs[2])' if args.bf16 else 'fp32 (BASELINE.json configs[1])'}; one ADMM iteration = closure "
                                   f"fwd+bwd + Adam (all 4 groups) + no-grad fwd + multiplier update",
                       "global_batch": world * B, "per_gpu_batch": B, "K": args.K, "bpb": args.bpb,
                       "parallelism": f"dp{world}", "launch": "hipgraph" if use_graph else "eager",

@@ -66,6 +66,12 @@ void lshm_set_tuning(int mode, int force);
  * precision from lshm_step_config.precision. */
 #define LSHM_PRECISION_F32 0
 #define LSHM_PRECISION_BF16_OPERANDS 1
+/* engines only: bf16 operands as above AND bf16 STORAGE of the image-sized tensors of the bandwidth-bound part
+ * of the step -- the three reconstructions, the row / column residuals fed to the 1-D autoencoders and every
+ * image-sized gradient (of the reconstructions, of the residuals, of the 2-D autoencoder's output) -- in the
+ * outermost convolution layers and the glue passes that read and write them; fp32 accumulation, fp32 master
+ * weights, losses, multipliers and optimiser (BASELINE.json configs[2]) */
+#define LSHM_PRECISION_BF16_STORAGE 2
 /* The cache as text ("policy M N K Z groups config" per line).  export returns the buffer size needed
  * (terminating 0 included) and fills buf up to cap; import merges entries and returns how many it read.
  * Importing the table measured on the target GPU makes runs start without timing launches and

@@ -36,7 +36,7 @@ class StepConfig(C.Structure):
                 ("precision", c_int)]
 
 
-PRECISION_F32, PRECISION_BF16_OPERANDS = 0, 1
+PRECISION_F32, PRECISION_BF16_OPERANDS, PRECISION_BF16_STORAGE = 0, 1, 2
 STEP_RECON_READY = 1
 
 

@@ -15,6 +15,35 @@ int check_launch(const char* what);  // hipGetLastError -> code + message
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Element types of the tensors in HBM.  Everything is computed in fp32 registers; with bf16 STORAGE
+// (LSHM_PRECISION_BF16_STORAGE, BASELINE.json configs[2]) the image-sized activations and gradients of the
+// bandwidth-bound outer layers and of the glue passes are kept as bf16 (round to nearest even on the way out:
+// v_cvt_pk_bf16_f32; a shift on the way in).  Kernels that touch such a tensor are templated on its type.
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+template <class T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ float ld_nt(const float* p) { return __builtin_nontemporal_load(p); }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+  static __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <>
+struct Elem<bf16> {
+  static __device__ __forceinline__ float ld(const bf16* p) { return (float)*p; }
+  static __device__ __forceinline__ float ld_nt(const bf16* p) { return (float)__builtin_nontemporal_load(p); }
+  static __device__ __forceinline__ void st(bf16* p, float v) { *p = (bf16)v; }
+  static __device__ __forceinline__ f32x4 ld4(const bf16* p) {
+    return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4);
+  }
+  static __device__ __forceinline__ void st4(bf16* p, f32x4 v) {
+    *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4);
+  }
+};
+
 // exp(v) - 1 for v <= 0 (the caller discards the value for v > 0).  Every activation of the path goes
 // through this, and in the bandwidth-heavy layers it is most of the vector work, so it is written out:
 // |v| < 1/4: six Taylor terms (truncation < 1.3e-8 relative); otherwise the hardware exp2 minus one,

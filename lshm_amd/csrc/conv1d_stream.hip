@@ -19,7 +19,8 @@ __device__ __forceinline__ float uniform_load(const float* q) { return *(cfloat_
 
 // upsampling direction: big[b, cb, 4j + t - pad] = bias[cb] + sum_cs small[b, cs, j] * w[cs, cb, t]
 //   pad = 0: forward of ConvTranspose1d(k4, s4);  pad = 1: data gradient of Conv1d(k4, s4, p1)
-template <int CS, int CB, bool PAD>
+// TO: element type of `big` (bf16 storage of the image-sized tensors, see common.h)
+template <int CS, int CB, bool PAD, class TO = float>
 __global__ __launch_bounds__(256) void tconv1d_stream_kernel(const Conv1dDgradParams p0, const Conv1dDgradParams p1) {
   const Conv1dDgradParams& p = blockIdx.y ? p1 : p0;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -60,25 +61,26 @@ __global__ __launch_bounds__(256) void tconv1d_stream_kernel(const Conv1dDgradPa
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] *= elu_grad_from_out(sv[r]);
     }
-    *reinterpret_cast<f32x4*>(p.big + g) = acc;
+    Elem<TO>::st4(reinterpret_cast<TO*>(p.big) + g, acc);
   }
 }
 
 // downsampling direction: y[b, co, j] = bias[co] + sum_{ci,t} w[co, ci, t] * x[b, ci, 4j - pad + t]
 //   pad = 1: forward of Conv1d(k4, s4, p1);  pad = 0: data gradient of ConvTranspose1d(k4, s4)
-template <int CIN, int COUT, bool PAD>
+// TI: element type of x
+template <int CIN, int COUT, bool PAD, class TI = float>
 __global__ __launch_bounds__(256) void conv1d_stream_kernel(const Conv1dFwdParams p0, const Conv1dFwdParams p1) {
   const Conv1dFwdParams& p = blockIdx.y ? p1 : p0;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)p.B * p.Lo) return;
   const int b = (int)(idx / p.Lo), j = (int)(idx - (long)b * p.Lo);
-  const float* xb = p.x + (long)b * p.x_bs + 4 * (long)j;
+  const TI* xb = reinterpret_cast<const TI*>(p.x) + (long)b * p.x_bs + 4 * (long)j;
   f32x4 v[CIN];
   float xm[CIN];
 #pragma unroll
   for (int ci = 0; ci < CIN; ++ci) {
-    v[ci] = *reinterpret_cast<const f32x4*>(xb + (long)ci * p.L);
-    xm[ci] = (PAD && j > 0) ? xb[(long)ci * p.L - 1] : 0.f;
+    v[ci] = Elem<TI>::ld4(xb + (long)ci * p.L);
+    xm[ci] = (PAD && j > 0) ? Elem<TI>::ld(xb + (long)ci * p.L - 1) : 0.f;
   }
   const long obase = (long)b * p.y_bs + j;
 #pragma unroll
@@ -116,16 +118,16 @@ __global__ __launch_bounds__(256) void conv1d_stream_kernel(const Conv1dFwdParam
 // the next tile's loads in flight while the current tile's MFMAs run.  Each slot accumulates its own
 // positions; slots, wavefronts and workgroups are combined at the end in a fixed order.
 // ----------------------------------------------------------------------------------------------
-template <int CS, int CB>
+template <int CS, int CB, class TB = float>
 __global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* __restrict__ small0,
                                                                   const float* __restrict__ small1, long s_bs,
-                                                                  const float* __restrict__ big0,
-                                                                  const float* __restrict__ big1, long big_bs,
+                                                                  const float* __restrict__ big0_,
+                                                                  const float* __restrict__ big1_, long big_bs,
                                                                   float* __restrict__ partial0,
                                                                   float* __restrict__ partial1, int Ls, int Lb,
                                                                   int pad, int bias_from, int ntiles) {
   const float* small = blockIdx.y ? small1 : small0;
-  const float* big = blockIdx.y ? big1 : big0;
+  const TB* big = reinterpret_cast<const TB*>(blockIdx.y ? big1_ : big0_);  // TB: element type of `big`
   float* partial = blockIdx.y ? partial1 : partial0;
   constexpr int GA = CS / 4, GB = CB / 4;
   constexpr int NW = CS * CB * 4, SLAB = NW + 16;
@@ -149,17 +151,17 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* _
   auto load_tile = [&](int tile) {
     const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * 64;
     const float* sb = small + (long)b * s_bs + j0 + 4 * slot;
-    const float* bb = big + (long)b * big_bs + 4L * (j0 + 4 * slot) - pad;
+    const TB* bb = big + (long)b * big_bs + 4L * (j0 + 4 * slot) - pad;
 #pragma unroll
     for (int a = 0; a < GA; ++a) ra[a] = *reinterpret_cast<const f32x4*>(sb + (long)(4 * a + q) * Ls);
     if (pad && j0 == 0 && slot == 0) {  // the window of position 0 starts one element before the row
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
-        const float* row = bb + pad + (long)(4 * g + q) * Lb;
+        const TB* row = bb + pad + (long)(4 * g + q) * Lb;
         float e[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(row + 4 * i);
+          const f32x4 v = Elem<TB>::ld4(row + 4 * i);
           e[4 * i] = v[0]; e[4 * i + 1] = v[1]; e[4 * i + 2] = v[2]; e[4 * i + 3] = v[3];
         }
 #pragma unroll
@@ -168,9 +170,24 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* _
       }
     } else {
 #pragma unroll
-      for (int g = 0; g < GB; ++g)
+      for (int g = 0; g < GB; ++g) {
+        if constexpr (sizeof(TB) == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[g][i] = *reinterpret_cast<const f32x4*>(bb + (long)(4 * g + q) * Lb + 4 * i);
+          for (int i = 0; i < 4; ++i) rb[g][i] = Elem<TB>::ld4(bb + (long)(4 * g + q) * Lb + 4 * i);
+        } else if (!pad) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rb[g][i] = Elem<TB>::ld4(bb + (long)(4 * g + q) * Lb + 4 * i);
+        } else {
+          // pad = 1: the windows start one element before an 8-byte boundary; two-byte elements cannot be loaded
+          // four at a time from there, so the five aligned quads around them are loaded and shifted in registers
+          const TB* al = bb + 1 + (long)(4 * g + q) * Lb;  // aligned: element 4 (j0 + 4 slot) of the row
+          f32x4 e[5];
+#pragma unroll
+          for (int i = 0; i < 5; ++i) e[i] = Elem<TB>::ld4(al + 4 * (i - 1));
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rb[g][i] = (f32x4){e[i][3], e[i + 1][0], e[i + 1][1], e[i + 1][2]};
+        }
+      }
     }
   };
   if (w0 < ntiles) load_tile(w0);
@@ -240,7 +257,7 @@ bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int 
 // one slab of Cs*Cb*4 + 16 floats per workgroup at ws (and ws2 for the second problem); returns the grid size
 int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
-                        int bias_from, int max_blocks, hipStream_t st, int* grid_out) {
+                        int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16) {
   const int ntiles = (Ls / 64) * B;
   // measured at B=256: 4..8 tiles per wavefront and at most 512 workgroups per problem (more workgroups
   // only add closing butterflies and partial slabs)
@@ -250,7 +267,11 @@ int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, cons
   if (grid > max_blocks) grid = max_blocks;
   *grid_out = grid;
   const dim3 g(grid, small2 ? 2 : 1);
-  if (Cs == 8)
+  if (big_bf16 && Cs != 8) { set_last_error("conv1d_wgrad_stream: bf16 storage only for the outermost layers"); return LSHM_ERR_UNSUPPORTED; }
+  if (Cs == 8 && big_bf16)
+    hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<8, 4, bf16>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs,
+                       ws, ws2, Ls, Lb, pad, bias_from, ntiles);
+  else if (Cs == 8)
     hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<8, 4>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs,
                        ws, ws2, Ls, Lb, pad, bias_from, ntiles);
   else
@@ -262,32 +283,36 @@ int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, cons
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 bool tconv1d_stream_supported(const Conv1dDgradParams& p) {
-  const bool shape = (p.Cs == 8 && p.Cb == 4) || (p.Cs == 12 && p.Cb == 8);
+  const bool shape = (p.Cs == 8 && p.Cb == 4) || (p.Cs == 12 && p.Cb == 8 && !p.big_bf16);
   return shape && (p.pad == 0 || p.pad == 1) && p.Lb == 4 * p.Ls && p.big_bs % 4 == 0 && aligned16(p.big) &&
          aligned16(p.w) && (!p.dact || aligned16(p.dact));
 }
 bool conv1d_stream_supported(const Conv1dFwdParams& p) {
-  const bool shape = (p.Cin == 4 && p.Cout == 8) || (p.Cin == 8 && p.Cout == 12);
+  const bool shape = (p.Cin == 4 && p.Cout == 8) || (p.Cin == 8 && p.Cout == 12 && !p.x_bf16);
   return shape && (p.pad == 0 || p.pad == 1) && p.L == 4 * p.Lo && p.x_bs % 4 == 0 && aligned16(p.x) && aligned16(p.w);
 }
 
 int tconv1d_stream(const Conv1dDgradParams& p, const Conv1dDgradParams* p1, hipStream_t st) {
   const dim3 grid(cdiv((long)p.B * p.Ls, 256), p1 ? 2 : 1);
   const Conv1dDgradParams& q = p1 ? *p1 : p;
-#define LSHM_LAUNCH(CS, CB)                                                                                   \
-  if (p.pad) hipLaunchKernelGGL((tconv1d_stream_kernel<CS, CB, true>), grid, dim3(256), 0, st, p, q);          \
-  else hipLaunchKernelGGL((tconv1d_stream_kernel<CS, CB, false>), grid, dim3(256), 0, st, p, q)
-  if (p.Cs == 8) { LSHM_LAUNCH(8, 4); } else { LSHM_LAUNCH(12, 8); }
+#define LSHM_LAUNCH(CS, CB, T)                                                                                \
+  if (p.pad) hipLaunchKernelGGL((tconv1d_stream_kernel<CS, CB, true, T>), grid, dim3(256), 0, st, p, q);       \
+  else hipLaunchKernelGGL((tconv1d_stream_kernel<CS, CB, false, T>), grid, dim3(256), 0, st, p, q)
+  if (p.Cs == 8 && p.big_bf16) { LSHM_LAUNCH(8, 4, bf16); }
+  else if (p.Cs == 8) { LSHM_LAUNCH(8, 4, float); }
+  else { LSHM_LAUNCH(12, 8, float); }
 #undef LSHM_LAUNCH
   return check_launch("tconv1d_stream");
 }
 int conv1d_stream(const Conv1dFwdParams& p, const Conv1dFwdParams* p1, hipStream_t st) {
   const dim3 grid(cdiv((long)p.B * p.Lo, 256), p1 ? 2 : 1);
   const Conv1dFwdParams& q = p1 ? *p1 : p;
-#define LSHM_LAUNCH(CI, CO)                                                                                   \
-  if (p.pad) hipLaunchKernelGGL((conv1d_stream_kernel<CI, CO, true>), grid, dim3(256), 0, st, p, q);           \
-  else hipLaunchKernelGGL((conv1d_stream_kernel<CI, CO, false>), grid, dim3(256), 0, st, p, q)
-  if (p.Cin == 4) { LSHM_LAUNCH(4, 8); } else { LSHM_LAUNCH(8, 12); }
+#define LSHM_LAUNCH(CI, CO, T)                                                                                \
+  if (p.pad) hipLaunchKernelGGL((conv1d_stream_kernel<CI, CO, true, T>), grid, dim3(256), 0, st, p, q);        \
+  else hipLaunchKernelGGL((conv1d_stream_kernel<CI, CO, false, T>), grid, dim3(256), 0, st, p, q)
+  if (p.Cin == 4 && p.x_bf16) { LSHM_LAUNCH(4, 8, bf16); }
+  else if (p.Cin == 4) { LSHM_LAUNCH(4, 8, float); }
+  else { LSHM_LAUNCH(8, 12, float); }
 #undef LSHM_LAUNCH
   return check_launch("conv1d_stream");
 }

@@ -186,13 +186,14 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
 // Wavefront (rp, ch) takes small rows {2rp, 2rp+1} and input channels 4ch..4ch+3 (64 weight
 // registers, resident); the two channel halves of a row meet in LDS and are added half 0 + half 1.
 // ----------------------------------------------------------------------------------------------
-template <int TH>
+template <int TH, class TO = float>  // TO: element type of `big` (bf16 storage, common.h)
 __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restrict__ small, long s_bs,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias,
-                                                            float* __restrict__ big, long big_bs,
+                                                            float* __restrict__ big_, long big_bs,
                                                             const float* __restrict__ dact, int Hs, int Ws,
                                                             int act, int ntiles) {
+  TO* __restrict__ big = reinterpret_cast<TO*>(big_);
   constexpr int CS = 8, CB = 4, TW = 64;
   constexpr int PH = TH + 2, PW = TW + 2;
   static_assert(TH == 4, "two small rows per wavefront pair");
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 4; ++r) { o0[r] *= elu_grad_from_out(v0[r]); o1[r] *= elu_grad_from_out(v1[r]); }
       }
-      *reinterpret_cast<f32x4*>(big + g) = o0;
-      *reinterpret_cast<f32x4*>(big + g + 4) = o1;
+      Elem<TO>::st4(big + g, o0);
+      Elem<TO>::st4(big + g + 4, o1);
     }
   }
 }
@@ -340,11 +341,16 @@ bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws) {
 
 int tconv2d_direct(const float* small, long s_bs, const float* w, const float* bias, float* big,
                    long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
-                   hipStream_t st) {
+                   hipStream_t st, int big_bf16) {
+  if (big_bf16 && !(Cs == 8 && Cb == 4)) { set_last_error("tconv2d_direct: bf16 storage only for the outermost layer"); return LSHM_ERR_UNSUPPORTED; }
   if (Cs == 8 && Cb == 4) {
     const int ntiles = (Ws / 64) * (Hs / 4) * B;
-    hipLaunchKernelGGL((tconv2d_q4_kernel<4>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, small, s_bs, w,
-                       bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    if (big_bf16)
+      hipLaunchKernelGGL((tconv2d_q4_kernel<4, bf16>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, small, s_bs, w,
+                         bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    else
+      hipLaunchKernelGGL((tconv2d_q4_kernel<4>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, small, s_bs, w,
+                         bias, big, big_bs, dact, Hs, Ws, act, ntiles);
   } else if (Cs == 12 && Cb == 8) {
     const int ntiles = (Ws / 32) * (Hs / 8) * B;
     hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st,
@@ -369,11 +375,12 @@ namespace lshm {
 // waves), fragments are read straight from the patch.  Accumulators stay in registers across all
 // tiles of the (persistent) workgroup; one slab per workgroup is combined by reduce_partials.
 // ----------------------------------------------------------------------------------------------
-template <int CS, int CB, int TH, int TW>
+template <int CS, int CB, int TH, int TW, class TB = float>  // TB: element type of `big`
 __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* __restrict__ small, long s_bs,
-                                                                  const float* __restrict__ big, long big_bs,
+                                                                  const float* __restrict__ big_, long big_bs,
                                                                   float* __restrict__ partial, int Hs, int Ws,
                                                                   int ntiles, int bias_from) {
+  const TB* __restrict__ big = reinterpret_cast<const TB*>(big_);
   // bias_from: 0 none, 1 bias gradient = sum of `small` (conv layer), 2 = sum of `big` (transposed conv);
   // every element passes through this thread's registers on its way to LDS, and a thread always stages
   // the same channel, so the sums cost one add per float4
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
     const int tr_ = tile - b * (tiles_x * tiles_y);
     const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
     const float* sb = small + (long)b * s_bs;
-    const float* bb = big + (long)b * big_bs;
+    const TB* bb = big + (long)b * big_bs;
     __syncthreads();
     // small tile: [cs][TH*TW] as float4 rows of TW
 #pragma unroll
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
         const int prow = rr % PH, cb = rr / PH;
         const int iy = 2 * m0 - 1 + prow;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)iy < (unsigned)Hb) v = *reinterpret_cast<const f32x4*>(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
+        if ((unsigned)iy < (unsigned)Hb) v = Elem<TB>::ld4(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
         float* d = &patch[(cb * PH + prow) * PW + 1 + 4 * c4];
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         // halo rows belong to the neighbouring tiles: only the 2*TH interior rows count towards the bias sum
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
       const int prow = rr % PH, cb = rr / PH;
       const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
       float v = 0.f;
-      if ((unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb) v = bb[((long)cb * Hb + iy) * Wb + ix];
+      if ((unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb) v = Elem<TB>::ld(bb + ((long)cb * Hb + iy) * Wb + ix);
       patch[(cb * PH + prow) * PW + (side ? PW - 1 : 0)] = v;
     }
     __syncthreads();
@@ -553,15 +560,20 @@ size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) {
 
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
-                        hipStream_t st, GradJobs* defer) {
+                        hipStream_t st, GradJobs* defer, int big_bf16) {
   if (!db) bias_from = 0;
+  if (big_bf16 && !(Cs == 8 && Cb == 4)) { set_last_error("conv2d_wgrad_direct: bf16 storage only for the outermost layer"); return LSHM_ERR_UNSUPPORTED; }
   if (wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv2d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   int grid;
   if (Cs == 8 && Cb == 4) {
     const int ntiles = (Ws / 64) * (Hs / 4) * B;
     grid = ntiles < 768 ? ntiles : 768;
-    hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<8, 4, 4, 64>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
-                       big_bs, ws, Hs, Ws, ntiles, bias_from);
+    if (big_bf16)
+      hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<8, 4, 4, 64, bf16>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
+                         big_bs, ws, Hs, Ws, ntiles, bias_from);
+    else
+      hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<8, 4, 4, 64>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
+                         big_bs, ws, Hs, Ws, ntiles, bias_from);
   } else if (Cs == 12 && Cb == 8) {
     const int ntiles = (Ws / 32) * (Hs / 8) * B;
     grid = ntiles < 512 ? ntiles : 512;
@@ -697,12 +709,13 @@ __global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restr
 // 32 weight registers stay resident for the whole launch); the four per-channel partial tiles meet in
 // LDS and are added in channel order (fixed order: bitwise reproducible) by the wavefront that owns the row.
 // ----------------------------------------------------------------------------------------------
-template <int COUT, int TH>
-__global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restrict__ x, long x_bs,
+template <int COUT, int TH, class TI = float>  // TI: element type of x
+__global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restrict__ x_, long x_bs,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         long y_bs, const float* __restrict__ dact, int Ho, int Wo,
                                                         int act, int ntiles) {
+  const TI* __restrict__ x = reinterpret_cast<const TI*>(x_);
   constexpr int CIN = 4, TW = 64;
   constexpr int NH = COUT / 4;
   constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;  // even row stride keeps the ds_read_b64 at column 2*ox aligned
@@ -732,7 +745,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
     const int b = tile / (tiles_x * tiles_y);
     const int tr_ = tile - b * (tiles_x * tiles_y);
     const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
-    const float* xb = x + (long)b * x_bs;
+    const TI* xb = x + (long)b * x_bs;
 #pragma unroll
     for (int k = 0; k < NV4; ++k) {
       const int i = k * 256 + t;
@@ -741,7 +754,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
       const int iy = 2 * m0 - 1 + prow;
       rv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (i < CIN * PH * (2 * TW / 4) && (unsigned)iy < (unsigned)H)
-        rv[k] = *reinterpret_cast<const f32x4*>(xb + ((long)ci * H + iy) * W + 2 * n0 + 4 * c4);
+        rv[k] = Elem<TI>::ld4(xb + ((long)ci * H + iy) * W + 2 * n0 + 4 * c4);
     }
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
@@ -750,7 +763,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
       const int prow = rr % PH, ci = rr / PH;
       const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
       rh[k] = 0.f;
-      if (i < CIN * PH * 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) rh[k] = xb[((long)ci * H + iy) * W + ix];
+      if (i < CIN * PH * 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) rh[k] = Elem<TI>::ld(xb + ((long)ci * H + iy) * W + ix);
     }
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -850,11 +863,16 @@ bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo) {
 }
 
 int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
-                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st) {
+                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st, int x_bf16) {
+  if (x_bf16 && !(Cin == 4 && Cout == 8)) { set_last_error("conv2d_direct: bf16 storage only for the outermost layer"); return LSHM_ERR_UNSUPPORTED; }
   if (Cin == 4 && Cout == 8) {
     const int ntiles = (Wo / 64) * (Ho / 4) * B;
-    hipLaunchKernelGGL((conv2d_q4_kernel<8, 4>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x, x_bs, w,
-                       bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+    if (x_bf16)
+      hipLaunchKernelGGL((conv2d_q4_kernel<8, 4, bf16>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x, x_bs, w,
+                         bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+    else
+      hipLaunchKernelGGL((conv2d_q4_kernel<8, 4>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x, x_bs, w,
+                         bias, y, y_bs, dact, Ho, Wo, act, ntiles);
   } else if (Cin == 8 && Cout == 12) {
     const int ntiles = (Wo / 32) * (Ho / 8) * B;
     hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x,
@@ -1076,7 +1094,7 @@ size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)204
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
                         size_t wsf, int accumulate, hipStream_t st, const float* small2, const float* big2,
-                        float* dw2, float* db2, GradJobs* defer) {
+                        float* dw2, float* db2, GradJobs* defer, int big_bf16) {
   const int G = small2 ? 2 : 1;
   if (wsf < G * conv1d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv1d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   if (!db) bias_from = 0;
@@ -1089,7 +1107,7 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
   const int slab = Cs * Cb * 4 + 16;
   int grid = 0;
   int rc = conv1d_wgrad_stream(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, bias_from,
-                               2048 / G, st, &grid);
+                               2048 / G, st, &grid, big_bf16);
 
   if (rc) return rc;
   if (defer) {

@@ -124,45 +124,63 @@ __device__ __forceinline__ TileIdx tile_idx_at(int P, int bx, int by) {
 }
 __device__ __forceinline__ TileIdx tile_idx(int P) { return tile_idx_at(P, blockIdx.x, blockIdx.y); }
 
+// T: element type of x1 and of the two outputs (x itself is the caller's fp32 minibatch)
+template <class T>
 __global__ __launch_bounds__(256) void residual_split_kernel(const float* __restrict__ x,
-                                                             const float* __restrict__ x1,
-                                                             float* __restrict__ out_row,
-                                                             float* __restrict__ out_col, int P) {
+                                                             const T* __restrict__ x1,
+                                                             T* __restrict__ out_row,
+                                                             T* __restrict__ out_col, int P) {
   __shared__ float tile[TILE][TILE + 1];
   const TileIdx t = tile_idx(P);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float v = (__builtin_nontemporal_load(x + t.row_off[i]) - x1[t.row_off[i]]) * 0.5f;
-    if (out_row) out_row[t.row_off[i]] = v;
+    const float v = (__builtin_nontemporal_load(x + t.row_off[i]) - Elem<T>::ld(x1 + t.row_off[i])) * 0.5f;
+    if (out_row) Elem<T>::st(out_row + t.row_off[i], v);
     tile[threadIdx.y + 8 * i][threadIdx.x] = v;
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < 4; ++i) out_col[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
+  for (int i = 0; i < 4; ++i) Elem<T>::st(out_col + t.col_off[i], tile[threadIdx.x][threadIdx.y + 8 * i]);
 }
 int residual_split(const float* x, const float* x1, float* out_row, float* out_col, int planes,
-                   int P, hipStream_t st) {
+                   int P, hipStream_t st, int bf) {
   if (P % TILE) { set_last_error("residual_split: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
-  hipLaunchKernelGGL(residual_split_kernel, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
-                     x, x1, out_row, out_col, P);
+  if (bf)
+    hipLaunchKernelGGL(residual_split_kernel<bf16>, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st, x,
+                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<bf16*>(out_row), reinterpret_cast<bf16*>(out_col), P);
+  else
+    hipLaunchKernelGGL(residual_split_kernel<float>, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
+                       x, x1, out_row, out_col, P);
   return check_launch("residual_split");
 }
 
-__global__ __launch_bounds__(256) void plane_transpose_kernel(const float* __restrict__ in,
+template <class T>
+__global__ __launch_bounds__(256) void plane_transpose_kernel(const T* __restrict__ in,
                                                               float* __restrict__ out, int P) {
   __shared__ float tile[TILE][TILE + 1];
   const TileIdx t = tile_idx(P);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = in[t.row_off[i]];
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = Elem<T>::ld(in + t.row_off[i]);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) out[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
 }
-int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t st) {
+int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t st, int in_bf) {
   if (P % TILE) { set_last_error("plane_transpose: size must be a multiple of 32"); return LSHM_ERR_ARG; }
-  hipLaunchKernelGGL(plane_transpose_kernel, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
-                     in, out, P);
+  if (in_bf)
+    hipLaunchKernelGGL(plane_transpose_kernel<bf16>, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
+                       reinterpret_cast<const bf16*>(in), out, P);
+  else
+    hipLaunchKernelGGL(plane_transpose_kernel<float>, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st, in, out, P);
   return check_launch("plane_transpose");
+}
+// out (fp32) = in (bf16), n elements: the reconstructions handed back by lshm_engine_encode
+__global__ void widen_kernel(const bf16* __restrict__ in, float* __restrict__ out, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) out[i] = (float)in[i];
+}
+int widen_bf16(const float* in_bf16, float* out, long n, hipStream_t st) {
+  hipLaunchKernelGGL(widen_kernel, dim3(min(cdiv(n, 256), 4096)), dim3(256), 0, st, reinterpret_cast<const bf16*>(in_bf16), out, n);
+  return check_launch("widen_bf16");
 }
 
 // --------------------------------------------------------------------------
@@ -258,17 +276,18 @@ int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* d
 // evaluate everything else with the new values: the multiplier update of one ADMM iteration and the
 // reconstruction terms of the next one read the same seven arrays, so they can share one pass.
 // GRAD = false: only the seven sums (the gradient-free closures of a line search).
-template <bool UPD, bool GRAD = true>
+// T: element type of the three reconstructions and of the three gradient images (x and the multipliers are fp32)
+template <bool UPD, bool GRAD = true, class T = float>
 __global__ __launch_bounds__(256) void recon_kernel(
-    const float* __restrict__ x, const float* __restrict__ x1, const float* __restrict__ x2,
-    const float* __restrict__ x3c, float* y1, float* y2, float* y3, float rho, float inv_n, int P,
-    double* __restrict__ partials, float* __restrict__ gx1p, float* __restrict__ gx2,
-    float* __restrict__ gx3c) {
+    const float* __restrict__ x, const T* __restrict__ x1, const T* __restrict__ x2,
+    const T* __restrict__ x3c, float* y1, float* y2, float* y3, float rho, float inv_n, int P,
+    double* __restrict__ partials, T* __restrict__ gx1p, T* __restrict__ gx2,
+    T* __restrict__ gx3c) {
   __shared__ float tile[TILE][TILE + 1];
   __shared__ float red[4][8];
   const TileIdx t = tile_idx(P);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = x3c[t.col_off[i]];
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = Elem<T>::ld(x3c + t.col_off[i]);
   __syncthreads();
   float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float g3[4];
@@ -277,7 +296,7 @@ __global__ __launch_bounds__(256) void recon_kernel(
     const long o = t.row_off[i];
     // x and the multipliers are not needed again soon (streamed); x2 / x3 were just written and the
     // three gradients are read next by the backward: leave those to the cache
-    const float xv = __builtin_nontemporal_load(x + o), a1 = x1[o], a2 = x2[o];
+    const float xv = __builtin_nontemporal_load(x + o), a1 = Elem<T>::ld(x1 + o), a2 = Elem<T>::ld(x2 + o);
     const float a3 = tile[threadIdx.x][threadIdx.y + 8 * i];
     const float r1 = xv - a1, h = 0.5f * r1, r2 = h - a2, r3 = h - a3;
     const float e = a1 + a2 + a3 - xv;
@@ -293,9 +312,9 @@ __global__ __launch_bounds__(256) void recon_kernel(
     s[5] += m3 * r3; s[6] += r3 * r3;
     if (GRAD) {
       const float t2 = m2 + rho * r2, t3 = m3 + rho * r3;
-      gx2[o] = (2.f * e - t2) * inv_n;
+      Elem<T>::st(gx2 + o, (2.f * e - t2) * inv_n);
       g3[i] = (2.f * e - t3) * inv_n;
-      gx1p[o] = (2.f * e - m1 - rho * r1) * inv_n - 0.5f * (t2 + t3) * inv_n;
+      Elem<T>::st(gx1p + o, (2.f * e - m1 - rho * r1) * inv_n - 0.5f * (t2 + t3) * inv_n);
     }
   }
   if (GRAD) {
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(256) void recon_kernel(
   __syncthreads();
   if (GRAD) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gx3c[t.col_off[i]] = tile[threadIdx.x][threadIdx.y + 8 * i];
+    for (int i = 0; i < 4; ++i) Elem<T>::st(gx3c + t.col_off[i], tile[threadIdx.x][threadIdx.y + 8 * i]);
   }
   const long blk = ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
   if (tid < 7)
@@ -332,22 +351,35 @@ __global__ __launch_bounds__(1024) void sum7_kernel(const double* __restrict__ p
 size_t recon_partials_floats(int planes, int P) {
   return (size_t)planes * (P / TILE) * (P / TILE) * 7 * 2;
 }
+template <class T>
+static void recon_launch_t(bool upd, const float* x, const T* x1, const T* x2, const T* x3c, float* y1, float* y2, float* y3,
+                           float rho, float inv_n, int P, double* part, T* gx1p, T* gx2, T* gx3c, dim3 grid,
+                           hipStream_t st) {
+  if (!gx1p && !upd)  // no gradient buffers: the sums alone
+    hipLaunchKernelGGL((recon_kernel<false, false, T>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho, inv_n,
+                       P, part, gx1p, gx2, gx3c);
+  else if (upd)
+    hipLaunchKernelGGL((recon_kernel<true, true, T>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho, inv_n, P,
+                       part, gx1p, gx2, gx3c);
+  else
+    hipLaunchKernelGGL((recon_kernel<false, true, T>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho, inv_n, P,
+                       part, gx1p, gx2, gx3c);
+}
 static int recon_launch(bool upd, const float* x, const float* x1, const float* x2, const float* x3c, float* y1,
                         float* y2, float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
-                        float* gx3c, float* block_partials, hipStream_t st, float grad_scale) {
+                        float* gx3c, float* block_partials, hipStream_t st, float grad_scale, int bf = 0) {
   if (P % TILE) { set_last_error("recon_losses: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
   const double n = (double)planes * P * P;
   double* part = reinterpret_cast<double*>(block_partials);
   dim3 grid(P / TILE, P / TILE, planes);
-  if (!gx1p && !upd)  // no gradient buffers: the sums alone
-    hipLaunchKernelGGL((recon_kernel<false, false>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
-                       (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
-  else if (upd)
-    hipLaunchKernelGGL(recon_kernel<true>, grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
-                       (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
-  else
-    hipLaunchKernelGGL(recon_kernel<false>, grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho,
-                       (float)(grad_scale / n), P, part, gx1p, gx2, gx3c);
+  const float inv_n = (float)(grad_scale / n);
+  if (bf) {
+    auto B = [](const float* q) { return reinterpret_cast<const bf16*>(q); };
+    auto Bw = [](float* q) { return reinterpret_cast<bf16*>(q); };
+    recon_launch_t<bf16>(upd, x, B(x1), B(x2), B(x3c), y1, y2, y3, rho, inv_n, P, part, Bw(gx1p), Bw(gx2), Bw(gx3c), grid, st);
+  } else {
+    recon_launch_t<float>(upd, x, x1, x2, x3c, y1, y2, y3, rho, inv_n, P, part, gx1p, gx2, gx3c, grid, st);
+  }
   int rc = check_launch("recon_losses");
   if (rc) return rc;
   hipLaunchKernelGGL(sum7_kernel, dim3(7), dim3(1024), 0, st, part,
@@ -357,67 +389,79 @@ static int recon_launch(bool upd, const float* x, const float* x1, const float* 
 int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const float* x3c,
                          const float* y1, const float* y2, const float* y3, float rho, int planes,
                          int P, double* sums7, float* gx1p, float* gx2, float* gx3c,
-                         float* block_partials, hipStream_t st, float grad_scale) {
+                         float* block_partials, hipStream_t st, float grad_scale, int bf) {
   return recon_launch(false, x, x1, x2, x3c, const_cast<float*>(y1), const_cast<float*>(y2), const_cast<float*>(y3),
-                      rho, planes, P, sums7, gx1p, gx2, gx3c, block_partials, st, grad_scale);
+                      rho, planes, P, sums7, gx1p, gx2, gx3c, block_partials, st, grad_scale, bf);
 }
 // y_k += rho r_k, then the reconstruction terms of the next closure with the updated multipliers
 int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
                             float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
-                            float* gx3c, float* block_partials, hipStream_t st, float grad_scale) {
+                            float* gx3c, float* block_partials, hipStream_t st, float grad_scale, int bf) {
   return recon_launch(true, x, x1, x2, x3c, y1, y2, y3, rho, planes, P, sums7, gx1p, gx2, gx3c, block_partials, st,
-                      grad_scale);
+                      grad_scale, bf);
 }
 
 // gx1 = gx1p - 0.5*(gT + gFc^T)
-__global__ __launch_bounds__(256) void combine_dx1_kernel(const float* __restrict__ gx1p,
-                                                          const float* __restrict__ gT,
-                                                          const float* __restrict__ gFc,
-                                                          float* __restrict__ gx1, int P) {
+template <class T>
+__global__ __launch_bounds__(256) void combine_dx1_kernel(const T* __restrict__ gx1p,
+                                                          const T* __restrict__ gT,
+                                                          const T* __restrict__ gFc,
+                                                          T* __restrict__ gx1, int P) {
   __shared__ float tile[TILE][TILE + 1];
   const TileIdx t = tile_idx(P);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = gFc[t.col_off[i]];
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = Elem<T>::ld(gFc + t.col_off[i]);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long o = t.row_off[i];
-    gx1[o] = __builtin_nontemporal_load(gx1p + o) - 0.5f * (gT[o] + tile[threadIdx.x][threadIdx.y + 8 * i]);
+    Elem<T>::st(gx1 + o, Elem<T>::ld_nt(gx1p + o) - 0.5f * (Elem<T>::ld(gT + o) + tile[threadIdx.x][threadIdx.y + 8 * i]));
   }
 }
 int combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes, int P,
-                hipStream_t st) {
-  hipLaunchKernelGGL(combine_dx1_kernel, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
-                     gx1p, gT, gFc, gx1, P);
+                hipStream_t st, int bf) {
+  if (bf)
+    hipLaunchKernelGGL(combine_dx1_kernel<bf16>, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
+                       reinterpret_cast<const bf16*>(gx1p), reinterpret_cast<const bf16*>(gT),
+                       reinterpret_cast<const bf16*>(gFc), reinterpret_cast<bf16*>(gx1), P);
+  else
+    hipLaunchKernelGGL(combine_dx1_kernel<float>, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st,
+                       gx1p, gT, gFc, gx1, P);
   return check_launch("combine_dx1");
 }
 
 // y1 += rho (x-x1); y2 += rho (h-x2); y3 += rho (h-x3)   (src/kharmonic_lofar.py:200-202)
+template <class T>
 __global__ __launch_bounds__(256) void multiplier_update_kernel(
-    const float* __restrict__ x, const float* __restrict__ x1, const float* __restrict__ x2,
-    const float* __restrict__ x3c, float* __restrict__ y1, float* __restrict__ y2,
+    const float* __restrict__ x, const T* __restrict__ x1, const T* __restrict__ x2,
+    const T* __restrict__ x3c, float* __restrict__ y1, float* __restrict__ y2,
     float* __restrict__ y3, float rho, int P) {
   __shared__ float tile[TILE][TILE + 1];
   const TileIdx t = tile_idx(P);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = x3c[t.col_off[i]];
+  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = Elem<T>::ld(x3c + t.col_off[i]);
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long o = t.row_off[i];
     // the multipliers are touched once per iteration: stream them past the caches
-    const float r1 = __builtin_nontemporal_load(x + o) - x1[o], h = 0.5f * r1;
+    const float r1 = __builtin_nontemporal_load(x + o) - Elem<T>::ld(x1 + o), h = 0.5f * r1;
     __builtin_nontemporal_store(fmaf(rho, r1, __builtin_nontemporal_load(y1 + o)), y1 + o);
-    __builtin_nontemporal_store(fmaf(rho, h - x2[o], __builtin_nontemporal_load(y2 + o)), y2 + o);
+    __builtin_nontemporal_store(fmaf(rho, h - Elem<T>::ld(x2 + o), __builtin_nontemporal_load(y2 + o)), y2 + o);
     __builtin_nontemporal_store(fmaf(rho, h - tile[threadIdx.x][threadIdx.y + 8 * i], __builtin_nontemporal_load(y3 + o)),
                                 y3 + o);
   }
 }
 int multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c, float* y1,
-                      float* y2, float* y3, float rho, int planes, int P, hipStream_t st) {
+                      float* y2, float* y3, float rho, int planes, int P, hipStream_t st, int bf) {
   if (P % TILE) { set_last_error("multiplier_update: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
-  hipLaunchKernelGGL(multiplier_update_kernel, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0,
-                     st, x, x1, x2, x3c, y1, y2, y3, rho, P);
+  if (bf)
+    hipLaunchKernelGGL(multiplier_update_kernel<bf16>, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st, x,
+                       reinterpret_cast<const bf16*>(x1), reinterpret_cast<const bf16*>(x2),
+                       reinterpret_cast<const bf16*>(x3c), y1, y2, y3, rho, P);
+  else
+    hipLaunchKernelGGL(multiplier_update_kernel<float>, dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0,
+                       st, x, x1, x2, x3c, y1, y2, y3, rho, P);
   return check_launch("multiplier_update");
 }
 

@@ -88,6 +88,7 @@ struct lshm_engine {
   size_t part_floats;
   size_t ws_floats;
   int device;      // HIP device current at creation (-1: none); the side stream and the events live there
+  int bf;          // bf16 storage of the image-sized activations / gradients (LSHM_PRECISION_BF16_STORAGE)
   // data parallelism inside the engine (lshm_engine_set_comm): the closures all-reduce their own results
   lshm_comm* comm = nullptr;
   hipStream_t cstream = nullptr;  // the early bucket (netT / netF gradients) runs here, beside the 2-D backward
@@ -443,7 +444,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
     const float* in0[1] = {x};
     if ((rc = ae_forward(e, 1, i0, prm, in0, ws, 0, st))) return rc;
   }
-  if ((rc = residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st))) return rc;
+  if ((rc = residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st, e->bf))) return rc;
   // the two 1-D autoencoders have identical shapes and are independent
   const int i12[2] = {1, 2};
   const float* in12[2] = {ws + e->o_row, ws + e->o_col};
@@ -568,7 +569,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   // (a gradient-free closure passes no gradient images: the kernel then only reads)
   if (!recon_done && (rc = recon_losses_fwd_bwd(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3,
                                  c.rho, planes, c.P, scal, grd ? ws + e->o_gx1p : nullptr, grd ? ws + e->o_gx2 : nullptr,
-                                 grd ? ws + e->o_gx3c : nullptr, ws + e->lane[0].o_part, st, (float)(1.0 / world)))) return rc;
+                                 grd ? ws + e->o_gx3c : nullptr, ws + e->lane[0].o_part, st, (float)(1.0 / world), e->bf))) return rc;
   const double inv_count = 1.0 / (world * (double)B * c.K * D);
   double* rica_part = scal + 16 + (B + c.bpb - 1) / c.bpb;  // [LOGCOSH3_BLOCKS][3]
   if (e->latent_event) {  // the latent-space terms ran beside the decoders
@@ -621,7 +622,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     if ((rc = comm_allreduce_segments(e->comm, seg, nseg, 1, nullptr, 0, e->cstream))) return rc;
     early_bucket = true;
   }
-  if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st))) return rc;
+  if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st, e->bf))) return rc;
   {
     const int i0[1] = {0};
     const float* in0[1] = {x};
@@ -667,7 +668,7 @@ struct EngineCall {
   MatrixPrecisionScope prec;
   int prev_dev = -1;
   bool switched = false;
-  explicit EngineCall(const lshm_engine* e) : prec(e->cfg.precision == LSHM_PRECISION_BF16_OPERANDS) {
+  explicit EngineCall(const lshm_engine* e) : prec(e->cfg.precision != LSHM_PRECISION_F32) {
     if (e->device >= 0 && hipGetDevice(&prev_dev) == hipSuccess && prev_dev != e->device)
       switched = hipSetDevice(e->device) == hipSuccess;
   }
@@ -702,7 +703,8 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     set_last_error("engine_create: bad configuration");
     return LSHM_ERR_ARG;
   }
-  if (cfg->precision != LSHM_PRECISION_F32 && cfg->precision != LSHM_PRECISION_BF16_OPERANDS) {
+  if (cfg->precision != LSHM_PRECISION_F32 && cfg->precision != LSHM_PRECISION_BF16_OPERANDS &&
+      cfg->precision != LSHM_PRECISION_BF16_STORAGE) {
     set_last_error("engine_create: unknown precision");
     return LSHM_ERR_ARG;
   }
@@ -723,6 +725,13 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   plan_ae(e, 1, "netT", 1, cfg->Lt, cfg->L, cur);
   plan_ae(e, 2, "netF", 1, cfg->Lt, cfg->L + cfg->Lt, cur);
   e->off1d = e->ae[1].cw[0];
+  e->bf = cfg->precision == LSHM_PRECISION_BF16_STORAGE;
+  if (e->bf) {
+    // bf16 tensors: the three reconstructions, the row / column residuals and every image-sized gradient.  The
+    // layers that touch them: the last decoder layer of each autoencoder and the first encoder layer of netT / netF.
+    for (int a = 0; a < 3; ++a) e->ae[a].dec[5].out_bf16 = 1;
+    for (int a = 1; a < 3; ++a) e->ae[a].enc[0].in_bf16 = 1;
+  }
   e->Moff = add_param(e, "mod.M", {cfg->K, e->D});
   e->o_scales = take(cur, 8);
   e->o_uvh = take(cur, (size_t)B * e->hdim);
@@ -939,7 +948,7 @@ int lshm_engine_multiplier_update_next(lshm_engine* e, const float* params, cons
   const double world = c.world > 0 ? c.world : 1;
   rc = multiplier_update_recon(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3, c.rho,
                                c.B * c.C, c.P, reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
-                               ws + e->o_gx2, ws + e->o_gx3c, ws + e->lane[0].o_part, st, (float)(1.0 / world));
+                               ws + e->o_gx2, ws + e->o_gx3c, ws + e->lane[0].o_part, st, (float)(1.0 / world), e->bf);
   if (rc) return rc;
   e->recon_ready = true;
   return LSHM_OK;
@@ -970,7 +979,7 @@ int lshm_engine_multiplier_update(lshm_engine* e, const float* params, const flo
   if (rc) return rc;
   const lshm_step_config& c = e->cfg;
   return multiplier_update(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3, c.rho,
-                           c.B * c.C, c.P, st);
+                           c.B * c.C, c.P, st, e->bf);
 }
 
 int lshm_engine_encode(lshm_engine* e, const float* params, const float* x, const float* uv, float* Mu,
@@ -985,9 +994,14 @@ int lshm_engine_encode(lshm_engine* e, const float* params, const float* x, cons
   const lshm_step_config& c = e->cfg;
   const size_t img = (size_t)c.B * c.C * c.P * c.P;
   if (Mu && (rc = hipMemcpyAsync(Mu, ws + e->o_Mu, sizeof(float) * c.B * e->D, hipMemcpyDeviceToDevice, st))) return rc;
-  if (x1 && (rc = hipMemcpyAsync(x1, ws + e->ae[0].out, sizeof(float) * img, hipMemcpyDeviceToDevice, st))) return rc;
-  if (x2 && (rc = hipMemcpyAsync(x2, ws + e->ae[1].out, sizeof(float) * img, hipMemcpyDeviceToDevice, st))) return rc;
-  if (x3 && (rc = plane_transpose(ws + e->ae[2].out, x3, c.B * c.C, c.P, st))) return rc;
+  if (e->bf) {  // the caller gets fp32 whatever the storage type
+    if (x1 && (rc = widen_bf16(ws + e->ae[0].out, x1, (long)img, st))) return rc;
+    if (x2 && (rc = widen_bf16(ws + e->ae[1].out, x2, (long)img, st))) return rc;
+  } else {
+    if (x1 && (rc = hipMemcpyAsync(x1, ws + e->ae[0].out, sizeof(float) * img, hipMemcpyDeviceToDevice, st))) return rc;
+    if (x2 && (rc = hipMemcpyAsync(x2, ws + e->ae[1].out, sizeof(float) * img, hipMemcpyDeviceToDevice, st))) return rc;
+  }
+  if (x3 && (rc = plane_transpose(ws + e->ae[2].out, x3, c.B * c.C, c.P, st, e->bf))) return rc;
   return LSHM_OK;
 }
 

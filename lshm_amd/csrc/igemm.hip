@@ -47,7 +47,7 @@ struct Pair {
 // BF: the operands are rounded to bf16 (nearest even) on their way into LDS and multiplied with
 // v_mfma_f32_16x16x16_bf16 (one instruction per k-block instead of four, 8-byte operand reads); the
 // accumulators, the epilogues and everything in HBM stay fp32.  Opt-in (MatrixPrecisionScope).
-typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));  // operand registers of v_mfma_f32_16x16x16_bf16
 __device__ __forceinline__ unsigned bf16_bits(float v) {  // round to nearest even; NaN stays NaN
   const unsigned u = __float_as_uint(v);
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
@@ -280,13 +280,13 @@ __device__ __forceinline__ void igemm_tile(const typename P::Params p, const int
 #pragma unroll
     for (int kb = wk; kb < NKB; kb += KW ? KW : 1) {
       if constexpr (BF) {
-        bf16x4 a[TM], b[TN];
+        s16x4 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          a[i] = *reinterpret_cast<const bf16x4*>(Ah + kb * A_KBS + (wm0 + 16 * i + lm) * LDK + 4 * lk);
+          a[i] = *reinterpret_cast<const s16x4*>(Ah + kb * A_KBS + (wm0 + 16 * i + lm) * LDK + 4 * lk);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          b[j] = *reinterpret_cast<const bf16x4*>(Bh + kb * B_KBS + (16 * j + lm) * LDK + 4 * lk);
+          b[j] = *reinterpret_cast<const s16x4*>(Bh + kb * B_KBS + (16 * j + lm) * LDK + 4 * lk);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1111,11 +1111,13 @@ int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t 
   return launch_auto<Conv2dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1) {
-  if (g_tune_force < 0 && conv1d_stream_supported(p) && (!p1 || conv1d_stream_supported(*p1))) return conv1d_stream(p, p1, st);
+  if ((g_tune_force < 0 || p.x_bf16) && conv1d_stream_supported(p) && (!p1 || conv1d_stream_supported(*p1))) return conv1d_stream(p, p1, st);
+  if (p.x_bf16) { set_last_error("conv1d: bf16 input needs the streaming kernel"); return LSHM_ERR_UNSUPPORTED; }
   return launch_auto<Conv1dFwd>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dDgradParams* p1) {
-  if (g_tune_force < 0 && tconv1d_stream_supported(p) && (!p1 || tconv1d_stream_supported(*p1))) return tconv1d_stream(p, p1, st);
+  if ((g_tune_force < 0 || p.big_bf16) && tconv1d_stream_supported(p) && (!p1 || tconv1d_stream_supported(*p1))) return tconv1d_stream(p, p1, st);
+  if (p.big_bf16) { set_last_error("tconv1d: bf16 output needs the streaming kernel"); return LSHM_ERR_UNSUPPORTED; }
   return launch_auto<Conv1dDgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1,

@@ -47,6 +47,7 @@ struct Conv1dFwdParams {
   int act;
   int M, N, K;
   SplitK sk;
+  int x_bf16 = 0;  // x is a bf16 tensor (streaming kernels of the outermost layers only)
 };
 struct Conv1dDgradParams {
   const float* s; const float* w; const float* bias; float* big; const float* dact;
@@ -55,6 +56,7 @@ struct Conv1dDgradParams {
   int act;
   int M, N, K;
   SplitK sk;
+  int big_bf16 = 0;  // big is a bf16 tensor (streaming kernels of the outermost layers only)
 };
 struct Conv1dWgradParams {
   const float* s; const float* big; float* dw;
@@ -136,7 +138,7 @@ bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int 
                                    const float* small, const float* big);
 int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
-                        int bias_from, int max_blocks, hipStream_t st, int* grid_out);
+                        int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16 = 0);
 bool tconv1d_stream_supported(const Conv1dDgradParams& p);
 int tconv1d_stream(const Conv1dDgradParams& p, const Conv1dDgradParams* p1, hipStream_t st);
 // mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
@@ -159,17 +161,17 @@ int igemm_tuning_import(const char* text);          // returns the entries read
 bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws);
 int tconv2d_direct(const float* small, long s_bs, const float* w, const float* bias, float* big,
                    long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
-                   hipStream_t st);
+                   hipStream_t st, int big_bf16 = 0);
 
 bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo);
 int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
-                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st);
+                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st, int x_bf16 = 0);
 bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws);
 size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb);
 // db (optional): bias gradient fused; bias_from 1: dz is `small` (conv), 2: dz is `big` (transposed conv)
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
-                        hipStream_t st, GradJobs* defer = nullptr);
+                        hipStream_t st, GradJobs* defer = nullptr, int big_bf16 = 0);
 
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
@@ -185,7 +187,7 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
                         size_t wsf, int accumulate, hipStream_t st, const float* small2 = nullptr,
                         const float* big2 = nullptr, float* dw2 = nullptr, float* db2 = nullptr,
-                        GradJobs* defer = nullptr);
+                        GradJobs* defer = nullptr, int big_bf16 = 0);
 
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
@@ -194,6 +196,9 @@ struct ConvLayer {
   int B, Cin, Cout;
   int Hin, Win;       // 1D: Hin = 1, Win = L
   long in_bs, out_bs; // batch strides of input / output tensors (elements)
+  // bf16 storage (engine precision LSHM_PRECISION_BF16_STORAGE): the layer's input / output tensor -- and with it the
+  // gradient w.r.t. that tensor -- is bf16; only the outermost layers (4 <-> 8 channels) have kernels for it
+  int in_bf16 = 0, out_bf16 = 0;
 };
 void conv_out_dims(const ConvLayer& L, int& Hout, int& Wout);
 // scratch (floats) that lets every problem of the layer use split-K + the bias partial sums
@@ -255,9 +260,11 @@ int uv_harmonics_host_scales(const float* uv, const float* scales_host, int H, i
                              hipStream_t st);
 int elu_bwd(const float* gy, const float* y, float* dz, long n, hipStream_t st);
 // out_row = (x-x1)/2 ; out_col = per-plane transpose of out_row (planes of P x P)
+// bf != 0: x1 and the outputs are bf16 tensors behind the float pointers (bf16 storage, see common.h)
 int residual_split(const float* x, const float* x1, float* out_row, float* out_col, int planes,
-                   int P, hipStream_t st);
-int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t st);
+                   int P, hipStream_t st, int bf = 0);
+int plane_transpose(const float* in, float* out, int planes, int P, hipStream_t st, int in_bf = 0);
+int widen_bf16(const float* in_bf16, float* out, long n, hipStream_t st);
 // reduce_partials: out[i] (=|+=) sum_{s<S} partial[s*n + i]
 int reduce_partials(const float* partial, float* out, long n, int S, int accumulate,
                     hipStream_t st, const float* partial2 = nullptr, float* out2 = nullptr);
@@ -275,16 +282,17 @@ int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const
                          const float* y1, const float* y2, const float* y3, float rho, int planes,
                          int P, double* sums7, float* gx1p, float* gx2, float* gx3c,
                          float* block_partials, hipStream_t st,
-                         float grad_scale = 1.f)  /* gradients (not the sums) are multiplied by grad_scale */;
+                         float grad_scale = 1.f, int bf = 0)  /* gradients (not the sums) are multiplied by grad_scale;
+                                                                 bf: x1..x3c and the gradient images are bf16 */;
 size_t recon_partials_floats(int planes, int P);
 int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
                             float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
-                            float* gx3c, float* block_partials, hipStream_t st, float grad_scale = 1.f);
+                            float* gx3c, float* block_partials, hipStream_t st, float grad_scale = 1.f, int bf = 0);
 int combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes,
-                int P, hipStream_t st);
+                int P, hipStream_t st, int bf = 0);
 int multiplier_update(const float* x, const float* x1, const float* x2, const float* x3c,
                       float* y1, float* y2, float* y3, float rho, int planes, int P,
-                      hipStream_t st);
+                      hipStream_t st, int bf = 0);
 int adam_step_flat(float* p, const float* g, float* m, float* v, long n, float lr, float b1,
                    float b2, float eps, const int* step_dev, int step_host, float gscale,
                    hipStream_t st);

@@ -70,6 +70,10 @@ class TrainConfig:
     # layers, losses and Adam stay fp32 (BASELINE.json configs[2]).  A property of this trainer's engine
     # (lshm_step_config.precision): other trainers / modules in the process are unaffected.
     matrix_precision: str = "fp32"
+    # "bf16" (with matrix_precision="bf16"): the image-sized activations and gradients of the bandwidth-bound part of
+    # the step -- the three reconstructions, the row / column residuals, every image-sized gradient -- live in HBM as
+    # bf16; accumulation, master weights, multipliers, losses and Adam stay fp32 (LSHM_PRECISION_BF16_STORAGE)
+    activation_storage: str = "fp32"
     # The multiplier update that closes iteration k and the reconstruction terms that open iteration k+1 read
     # the same seven image-sized arrays; True (default): they share one pass (the closure forward itself is
     # still recomputed, as upstream does) -- identical results, one 0.67 GB pass less per iteration.
@@ -82,6 +86,10 @@ class KHarmonicTrainer:
         self.cfg = cfg
         if cfg.matrix_precision not in ("fp32", "bf16"):
             raise ValueError("matrix_precision must be 'fp32' or 'bf16'")
+        if cfg.activation_storage not in ("fp32", "bf16"):
+            raise ValueError("activation_storage must be 'fp32' or 'bf16'")
+        if cfg.activation_storage == "bf16" and cfg.matrix_precision != "bf16":
+            raise ValueError("activation_storage='bf16' goes with matrix_precision='bf16' (BASELINE configs[2])")
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise RuntimeError("KHarmonicTrainer needs a HIP device; there is no CPU path")
@@ -107,7 +115,8 @@ class KHarmonicTrainer:
         for i, s in enumerate(cfg.harmonic_scales):
             sc.scales[i] = s
         sc.world = self.world
-        sc.precision = L.PRECISION_BF16_OPERANDS if cfg.matrix_precision == "bf16" else L.PRECISION_F32
+        sc.precision = (L.PRECISION_BF16_STORAGE if cfg.activation_storage == "bf16" else
+                        L.PRECISION_BF16_OPERANDS if cfg.matrix_precision == "bf16" else L.PRECISION_F32)
         self._sc = sc
         h = C.c_void_p()
         # the engine's side stream and events are created on the device that is current now, and every

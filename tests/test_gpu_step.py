@@ -238,7 +238,9 @@ def _full_trainer(world=1, batch=256, bs=None, K=10, precision="fp32"):
     from lshm_amd import KHarmonicTrainer, TrainConfig
     import ctypes as C
     from lshm_amd import _lib as L
-    tr = KHarmonicTrainer(TrainConfig(Kc=K, matrix_precision=precision), batch=batch, batch_per_bline=8,
+    cfg = (TrainConfig(Kc=K, matrix_precision="bf16", activation_storage="bf16") if precision == "bf16s" else
+           TrainConfig(Kc=K, matrix_precision=precision))
+    tr = KHarmonicTrainer(cfg, batch=batch, batch_per_bline=8,
                           default_batch=bs if bs is not None else batch // 8, device=DEV)
     if world != 1:
         tr._sc.world = world
@@ -250,8 +252,8 @@ def _full_trainer(world=1, batch=256, bs=None, K=10, precision="fp32"):
     return tr
 
 
-@pytest.mark.parametrize("K,precision", [(10, "fp32"), (64, "fp32"), (10, "bf16")],
-                         ids=["K10", "K64-config5", "bf16-config3"])
+@pytest.mark.parametrize("K,precision", [(10, "fp32"), (64, "fp32"), (10, "bf16"), (10, "bf16s")],
+                         ids=["K10", "K64-config5", "bf16-operands", "bf16-storage-config3"])
 def test_full_size_step_is_bitwise_reproducible_and_finite(K, precision):
     """Deterministic reductions everywhere (no float atomics): two runs of 3 iterations at
     B=256 give bit-identical parameters, multipliers and loss terms -- at K=10 (configs[1]), at config 5's
@@ -300,8 +302,8 @@ def test_full_size_two_stream_schedule_equals_single_stream():
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("K,precision,tol", [(10, "fp32", 5e-5), (64, "fp32", 5e-5), (10, "bf16", 5e-5)],
-                         ids=["K10", "K64-config5", "bf16-config3"])
+@pytest.mark.parametrize("K,precision,tol", [(10, "fp32", 5e-5), (64, "fp32", 5e-5), (10, "bf16", 5e-5), (10, "bf16s", 5e-5)],
+                         ids=["K10", "K64-config5", "bf16-operands", "bf16-storage-config3"])
 def test_full_size_batch_additivity(K, precision, tol):
     """Every loss term is a batch mean (or batch independent): the world=2 shares of the two
     half-batches of a B=256 minibatch sum to the B=256 result (gradients and the 9 terms).  The property does
@@ -653,3 +655,54 @@ def test_config5_composition_loader_k64_lbfgs():
     y_new = O.multiplier_update(params, x, uv, y, ocfg)
     for k in range(3):
         assert rel_err(tr.y[k], y_new[k]) < 2e-3
+
+
+def test_bf16_storage_step_vs_fp32_oracle():
+    """BASELINE configs[2] with bf16 STORAGE (TrainConfig.activation_storage='bf16'): the three reconstructions, the
+    row / column residuals and every image-sized gradient live in HBM as bf16 (fp32 accumulation, master weights,
+    multipliers, losses, Adam).  Against the fp32 oracle: every logged term within 2e-2, the gradient vector within
+    5e-2 norm-wise, three Adam iterations; and the storage really is bf16 (the engine's x1 equals its own bf16
+    rounding, and differs from the fp32-storage engine's)."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    B, K, bpb, bs = 4, 5, 2, 2
+    ocfg = O.StepConfig(K=K, bpb=bpb, batch_size=bs)
+    params, M = O.make_params(ocfg)
+    x, uv = O.closed_form_inputs(B, 4)
+    tr = KHarmonicTrainer(TrainConfig(Kc=K, matrix_precision="bf16", activation_storage="bf16"), batch=B,
+                          batch_per_bline=bpb, default_batch=bs, device=DEV)
+    tr.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
+    tr.new_minibatch(x.to(DEV), uv.to(DEV))
+    Mu, x1, x2, x3 = tr.encode(want_recon=True)
+    ref = KHarmonicTrainer(TrainConfig(Kc=K, matrix_precision="bf16"), batch=B, batch_per_bline=bpb, default_batch=bs,
+                           device=DEV)
+    ref.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
+    ref.new_minibatch(x.to(DEV), uv.to(DEV))
+    _, r1, r2, r3 = ref.encode(want_recon=True)
+    for a, b in ((x1, r1), (x2, r2), (x3, r3)):
+        assert torch.equal(a, a.to(torch.bfloat16).float())      # what came back is exactly representable in bf16
+        assert 0 < rel_err(a, b) < 1e-2                           # and is the fp32-storage result, rounded
+    tr.closure_only()
+    y = [torch.zeros(x.numel()) for _ in range(3)]
+    leaves = O.flat_leaves(params, M)
+    for l in leaves:
+        l.requires_grad_(True)
+    total, terms = O.closure_losses(params, M, x, uv, y, ocfg)
+    grads = torch.autograd.grad(total, leaves)
+    for l in leaves:
+        l.requires_grad_(False)
+    t = tr.read_terms()
+    assert abs(t["total"] - total.item()) <= 2e-2 * abs(total.item())
+    for n, rf in zip(("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica"), terms):
+        assert abs(t[n] - float(rf)) <= 2e-2 * abs(float(rf)) + 1e-7, n
+    names = [f"{g}.{k}" for g in O.GROUPS for k in params[g]] + ["mod.M"]
+    num = sum(float((tr.view(n, tr.grads).cpu().double() - gr.double()).pow(2).sum()) for n, gr in zip(names, grads))
+    den = sum(float(gr.double().pow(2).sum()) for gr in grads)
+    assert 1e-5 < (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+    adam = O.AdamState(leaves, ocfg.lr)
+    for _ in range(3):
+        tr.step()
+        ref_terms, y, _ = O.admm_iteration(params, M, x, uv, y, ocfg, adam)
+    t = tr.read_terms()
+    for n, rf in zip(("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica"), ref_terms):
+        assert abs(t[n] - rf) <= 2e-2 * abs(rf) + 1e-7, n
+    assert t["nonfinite"] == 0.0
