@@ -410,17 +410,19 @@ def test_bf16_matrix_precision_step_vs_fp32_oracle():
         for l in leaves:
             l.requires_grad_(False)
         t = tr.read_terms()
-        assert abs(t["total"] - total.item()) <= 2e-2 * abs(total.item())
+        # gates at ~4x the measured errors (profiles/bf16_error_probe.py: total 4e-5, worst term 2.2e-3,
+        # gradient vector 1.7e-3, median tensor 3.7e-2)
+        assert abs(t["total"] - total.item()) <= 5e-4 * abs(total.item())
         for n, ref in zip(("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica"), terms):
-            assert abs(t[n] - float(ref)) <= 2e-2 * abs(float(ref)) + 1e-7, n
+            assert abs(t[n] - float(ref)) <= 1e-2 * abs(float(ref)) + 1e-7, n
         names = [f"{g}.{k}" for g in O.GROUPS for k in params[g]] + ["mod.M"]
         # per-tensor errors are dominated by a few cancelling sums (bias gradients of the deep layers): gate the
         # whole gradient vector, and the median tensor
         num = sum(float((tr.view(n, tr.grads).cpu().double() - gr.double()).pow(2).sum()) for n, gr in zip(names, grads))
         den = sum(float(gr.double().pow(2).sum()) for gr in grads)
         errs = sorted((rel_err(tr.view(n, tr.grads), gr), n) for n, gr in zip(names, grads))
-        assert 1e-5 < (num / den) ** 0.5 < 3e-2, ((num / den) ** 0.5, errs[-3:])
-        assert errs[len(errs) // 2][0] < 1e-1, errs[len(errs) // 2]   # measured 3.5e-2 (net.tconv1.weight)
+        assert 1e-5 < (num / den) ** 0.5 < 6e-3, ((num / den) ** 0.5, errs[-3:])
+        assert errs[len(errs) // 2][0] < 7e-2, errs[len(errs) // 2]   # measured 3.7e-2
         adam = O.AdamState(leaves, ocfg.lr)
         for _ in range(3):
             tr.step()
@@ -660,8 +662,8 @@ def test_config5_composition_loader_k64_lbfgs():
 def test_bf16_storage_step_vs_fp32_oracle():
     """BASELINE configs[2] with bf16 STORAGE (TrainConfig.activation_storage='bf16'): the three reconstructions, the
     row / column residuals and every image-sized gradient live in HBM as bf16 (fp32 accumulation, master weights,
-    multipliers, losses, Adam).  Against the fp32 oracle: every logged term within 2e-2, the gradient vector within
-    5e-2 norm-wise, three Adam iterations; and the storage really is bf16 (the engine's x1 equals its own bf16
+    multipliers, losses, Adam).  Against the fp32 oracle: every logged term within 1e-2, the gradient vector within
+    6e-3 norm-wise, three Adam iterations; and the storage really is bf16 (the engine's x1 equals its own bf16
     rounding, and differs from the fp32-storage engine's)."""
     from lshm_amd import KHarmonicTrainer, TrainConfig
     B, K, bpb, bs = 4, 5, 2, 2
@@ -691,13 +693,14 @@ def test_bf16_storage_step_vs_fp32_oracle():
     for l in leaves:
         l.requires_grad_(False)
     t = tr.read_terms()
-    assert abs(t["total"] - total.item()) <= 2e-2 * abs(total.item())
+    # gates at ~4x the measured errors (profiles/bf16_error_probe.py: total 2.5e-5, worst term 2.3e-3, gradient vector 1.7e-3)
+    assert abs(t["total"] - total.item()) <= 5e-4 * abs(total.item())
     for n, rf in zip(("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica"), terms):
-        assert abs(t[n] - float(rf)) <= 2e-2 * abs(float(rf)) + 1e-7, n
+        assert abs(t[n] - float(rf)) <= 1e-2 * abs(float(rf)) + 1e-7, n
     names = [f"{g}.{k}" for g in O.GROUPS for k in params[g]] + ["mod.M"]
     num = sum(float((tr.view(n, tr.grads).cpu().double() - gr.double()).pow(2).sum()) for n, gr in zip(names, grads))
     den = sum(float(gr.double().pow(2).sum()) for gr in grads)
-    assert 1e-5 < (num / den) ** 0.5 < 5e-2, (num / den) ** 0.5
+    assert 1e-5 < (num / den) ** 0.5 < 6e-3, (num / den) ** 0.5
     adam = O.AdamState(leaves, ocfg.lr)
     for _ in range(3):
         tr.step()
