@@ -239,6 +239,13 @@ int lshm_asum_flat(const float* a, long n, double* out, float* workspace, lshm_s
 int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clamp,
                                     lshm_stream_t stream);
 
+/* its backward (the notebooks run the step on detached residuals; this makes the FFT second stage trainable):
+ * grad_out, out (B,2C,128,128) = gradient w.r.t. and value of the forward's output (the clamp passes the gradient
+ * where |out| < clamp); grad_x (B,C,128,128).  workspace >= lshm_fft2_backward_workspace_floats(B, C). */
+size_t lshm_fft2_backward_workspace_floats(int B, int C);
+int lshm_fft2_backward(const float* grad_out, const float* out, float* grad_x, int B, int C, float clamp,
+                       float* workspace, size_t workspace_floats, lshm_stream_t stream);
+
 /* ---- minibatch patch pipeline (tensor half of get_data_minibatch)      src/lofar_tools.py:113-193
  * vis (nb, ntime, nfreq, 4 pol, 2) int8, scale (nb, nfreq, 4) fp32  ->  y (px*py*nb, 4, patch, patch),
  * px = (max(ntime,patch)-patch)/(patch/2)+1, py likewise; patch-major order (:170-173); clamp (:187);

@@ -110,6 +110,8 @@ _SIGNATURES = {
     "lshm_comm_world": (c_int, [c_void_p]),
     "lshm_comm_allreduce_flat": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "lshm_engine_set_comm": (c_int, [c_void_p, c_void_p]),
+    "lshm_fft2_backward_workspace_floats": (c_size_t, [c_int, c_int]),
+    "lshm_fft2_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "lshm_engine_create": (c_int, [C.POINTER(StepConfig), C.POINTER(c_void_p)]),
     "lshm_engine_destroy": (None, [c_void_p]),
     "lshm_engine_param_count": (c_long, [c_void_p]),

@@ -265,6 +265,13 @@ int lshm_fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, fl
   return fft2_ortho_shift_cat_clamp(x, out, B, C, clampv, ST(s));
 }
 
+size_t lshm_fft2_backward_workspace_floats(int B, int C) { return (B > 0 && C > 0) ? fft2_backward_workspace_floats(B, C) : 0; }
+int lshm_fft2_backward(const float* grad_out, const float* out, float* grad_x, int B, int C, float clampv, float* ws,
+                       size_t wsf, lshm_stream_t s) {
+  REQUIRE(grad_out && out && grad_x && ws && B > 0 && C > 0, "fft2_backward: bad argument");
+  return fft2_feature_backward(grad_out, out, grad_x, B, C, clampv, ws, wsf, ST(s));
+}
+
 /* ---- `_bf16` forms of the GEMM-shaped entry points: same arguments, operands rounded to bf16 at LDS
  * staging (v_mfma_f32_16x16x16_bf16), fp32 accumulation and storage.  The precision is a property of the
  * call (scope of the calling thread), never of the process. */

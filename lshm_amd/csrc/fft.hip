@@ -212,4 +212,51 @@ int fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float c
   return check_launch("fft2");
 }
 
+// ---- backward of the feature step.  With Z[k] = F[(k + 64) mod 128] (per dimension), F the orthonormal DFT of the
+// real image x, and G = gRe + i gIm the gradient w.r.t. (Re Z, Im Z) -- zero where the forward clamp was active --
+//   dL/dx[m] = sum_k Re(conj(G[k]) dZ[k]/dx[m]) = (-1)^(m1+m2) * ( Re F(gRe)[m] + Im F(gIm)[m] ),
+// i.e. two more transforms of REAL images: the forward kernel runs on the 2C masked gradient planes (no clamp), and
+// because it stores F shifted, F(.)[m] is found at index (m + 64) mod 128 of its output.
+// g, y: (B, 2C, 128, 128) [Re planes | Im planes]; masked: same shape, scratch; spec: (B, 4C, 128, 128) scratch.
+__global__ void fft_mask_kernel(const float* __restrict__ g, const float* __restrict__ y, float clampv, long n,
+                                float* __restrict__ masked) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = y[i];
+    // torch.clamp passes the gradient where min <= input <= max; an output strictly inside the bounds was not clamped,
+    // one AT a bound came from an input at or beyond it (measure-zero difference, resolved as torch does for '>' / '<')
+    masked[i] = (v > -clampv && v < clampv) ? g[i] : 0.f;
+  }
+}
+__global__ void fft_combine_kernel(const float* __restrict__ spec, int C, long nimg, float* __restrict__ dx) {
+  // image (b, c): planes of spec for batch b are [Re F(gRe_0..C-1) | Re F(gIm_0..C-1) | Im F(gRe) | Im F(gIm)]
+  const long n = nimg * FFT_N * FFT_N;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int m2 = (int)(i % FFT_N), m1 = (int)((i / FFT_N) % FFT_N);
+    const long img = i / (FFT_N * FFT_N);
+    const long b = img / C, c = img - b * C;
+    const int s1 = (m1 + 64) & 127, s2 = (m2 + 64) & 127;
+    const long base = b * 4 * C * (long)(FFT_N * FFT_N) + (long)s1 * FFT_N + s2;
+    const float re_gre = spec[base + c * (long)(FFT_N * FFT_N)];
+    const float im_gim = spec[base + (3 * C + c) * (long)(FFT_N * FFT_N)];
+    const float v = re_gre + im_gim;
+    dx[i] = ((m1 + m2) & 1) ? -v : v;
+  }
+}
+size_t fft2_backward_workspace_floats(int B, int C) { return (size_t)B * 6 * C * FFT_N * FFT_N; }
+int fft2_feature_backward(const float* g, const float* y, float* dx, int B, int C, float clampv, float* ws, size_t wsf,
+                          hipStream_t st) {
+  if (wsf < fft2_backward_workspace_floats(B, C)) { set_last_error("fft2 backward: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  const long plane = (long)FFT_N * FFT_N;
+  float* masked = ws;                              // (B, 2C, 128, 128)
+  float* spec = ws + (size_t)B * 2 * C * plane;    // (B, 4C, 128, 128)
+  const long n = (long)B * 2 * C * plane;
+  hipLaunchKernelGGL(fft_mask_kernel, dim3(min(cdiv(n, 256), 8192)), dim3(256), 0, st, g, y, clampv, n, masked);
+  int rc = check_launch("fft_mask");
+  if (rc) return rc;
+  if ((rc = fft2_ortho_shift_cat_clamp(masked, spec, B, 2 * C, 3.0e38f, st))) return rc;
+  const long nd = (long)B * C * plane;
+  hipLaunchKernelGGL(fft_combine_kernel, dim3(min(cdiv(nd, 256), 8192)), dim3(256), 0, st, spec, C, (long)B * C, dx);
+  return check_launch("fft_combine");
+}
+
 }  // namespace lshm

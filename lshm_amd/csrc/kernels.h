@@ -334,5 +334,8 @@ int patches_normalize_moments(float* y, long n, const double* moments, hipStream
 // ---- batched 2D FFT feature op (fft.hip) ------------------------------------
 int fft2_ortho_shift_cat_clamp(const float* x, float* out, int B, int C, float clampv,
                                hipStream_t st);
+size_t fft2_backward_workspace_floats(int B, int C);
+int fft2_feature_backward(const float* g, const float* y, float* dx, int B, int C, float clampv, float* ws, size_t wsf,
+                          hipStream_t st);
 
 }  // namespace lshm

@@ -18,8 +18,9 @@ from .functional import fft_features
 def fft_cascade_forward(net, fnet, x: torch.Tensor, uv: torch.Tensor, clamp: float = 10.0,
                         detach_residual: bool = True):
     """(xhat, mu) = net(x, uv);  F = clamp(cat(Re, Im)(fftshift(fftn(x - xhat, ortho))));
-    (Fhat, fmu) = fnet(F, uv).  The FFT feature op has no backward (the notebooks only run it under
-    no_grad / on detached residuals), so the residual is detached unless the caller already did."""
+    (Fhat, fmu) = fnet(F, uv).  The notebooks run the FFT step on detached residuals (the default here);
+    with detach_residual=False the second stage is trainable end to end: the feature op has a backward
+    (lshm_fft2_backward), so gradients of a loss on Fhat / fmu reach `net` through the residual."""
     xhat, mu = net(x, uv)
     resid = x - xhat
     if detach_residual:

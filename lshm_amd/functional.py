@@ -341,15 +341,38 @@ def khm_assign(dist: torch.Tensor):
     return idx[0].to(torch.int64), prob
 
 
-@_on_tensor_device
+class _FFTFeatures(torch.autograd.Function):
+    """fftn(dim=(2,3), ortho) -> fftshift -> cat(real, imag) -> clamp (Demo.ipynb:169-175) with its backward."""
+
+    @staticmethod
+    @_on_tensor_device
+    def forward(ctx, r, clamp):
+        L.require_device(r)
+        r = r.contiguous()
+        if r.dim() != 4 or r.shape[2] != 128 or r.shape[3] != 128:
+            raise RuntimeError("fft_features expects (B, C, 128, 128)")
+        B, Cc = r.shape[0], r.shape[1]
+        out = torch.empty((B, 2 * Cc, 128, 128), device=r.device, dtype=torch.float32)
+        L.check(L.load().lshm_fft2_ortho_shift_cat_clamp(L.ptr(r), L.ptr(out), B, Cc, float(clamp), L.stream()), "fft2")
+        ctx.save_for_backward(out)
+        ctx.clamp = float(clamp)
+        return out
+
+    @staticmethod
+    @_on_tensor_device
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        B, Cc = out.shape[0], out.shape[1] // 2
+        g = g.contiguous()
+        lib = L.load()
+        nws = lib.lshm_fft2_backward_workspace_floats(B, Cc)
+        ws = torch.empty(nws, device=g.device, dtype=torch.float32)
+        dx = torch.empty((B, Cc, 128, 128), device=g.device, dtype=torch.float32)
+        L.check(lib.lshm_fft2_backward(L.ptr(g), L.ptr(out), L.ptr(dx), B, Cc, ctx.clamp, L.ptr(ws), nws, L.stream()),
+                "fft2_backward")
+        return dx, None
+
+
 def fft_features(r: torch.Tensor, clamp: float = 10.0) -> torch.Tensor:
-    """fftn(dim=(2,3), ortho) -> fftshift -> cat(real, imag) -> clamp (Demo.ipynb:169-175)."""
-    L.require_device(r)
-    r = r.detach().contiguous()
-    if r.dim() != 4 or r.shape[2] != 128 or r.shape[3] != 128:
-        raise RuntimeError("fft_features expects (B, C, 128, 128)")
-    B, Cc = r.shape[0], r.shape[1]
-    out = torch.empty((B, 2 * Cc, 128, 128), device=r.device, dtype=torch.float32)
-    L.check(L.load().lshm_fft2_ortho_shift_cat_clamp(L.ptr(r), L.ptr(out), B, Cc, float(clamp), L.stream()),
-            "fft2")
-    return out
+    """fftn(dim=(2,3), ortho) -> fftshift -> cat(real, imag) -> clamp (Demo.ipynb:169-175); differentiable."""
+    return _FFTFeatures.apply(r, clamp)

@@ -333,6 +333,59 @@ def test_fft_features_vs_golden_and_known_answers():
     assert o.abs().max() < 1e-3
 
 
+@pytest.mark.parametrize("B,C,scale,clamp", [(2, 4, 3.0, 10.0), (1, 1, 1.0, 1e9), (3, 8, 3.0, 2.0)])
+def test_fft_features_backward_vs_autograd(B, C, scale, clamp):
+    """The feature step is differentiable (lshm_fft2_backward): gradient w.r.t. the real input against torch autograd
+    through torch.fft.fftn + roll + cat + clamp (the oracle's restatement of Demo.ipynb:169-175 and
+    src/lofar_tools.py:24-30), with the clamp active on part of the spectrum."""
+    Fh = _F()
+    r = O.closed_form((B, C, 128, 128), f"fftb:{B}{C}", scale, 0.37)
+    gy = O.closed_form((B, 2 * C, 128, 128), f"fftb:g{B}{C}", 1.0, 0.91)
+    rc = r.clone().requires_grad_(True)
+    (O.fft_features(rc, clamp) * gy).sum().backward()
+    rg = r.to(DEV).requires_grad_(True)
+    out = Fh.fft_features(rg, clamp)
+    (out * gy.to(DEV)).sum().backward()
+    if clamp < 1e8:
+        frac = float((out.detach().abs() >= clamp).float().mean())
+        assert 0.0 < frac < 0.9, frac         # the clamp bites somewhere and not everywhere
+    assert rel_err(rg.grad, rc.grad) < 5e-6
+    # adjointness without the clamp: <F x, g> == <x, F^T g>
+    if clamp >= 1e8:
+        lhs = float((out.detach().double() * gy.to(DEV).double()).sum())
+        rhs = float((r.to(DEV).double() * rg.grad.double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * abs(lhs)
+
+
+def test_fft_cascade_trains_end_to_end():
+    """feature_mode='fft' as a trainable second stage: with detach_residual=False a loss on the second autoencoder's
+    output back-propagates through the FFT feature op into the first autoencoder (same gradient as the oracle
+    composition built from torch ops)."""
+    from lshm_amd.fft_cascade import fft_cascade_forward
+    from lshm_amd.lofar_models import AutoEncoderCNN2
+    hs = torch.tensor(O.DEFAULT_SCALES)
+    torch.manual_seed(0)
+    net = AutoEncoderCNN2(32, 4, hs, True)
+    fnet = AutoEncoderCNN2(16, 8, hs, True)
+    x, uv = O.closed_form_inputs(2, 4)
+    sd, fsd = net.state_dict(), fnet.state_dict()
+    # oracle side (CPU, torch ops)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xhat, mu = O.ae_forward(p, x, uv, hs, 2, True)
+    Fx = O.fft_features(x - xhat, 10.0)
+    Fhat, fmu = O.ae_forward({k: v.clone() for k, v in fsd.items()}, Fx, uv, hs, 2, True)
+    loss_ref = ((Fhat - Fx) ** 2).mean() + fmu.mean()
+    gref = torch.autograd.grad(loss_ref, [p["conv0.weight"], p["tconv5.bias"]])
+    net, fnet = net.to(DEV), fnet.to(DEV)
+    net.harmonic_scales = fnet.harmonic_scales = hs.to(DEV)
+    xh, mu_, Fx_, Fhat_, fmu_ = fft_cascade_forward(net, fnet, x.to(DEV), uv.to(DEV), detach_residual=False)
+    loss = ((Fhat_ - Fx_) ** 2).mean() + fmu_.mean()
+    loss.backward()
+    assert abs(loss.item() - loss_ref.item()) <= 1e-4 * abs(loss_ref.item())
+    assert rel_err(net.conv0.weight.grad, gref[0]) < 2e-3
+    assert rel_err(net.tconv5.bias.grad, gref[1]) < 2e-3
+
+
 def test_full_size_conv_linearity_and_adjointness():
     """B=256 layer kernels (direct LDS-patch paths) through size-independent properties:
     linearity in the input and <conv(x), y> == <x, conv^T(y)> (the transposed conv is the adjoint)."""
