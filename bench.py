@@ -93,18 +93,21 @@ def khm_roofline(dev, N=1 << 20, D=256, K=10, p=4.0):
                                      D, L.ptr(dM), 0, L.ptr(ws), nws, L.stream()))
     ms = event_time_ms(run, 10)
     nbytes = 8.0 * (N * D + K * D)
-    flop = 7.0 * N * K * D
     ach = nbytes / (ms * 1e-3) / 1e9
-    out = {"kernel": ("khm256_kernel<0,...> + khm_reduce" if K <= 16 else "khm_rowsplit_kernel + khm_reduce") + " (fused fwd+bwd)",
-           "shape": f"N={N},D={D},K={K}", "bound": "hbm",
-           "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-           "ms": round(ms, 4), "bytes_per_launch": nbytes,
-           "traffic": _pmc_traffic("khm256_kernel<0" if K <= 16 else "khm_rowsplit_kernel<0", f"khm_N{N}_K{K}") if N == 1 << 20 else None}
-    if K > 16:  # arithmetic intensity ~7 K / 8 flop per byte: at K = 64 the fp32 vector pipe is the other candidate bound
-        vec = flop / (ms * 1e-3) / 1e12
-        out["vector_f32"] = {"achieved": round(vec, 2), "peak": 157.3, "unit": "TFLOP/s", "frac": round(vec / 157.3, 4),
-                             "note": "~7 N K D flop on the fp32 vector pipe (SURVEY 8d: compute-leaning at K=64)"}
-    return out
+    if K <= 16:
+        return {"kernel": "khm256_kernel<0,...> + khm_reduce (fused fwd+bwd)", "shape": f"N={N},D={D},K={K}", "bound": "hbm",
+                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "ms": round(ms, 4), "bytes_per_launch": nbytes,
+                "traffic": _pmc_traffic("khm256_kernel<0", f"khm_N{N}_K{K}") if N == 1 << 20 else None}
+    # 16 < K <= 64: three K x D x N products on the fp32 matrix cores (S = X M^T, W M, W^T X): 6 N K D flop for
+    # 8 N D bytes -- arithmetic intensity 48 flop/B at K = 64 against a ridge of ~20: the matrix pipe is the bound
+    flop = 6.0 * N * K * D
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"kernel": "khm_mfma_kernel<0> + khm_reduce (fused fwd+bwd, v_mfma_f32_16x16x4_f32)", "shape": f"N={N},D={D},K={K}",
+            "bound": "mfma", "achieved": round(tf, 1), "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4),
+            "ms": round(ms, 4), "flop_per_launch": flop, "bytes_per_launch": nbytes,
+            "hbm": {"achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)},
+            "traffic": _pmc_traffic("khm_mfma_kernel<0", f"khm_N{N}_K{K}") if N == 1 << 20 else None}
 
 
 def khm_distance_roofline(dev, N=1 << 20, D=256, K=10, p=4.0):

@@ -12,6 +12,8 @@
 // (sum_i w_ik and sum_i w_ik x_i) live in registers per wave, are combined in a
 // fixed order through LDS per workgroup and over workgroups by a second kernel:
 // bitwise reproducible, no float atomics.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace lshm {
@@ -468,6 +470,227 @@ __global__ __launch_bounds__(KHM_FAST_THREADS) void khm256_kernel(
   }
 }
 
+// --------------------------------------------------------------------------
+// 16 < K <= 64, latent_dim == 256 (config 5: K = 64) on the matrix cores.  At K = 64 the all-pairs work is
+// ~7 N K D flop for 8 N D bytes (arithmetic intensity ~56 flop/B): compute-bound, and as per-centroid wavefront
+// reductions it is also instruction-bound (the row-split form above: 45 ms at N = 2^20).  Here the three K x D x N
+// products are v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulation):
+//   S^T = M X^T            squared distances as  s_ik = |x_i|^2 + |m_k|^2 - 2 S_ik   (clamped at 0)
+//   (W M)^T = M^T W^T      dX_i = (sum_k w_ik) x_i - (W M)_i
+//   T = W^T X              dM_k = (sum_i w_ik) m_k - T_k          (finished by khm_reduce_kernel)
+// The expansion of the squared distance cancels where x_i is within rounding of m_k: its absolute error is
+// ~1e-7 (|x|^2 + |m|^2), against the exact (x - m)^2 form of the other kernels -- stated in the tests that compare
+// this path (relative tolerance 2e-5 on well-separated data, as the others; a latent that coincides with a
+// centroid to 1e-3 relative loses the p-th power's leading digits).
+// A workgroup = 4 wavefronts walks tiles of 64 rows, 16 per wavefront.  Register layouts (lane = 16 lk + lm):
+//   X   : xv[e][t] = X[row lm][16 e + 4 lk + t]                   (float4 loads, 64 B per row per instruction)
+//   S^T : acc[j][r] = S[row lm][centroid 16 j + 4 lk + r]           -> a lane owns 16 centroids of ITS row: the
+//         soft-min sums over k are in-lane adds plus two shuffles, and the same registers are the B operand
+//         (k index = centroid) of the second product with no data movement
+//   dX  : C[r] = (W M)[row lm][16 dt + 4 lk + r]                    -> same positions as xv[dt][r]: float4 stores
+//   T   : per wavefront w the columns 64 w .. 64 w + 63 of all K rows, K dimension = the 64 rows of the tile,
+//         operands from LDS copies of the tile (rows must run along lk there).
+// LDS: the centroids in fragment order (one conflict-free ds_read_b128 per A fragment of the first product, 64 KB),
+// the X tile (68 KB), the W tile (20 KB): 152 KB, one workgroup per CU.
+// --------------------------------------------------------------------------
+#define KHM_MM_XP 272  // X tile row pitch (floats): == 16 (mod 32), rows 4 s + lk land on distinct banks
+#define KHM_MM_WP 80   // W tile row pitch
+template <int MODE>
+__global__ __launch_bounds__(256) void khm_mfma_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ Mg, int N, int K, float p, int pint, float eps,
+    float wscale, float* __restrict__ dX, long lddx, int accumulate_dx, float* __restrict__ partial /* [grid][K*256 + K] */,
+    double* __restrict__ loss_partial /* [grid] */) {
+  constexpr int D = 256;
+  extern __shared__ float lds[];
+  float* MA = lds;                       // [4 j][16 e][64 lanes][4]: M[16 j + lm][16 e + 4 lk + t]
+  float* XT = MA + 4 * 16 * 64 * 4;      // [64 rows][KHM_MM_XP]
+  float* WT = XT + 64 * KHM_MM_XP;       // [64 rows][KHM_MM_WP]
+  float* mn = WT + 64 * KHM_MM_WP;       // [64] |m_k|^2
+  float* sred = mn + 64;                 // [4 waves][64] closing sums
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lm = lane & 15, lk = lane >> 4;
+  // ---- centroids -> fragment order (rows >= K are zero), |m_k|^2
+  for (int i = t; i < 4 * 16 * 64; i += 256) {
+    const int ln = i & 63, e = (i >> 6) & 15, j = i >> 10;
+    const int c = 16 * j + (ln & 15), col = 16 * e + 4 * (ln >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (c < K) v = *reinterpret_cast<const f32x4*>(Mg + (long)c * D + col);
+    *reinterpret_cast<f32x4*>(MA + 4 * i) = v;
+  }
+  if (t < 64) {
+    float a = 0.f;
+    if (t < K)
+      for (int d = 0; d < D; ++d) { const float v = Mg[(long)t * D + d]; a = fmaf(v, v, a); }
+    mn[t] = a;
+  }
+  __syncthreads();
+
+  f32x4 T[4][4];     // T[j][n][r] = sum_i w[i][16 j + 4 lk + r] * X[i][64 wave + 16 n + lm]
+  float Ssum[4][4];  // this lane's row only: sum over tiles of w[row][16 j + 4 lk + r]
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) { T[j][n] = (f32x4){0.f, 0.f, 0.f, 0.f}; Ssum[j][n] = 0.f; }
+  double lsum = 0.0;
+  const int ntiles = (N + 63) / 64;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row = tile * 64 + 16 * wave + lm;
+    const bool rok = row < N;
+    const float* xr = X + (long)(rok ? row : 0) * ldx + 4 * lk;
+    f32x4 xv[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) xv[e] = rok ? *reinterpret_cast<const f32x4*>(xr + 16 * e) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- S^T = M X^T
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float x2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x2 = fmaf(xv[e][q], xv[e][q], x2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(MA + ((j * 16 + e) * 64 + lane) * 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], xv[e][q], acc[j], 0, 0, 0);
+      }
+    }
+    x2 += __shfl_xor(x2, 16, 64);
+    x2 += __shfl_xor(x2, 32, 64);
+    // ---- soft-min weights of this lane's 16 centroids
+    float w[4][4], ph[4][4], s2[4][4];
+    float einv = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * j + 4 * lk + r;
+        const bool ok = rok && c < K;
+        const float sq = fmaxf(x2 + mn[c] - 2.f * acc[j][r], 0.f);
+        s2[j][r] = sq;
+        ph[j][r] = pow_half(sq, p, pint);
+        if (MODE != KHM_DIST) einv += ok ? 1.f / (ph[j][r] + eps) : 0.f;
+      }
+    float wsum = 0.f;
+    if (MODE == KHM_DIST) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[j][r] = (rok && 16 * j + 4 * lk + r < K) ? ph[j][r] : 0.f;
+    } else {
+      einv += __shfl_xor(einv, 16, 64);
+      einv += __shfl_xor(einv, 32, 64);
+      const float ee = einv + eps;
+      if (MODE == KHM_FWD_BWD && rok && lk == 0) lsum += (double)((float)K / ee);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool ok = rok && 16 * j + 4 * lk + r < K;
+          const float inv = 1.f / (ph[j][r] + eps);
+          float wv;
+          if (MODE == KHM_FWD_BWD) wv = wscale / (ee * ee) * p * pow_half_m1(s2[j][r], p, pint) * inv * inv;
+          else wv = (1.f / (einv * einv + eps)) / (ph[j][r] * s2[j][r] + eps);
+          w[j][r] = ok ? wv : 0.f;
+          wsum += w[j][r];
+        }
+      wsum += __shfl_xor(wsum, 16, 64);
+      wsum += __shfl_xor(wsum, 32, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ssum[j][r] += w[j][r];
+    if (MODE == KHM_DIST) continue;  // (no barriers on this path)
+    // ---- dX = wsum x - W M   (A = M^T gathered from the fragment image, B = the w registers)
+    if (MODE == KHM_FWD_BWD && dX) {
+      float* dr = dX + (long)(rok ? row : 0) * lddx + 4 * lk;
+#pragma unroll
+      for (int dt = 0; dt < 16; ++dt) {  // fully unrolled: xv[dt] must stay in registers
+        f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+        // element M[16 j + 4 lk + r][16 dt + lm] of the fragment image (j, e = dt): lane' = 16 (lm / 4) + 4 lk + r, t = lm % 4
+        const float* mb = MA + (dt * 64 + (lm >> 2) * 16 + 4 * lk) * 4 + (lm & 3);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(mb[(j * 16 * 64 + r) * 4], w[j][r], c4, 0, 0, 0);
+        if (rok) {
+          f32x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = fmaf(wsum, xv[dt][r], -c4[r]);
+          f32x4* dp = reinterpret_cast<f32x4*>(dr + 16 * dt);
+          *dp = accumulate_dx ? *dp + o : o;
+        }
+      }
+    }
+    // ---- T += W^T X over the 64 rows of the tile: rows must run along lk, so both go through LDS
+    __syncthreads();  // the previous tile's readers are done
+    {
+      float* xw = XT + (16 * wave + lm) * KHM_MM_XP + 4 * lk;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) *reinterpret_cast<f32x4*>(xw + 16 * e) = xv[e];
+      float* ww = WT + (16 * wave + lm) * KHM_MM_WP + 4 * lk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(ww + 16 * j) = (f32x4){w[j][0], w[j][1], w[j][2], w[j][3]};
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < 16; ++s) {
+      const float* wrow = WT + (4 * s + lk) * KHM_MM_WP + lm;
+      const float* xrow = XT + (4 * s + lk) * KHM_MM_XP + 64 * wave + lm;
+      float a[4], b[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = wrow[16 * j];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = xrow[16 * n];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) T[j][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[n], T[j][n], 0, 0, 0);
+    }
+  }
+  // ---- slab of this workgroup: T (K x 256), S_k = sum_i w_ik (K), loss partial
+  const int slab = K * D + K;
+  float* out = partial + (size_t)blockIdx.x * slab;
+  if (MODE != KHM_DIST) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * j + 4 * lk + r;
+          if (c < K) out[c * D + 64 * wave + 16 * n + lm] = T[j][n][r];
+        }
+  }
+  // S_k: sum over the 16 rows of a wavefront (DPP row = the 16 lanes that share lk), then over the 4 wavefronts
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = row16_allsum(Ssum[j][r]);
+      if (lm == 0) sred[wave * 64 + 16 * j + 4 * lk + r] = v;
+    }
+  __syncthreads();
+  if (t < K) out[K * D + t] = (sred[t] + sred[64 + t]) + (sred[128 + t] + sred[192 + t]);
+  if (loss_partial) {
+    // rows are spread over the lk == 0 lanes of all wavefronts: fixed-order sum
+    __shared__ double lred[4];
+    const double tot = wave_sum_d(lsum);
+    if (lane == 0) lred[wave] = tot;
+    __syncthreads();
+    if (t == 0) loss_partial[blockIdx.x] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+  }
+}
+static size_t khm_mfma_lds_bytes() { return (size_t)(4 * 16 * 64 * 4 + 64 * KHM_MM_XP + 64 * KHM_MM_WP + 64 + 256) * sizeof(float); }
+static bool khm_mfma_ok(int D, int K, long ldx, long lddx, const float* X, const float* dX, const float* M) {
+  static const bool off = getenv("LSHM_KHM_MFMA_OFF") != nullptr;
+  return !off && D == 256 && K > 16 && K <= 64 && (ldx % 4) == 0 && (lddx % 4) == 0 &&
+         ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(M)) & 15) == 0;
+}
+
 // second stage.  MODE fwd_bwd: dM[k,:] (+)= (sum S_k) M[k,:] - sum T_k ; loss = sum partial
 //               offline  : num = sum T, den = sum S
 //               dist     : dist[k] = sum S_k / N
@@ -534,6 +757,10 @@ static bool khm_fast(int D, int K, long ldx, long lddx) {
   return D == 256 && K <= 16 && (ldx % 4) == 0 && (lddx % 4) == 0;
 }
 static int khm_grid(int N, int D, int K) {
+  if (D == 256 && K > 16) {  // matrix-core path: 64 rows per workgroup pass, one workgroup per CU (also bounds the
+    int g = cdiv(N, 64);     // row-split fallback's grid: the workspace is sized from this number)
+    return g < 1 ? 1 : (g > 256 ? 256 : g);
+  }
   if (D == 256 && K <= 16) {  // fast path: 16 rows per workgroup pass, persistent grid
     int g = cdiv(N, 16);
     return g < 1 ? 1 : (g > 768 ? 768 : g);
@@ -643,6 +870,15 @@ static int khm_run(const float* X, long ldx, const float* M, int N, int D, int K
     else KHM_FAST(16);
 #undef KHM_FAST
     rc = check_launch("khm256");
+  } else if (khm_mfma_ok(D, K, ldx, dX ? lddx : 0, X, dX, M)) {
+    auto kern = khm_mfma_kernel<MODE>;
+    const size_t lds_bytes = khm_mfma_lds_bytes();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds_bytes);
+    if (e != hipSuccess) { set_last_error("khm: cannot raise dynamic LDS limit"); return (int)e; }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, X, ldx, M, N, K, p, pint, eps, wscale, dX, lddx, acc_dx,
+                       partial, lpart);
+    rc = check_launch("khm_mfma");
   } else if (K > 16) {  // row-split form: RS wavefronts per row
 #define KHM_RS(RSV) rc = khm_launch_rowsplit_kt<MODE, RSV>(grid, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx, acc_dx, partial, lpart)
     if (nc <= 1) KHM_RS(1);
