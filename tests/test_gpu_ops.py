@@ -244,6 +244,39 @@ def test_distance_epilogues_argmin_and_softmax(K):
     assert int(i2) == 0 and rel_err(p2, torch.full((K,), 1.0 / K)) < 1e-6
 
 
+@pytest.mark.parametrize("N,K,p", [(1, 17, 4), (64, 64, 4), (65, 33, 2), (1000, 48, 4), (257, 64, 3)])
+def test_khm_matrix_core_kernel_vs_fp64(N, K, p):
+    """16 < K <= 64 at latent_dim 256 runs on the matrix cores with the squared distance expanded as
+    |x|^2 + |m|^2 - 2 x.m (lshm_amd/csrc/khm.hip: khm_mfma_kernel).  On separated data (every distance well above
+    rounding of the norms) loss, both gradients, the offline partial sums and the evaluation distances match the fp64
+    formula to the same 2e-5 as the exact-difference kernels; the stated loss of accuracy is for points that coincide
+    with a centroid: there the expansion's absolute error ~1e-7 (|x|^2 + |m|^2) shows, and the test bounds it."""
+    Fh = _F()
+    D = 256
+    X = 0.8 * O.closed_form((N, D), f"mm:X{N}", 1.0, 0.4142) + 0.3
+    M = 0.5 + 0.5 * O.closed_form((K, D), f"mm:M{K}", 1.0, 0.618)
+    Xg, Mg = X.to(DEV).requires_grad_(True), M.to(DEV).requires_grad_(True)
+    loss = Fh.khm_loss(Xg, Mg, p)
+    loss.backward()
+    lo, dXo, dMo = O.khm_grads(X.double(), M.double(), p)
+    assert abs(loss.item() - lo.item()) <= 1e-5 * abs(lo.item())
+    assert rel_err(Xg.grad, dXo) < 2e-5 and rel_err(Mg.grad, dMo) < 2e-5
+    num, den = Fh.khm_offline_partials(X.to(DEV), M.to(DEV), p)
+    no, do = O.khm_offline_partials(X.double(), M.double(), p)
+    assert rel_err(num, no) < 2e-5 and rel_err(den, do) < 2e-5
+    dist = Fh.khm_mean_distances(X.to(DEV), M.to(DEV), p)
+    dref = ((X[:, None, :].double() - M[None].double()) ** 2).sum(-1).pow(p / 2).mean(0)
+    assert rel_err(dist, dref) < 1e-5
+    # a row that IS a centroid: squared distance 0 up to the cancellation error, everything stays finite
+    X2 = X.clone()
+    X2[0] = M[1]
+    d2 = Fh.khm_mean_distances(X2[:1].to(DEV), M.to(DEV), 2)   # p = 2: the squared distance itself
+    assert abs(float(d2[1])) <= 4e-7 * float((M[1].double() ** 2).sum() * 2)
+    Xc, Mc = X2.to(DEV).requires_grad_(True), M.to(DEV).requires_grad_(True)
+    Fh.khm_loss(Xc, Mc, p).backward()
+    assert torch.isfinite(Xc.grad).all() and torch.isfinite(Mc.grad).all()
+
+
 def test_kmeans_module_offline_update_and_state_dict():
     from lshm_amd.lofar_models import Kmeans
     mod = Kmeans(latent_dim=256, K=10, p=4)
@@ -447,12 +480,14 @@ def test_conv_fwd_pair_matches_two_single_launches():
             assert rel_err(pair[i], single[i]) < 1e-6
 
 
-def test_full_size_khm_streaming_properties():
+@pytest.mark.parametrize("K", [10, 64], ids=["K10-stream-kernel", "K64-matrix-core-kernel"])
+def test_full_size_khm_streaming_properties(K):
     """N = 2^20 rows (the streaming shape): loss of the concatenation is the mean of the two halves'
-    losses, dM adds, dX rows are independent; K-harmonic loss is invariant to a row permutation."""
+    losses, dM adds, dX rows are independent; K-harmonic loss is invariant to a row permutation.  K = 64
+    (config 5) takes the matrix-core kernel, K = 10 the streaming one."""
     Fh = _F()
     g = torch.Generator().manual_seed(9)
-    N, D, K = 1 << 20, 256, 10
+    N, D = 1 << 20, 256
     X = torch.rand(N, D, generator=g).to(DEV)
     M = torch.rand(K, D, generator=g).to(DEV)
     Xg, Mg = X.clone().requires_grad_(True), M.clone().requires_grad_(True)
