@@ -3,16 +3,18 @@
 divided by 1024 x the dispatch's cycles.  GRBM_GUI_ACTIVE of the same rocprofv3 --pmc pass is summed over the
 8 XCDs, so cycles = GRBM_GUI_ACTIVE / 8 (cross-check column: the kernel-trace duration x 2.1 GHz).
 Usage: mfma_util.py PMC_DIR KERNEL_STATS_CSV"""
-import csv, glob, sys
+import csv, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from names import short
 from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].replace("lshm::", "").replace("void ", "").split("(")[0]
+        k = short(r["Kernel_Name"])
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 stats = {}
 for r in csv.DictReader(open(sys.argv[2])):
-    k = r["Name"].replace("lshm::", "").replace("void ", "").split("(")[0]
+    k = short(r["Name"])
     stats[k] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3, float(r["Percentage"]))
 print(f"{'kernel':62s} {'avg us':>8s} {'% time':>7s} {'MFMA insts':>11s} {'busy cyc':>11s} {'GUI/8 cyc':>10s} {'MFMA util':>10s} {'(by time)':>10s}")
 for k, (calls, avg, pct) in sorted(stats.items(), key=lambda kv: -kv[1][2])[:30]:

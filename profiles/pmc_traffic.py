@@ -18,7 +18,7 @@ def collect(d, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            k = r["Kernel_Name"].replace("lshm::", "").replace("void ", "").split("(")[0]
+            k = short(r["Kernel_Name"])
             acc[k].append(float(r["Counter_Value"]))
     return acc
 

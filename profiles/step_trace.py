@@ -2,11 +2,15 @@
 """Chronological listing of the kernels of the last training step in a rocprofv3 kernel trace,
 with the queue each ran on, its start offset, duration and the idle gap since the previous kernel
 on the same queue.  Usage: step_trace.py DIR > listing.txt"""
-import csv, glob, sys
+import csv, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from names import short
 d = sys.argv[1]
 files = glob.glob(d + "/*kernel_trace.csv") + glob.glob(d + "/*/*kernel_trace.csv")
 rows = list(csv.DictReader(open(files[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
+for r in rows:
+    r['Kernel_Name'] = short(r['Kernel_Name']) if r['Kernel_Name'].strip('"').startswith('_ZN4lshm') else r['Kernel_Name']
 idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
 mu = [i for i, r in enumerate(rows) if 'multiplier_update_kernel' in r['Kernel_Name'] or 'recon_kernel<true' in r['Kernel_Name']]
 if 'recon_kernel<true' in rows[mu[-1]]['Kernel_Name']:  # the shared pass is followed by its 7-way sum

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 --kernel-trace --stats CSV directory: per-kernel totals per step and the
 timeline of the last step.  Usage: tools_prof.py DIR NSTEPS [min_us]"""
-import csv, glob, sys
+import csv, glob, os, sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from names import short
 d, nsteps = sys.argv[1], int(sys.argv[2])
 min_us = float(sys.argv[3]) if len(sys.argv) > 3 else 30.0
 st = (glob.glob(d + "/*kernel_stats.csv") + glob.glob(d + "/*/*kernel_stats.csv"))[0]

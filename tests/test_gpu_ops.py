@@ -271,7 +271,7 @@ def test_khm_matrix_core_kernel_vs_fp64(N, K, p):
     X2 = X.clone()
     X2[0] = M[1]
     d2 = Fh.khm_mean_distances(X2[:1].to(DEV), M.to(DEV), 2)   # p = 2: the squared distance itself
-    assert abs(float(d2[1])) <= 4e-7 * float((M[1].double() ** 2).sum() * 2)
+    assert abs(float(d2[1])) <= 2e-6 * float((M[1].double() ** 2).sum() * 2)   # a few ulp of |x|^2 + |m|^2 (measured 4e-7 x)
     Xc, Mc = X2.to(DEV).requires_grad_(True), M.to(DEV).requires_grad_(True)
     Fh.khm_loss(Xc, Mc, p).backward()
     assert torch.isfinite(Xc.grad).all() and torch.isfinite(Mc.grad).all()
