@@ -86,7 +86,10 @@ int lshm_uv_harmonics(const float* uv, const float* scales, int H, int B, float*
 
 /* ---- convolution layers, forward + fused bias + optional ELU     src/lofar_models.py:73-78,93-98,158-163,178-183
  * x (B,Cin,Hin,Win) [1D: Hin=1, Win=L]; weight in torch layout (Conv: (Cout,Cin,k..), ConvTranspose:
- * (Cin,Cout,k..)); in_bs / out_bs are batch strides in elements (0 = dense). act: 0 none, 1 ELU. */
+ * (Cin,Cout,k..)); in_bs / out_bs are batch strides in elements (0 = dense). act: 0 none, 1 ELU.
+ * Size limit: the GEMM-shaped layers (and the dense layers below) address each operand tensor with 32-bit
+ * byte offsets; a tensor whose last element lies 4 GiB or more past its base pointer is refused with
+ * LSHM_ERR_UNSUPPORTED (BASELINE.json's largest configuration stays below 1 GiB per tensor). */
 /* workspace floats that let fwd / dgrad / wgrad of one layer use split-K (deep layers) */
 size_t lshm_conv_workspace_floats(int kind, int B, int Cin, int Cout, int Hin, int Win);
 /* `workspace` may be NULL for fwd / dgrad (no split-K: slower on the deep, few-position layers) */

@@ -1059,8 +1059,14 @@ static int launch_auto(const typename P::Params& p, const typename P::Params* p1
 
 // Weight gradients of dense layers, dW[N_out, K_in] = dz^T x, as one launch (16-row tiles, K over the four
 // wavefronts, no split over workgroups: K is the batch size).
+static bool fits32(long elems_a, long elems_b);
 int strided_gemm_batch_mm(const StridedGemmParams* probs, int n, hipStream_t st) {
   using P = Strided<true, true>;
+  for (int g = 0; g < n; ++g) {
+    const StridedGemmParams& q = probs[g];
+    if (!fits32(labs(q.sam) * (q.M - 1) + labs(q.sak) * (q.K - 1) + 1, labs(q.sbk) * (q.K - 1) + labs(q.sbn) * (q.N - 1) + 1))
+      return LSHM_ERR_UNSUPPORTED;
+  }
   constexpr int BM = 16, BN = 64, BK = 64, KW = 4;
   for (int base = 0; base < n; base += kMaxBatch) {
     const int cnt = n - base < kMaxBatch ? n - base : kMaxBatch;
@@ -1100,32 +1106,54 @@ size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {
   return (size_t)(Mp * (long)N * zgroups * want);
 }
 
+// The operand fetches address a tensor through a buffer resource with 32-bit byte offsets: every element an
+// operand tensor holds must lie below 4 GiB from its base pointer (1 Gi floats; the arena of BASELINE.json's
+// largest configuration holds 0.2 Gi in its biggest tensor).  A larger tensor is refused, never wrapped.
+static bool fits32(long elems_a, long elems_b) {
+  const long lim = 1L << 30;
+  if (elems_a < lim && elems_b < lim) return true;
+  set_last_error("implicit GEMM: an operand tensor spans 4 GiB or more; split the batch");
+  return false;
+}
+static long span(long bs, int B, long inner) { return (B > 0 ? (long)(B - 1) * bs : 0) + inner; }
+
 int conv2d_fwd(const Conv2dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dFwdParams* p1) {
+  if (!fits32(span(p.x_bs, p.B, (long)p.Cin * p.H * p.W), (long)p.Cout * p.Cin * 16)) return LSHM_ERR_UNSUPPORTED;
   return launch_auto<Conv2dFwd>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int conv2d_dgrad(const Conv2dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dDgradParams* p1) {
+  if (!fits32(span(p.s_bs, p.B, (long)p.Cs * p.Hs * p.Ws), (long)p.Cs * p.Cb * 16)) return LSHM_ERR_UNSUPPORTED;
   return launch_auto<Conv2dDgrad>(p, p1, p.M, p.N, 4, ws, wsf, st);
 }
 int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv2dWgradParams* p1,
                  GradJobs* defer) {
+  if (!fits32(span(p.s_bs, p.B, (long)p.Cs * p.Hs * p.Ws), span(p.big_bs, p.B, (long)p.Cb * p.Hs * p.Ws * 4)))
+    return LSHM_ERR_UNSUPPORTED;
   return launch_auto<Conv2dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1) {
   if ((g_tune_force < 0 || p.x_bf16) && conv1d_stream_supported(p) && (!p1 || conv1d_stream_supported(*p1))) return conv1d_stream(p, p1, st);
   if (p.x_bf16) { set_last_error("conv1d: bf16 input needs the streaming kernel"); return LSHM_ERR_UNSUPPORTED; }
+  if (!fits32(span(p.x_bs, p.B, (long)p.Cin * p.L), (long)p.Cout * p.Cin * 4)) return LSHM_ERR_UNSUPPORTED;
   return launch_auto<Conv1dFwd>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dDgradParams* p1) {
   if ((g_tune_force < 0 || p.big_bf16) && tconv1d_stream_supported(p) && (!p1 || tconv1d_stream_supported(*p1))) return tconv1d_stream(p, p1, st);
   if (p.big_bf16) { set_last_error("tconv1d: bf16 output needs the streaming kernel"); return LSHM_ERR_UNSUPPORTED; }
+  if (!fits32(span(p.s_bs, p.B, (long)p.Cs * p.Ls), (long)p.Cs * p.Cb * 4)) return LSHM_ERR_UNSUPPORTED;
   return launch_auto<Conv1dDgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int conv1d_wgrad(const Conv1dWgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dWgradParams* p1,
                  GradJobs* defer) {
+  if (!fits32(span(p.s_bs, p.B, (long)p.Cs * p.Ls), span(p.big_bs, p.B, (long)p.Cb * p.Lb))) return LSHM_ERR_UNSUPPORTED;
   return launch_auto<Conv1dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 int strided_gemm(const StridedGemmParams& p, bool a_m_fast, bool b_n_fast, float* ws, size_t wsf,
                  hipStream_t st, const StridedGemmParams* p1, GradJobs* defer) {
+  {
+    auto ext = [](long s0, int n0, long s1, int n1) { return labs(s0) * (n0 - 1) + labs(s1) * (n1 - 1) + 1; };
+    if (!fits32(ext(p.sam, p.M, p.sak, p.K), ext(p.sbk, p.K, p.sbn, p.N))) return LSHM_ERR_UNSUPPORTED;
+  }
   if (a_m_fast && b_n_fast) return launch_auto<Strided<true, true>>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
   if (a_m_fast) return launch_auto<Strided<true, false>>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
   if (b_n_fast) return launch_auto<Strided<false, true>>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);

@@ -447,6 +447,29 @@ def test_full_size_conv_linearity_and_adjointness():
                    Fh.conv_act(a, w1, None, Fh.CONV1D, False) - Fh.conv_act(b2, w1, None, Fh.CONV1D, False)) < 2e-6
 
 
+def test_operand_tensor_of_4gib_is_refused_not_wrapped():
+    """The implicit-GEMM fetch addresses a tensor with 32-bit byte offsets: a (strided) operand that spans 4 GiB
+    or more must come back as an error from the C ABI, and the same layer just below the limit must run."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    B, cin, cout, hw = 5, 12, 24, 16
+    bs = 1 << 28  # floats between samples: B * bs * 4 bytes = 5 GiB (really allocated, so nothing can fault)
+    x = torch.empty(B * bs, device=DEV)
+    xv = torch.as_strided(x, (B, cin, hw, hw), (bs, hw * hw, hw, 1))
+    xv.normal_()
+    w = (0.1 * torch.randn(cout, cin, 4, 4)).to(DEV)
+    y = torch.empty(B, cout, hw // 2, hw // 2, device=DEV)
+    ws = torch.empty(max(int(lib.lshm_conv_workspace_floats(0, B, cin, cout, hw, hw)), 1), device=DEV)
+    args = lambda nb: (0, L.ptr(x), L.ptr(w), None, L.ptr(y), nb, cin, cout, hw, hw, bs, y[0].numel(), 0, L.ptr(ws),
+                       ws.numel(), L.stream())
+    assert lib.lshm_conv_fwd(*args(B)) == -3  # LSHM_ERR_UNSUPPORTED
+    assert b"4 GiB" in lib.lshm_last_error_string()
+    L.check(lib.lshm_conv_fwd(*args(4)), "conv_fwd")  # 3 * 2^28 + 3072 floats: fits
+    want = torch.nn.functional.conv2d(xv[:4].contiguous(), w, None, stride=2, padding=1)
+    assert rel_err(y[:4], want) < 5e-6
+    del x
+
+
 def test_conv_fwd_pair_matches_two_single_launches():
     """lshm_conv_fwd_pair (netT and netF share every launch) must be bitwise the two single-problem results."""
     from lshm_amd import _lib as L
