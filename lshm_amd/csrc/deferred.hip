@@ -58,9 +58,16 @@ __global__ __launch_bounds__(256) void chan_partials_multi_kernel(const ChanTabl
 // in group order.
 __global__ __launch_bounds__(256) void sum_jobs_multi_kernel(const SumTable tab) {
   __shared__ float red[256];
-  const int jx = find_job(tab, blockIdx.x);
+  // Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  With many lanes per
+  // output a workgroup uses 16 bytes of every 128-byte line it touches; its neighbours use the rest, so they
+  // must sit behind the same L2 or every XCD fetches the whole line again (measured: 3x the slab bytes from
+  // HBM).  Give XCD x the x-th contiguous eighth of the blocks.
+  const int per_xcd = (tab.blk0[tab.njobs] + 7) >> 3;
+  const int blk = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+  if (blk >= tab.blk0[tab.njobs]) return;
+  const int jx = find_job(tab, blk);
   const SumJob& J = tab.job[jx];
-  const int lb = blockIdx.x - tab.blk0[jx];
+  const int lb = blk - tab.blk0[jx];
   const int lpo = J.lpo;
   const int opb = 256 / lpo;
   const int sl = threadIdx.x / opb, ol = threadIdx.x - sl * opb;
@@ -146,7 +153,7 @@ int grad_jobs_finish(GradJobs& jobs, hipStream_t st) {
     }
     tab.blk0[tab.njobs] = blk;
     if (blk == 0) continue;
-    hipLaunchKernelGGL(sum_jobs_multi_kernel, dim3(blk), dim3(256), 0, st, tab);
+    hipLaunchKernelGGL(sum_jobs_multi_kernel, dim3((blk + 7) / 8 * 8), dim3(256), 0, st, tab);
     int rc = check_launch("sum_jobs_multi");
     if (rc) return rc;
   }

@@ -75,6 +75,7 @@ struct lshm_engine {
   size_t defer_floats;
   // optional side stream: netF beside netT (LSHM_FORK=1)
   hipStream_t wstream;
+  hipStream_t lstream = nullptr;  // latent-space terms (K-harmonic, similarity, augmentation, RICA): beside everything
   std::vector<hipEvent_t> events;
   mutable size_t next_event;
   hipEvent_t latent_event;  // set while the latent-space terms of the current forward are in flight
@@ -254,7 +255,8 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
 // gradients) on a job list that two launches finish at the end; every dz therefore has its own buffer.
 static int ae_backward(const lshm_engine* e, int G, const int* idx, const float* prm, float* grd,
                        const float* const* input, const float* const* dz_out, float* const* dinput, float* ws,
-                       int ln, hipStream_t st, hipStream_t wgrad_stream) {
+                       int ln, hipStream_t st, hipStream_t wgrad_stream,
+                       const std::function<int()>* before_dense = nullptr) {
   const lshm_step_config& c = e->cfg;
   const AEPlan& a0 = e->ae[idx[0]];
   const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
@@ -288,6 +290,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   };
   // The small layers' weight gradients are released in groups: every release costs a barrier packet
   // on both queues (a few microseconds each), which for 5-10 us kernels is most of their run time.
+  static const bool tail_inline = getenv("LSHM_WGRAD_TAIL_SIDE") == nullptr;
   static const int group = [] { const char* v = getenv("LSHM_WGRAD_GROUP"); return v ? atoi(v) : 3; }();
   std::vector<std::function<int()>> pending;
   auto release = [&](bool force) -> int {
@@ -331,6 +334,8 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr);
   };
+  // the latent-space gradient enters at fc3: whoever produced it beside the decoders is joined here, not earlier
+  if (before_dense && (rc = (*before_dense)())) return rc;
   // ---- fc3 (no activation on its output): dd0 is its pre-activation gradient
   for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{ws + A(g).cat3, ws + LA(g).o_dd0, grd + A(g).fc3w, grd + A(g).fc3b};
   if ((rc = wgrad(L + hd, 768, L + hd, 768))) return rc;
@@ -382,6 +387,14 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       dx[g] = (i == 0) ? dinput[g] : ws + LA(g).o_genc[i];
       wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).cw[i], grd + A(g).cb[i]};
       dg[g] = ConvDgradIO{dz[g], prm + A(g).cw[i], dx[g], i == 0 ? nullptr : xin};
+    }
+    if (i == 0 && side && !dinput[0] && tail_inline) {
+      // The first layer has no data gradient to compute: the data-gradient stream would idle from here to the
+      // join while the other one still holds two of the largest weight gradients.  This one runs on `st`
+      // (its dz was produced there: no event), and the closing sums wait for it.
+      if ((rc = conv_layer_wgrad(a0.enc[0], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
+      if ((rc = dz_ready())) return rc;
+      break;
     }
     pending.push_back([&, i, w0 = wg[0], w1 = wg[1]]() {
       return conv_layer_wgrad(a0.enc[i], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
@@ -514,14 +527,14 @@ static int start_latent_losses(lshm_engine* e, const float* prm, float* grd, flo
   e->latent_event = nullptr;
   if (!(e->side_ok && e->side_wgrad)) return latent_losses(e, prm, grd, ws, st);
   hipEvent_t ev = e->take_event();
-  if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->wstream, ev, 0) != hipSuccess) {
+  if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->lstream, ev, 0) != hipSuccess) {
     set_last_error("engine: stream fork failed");
     return LSHM_ERR_ARG;
   }
-  int rc = latent_losses(e, prm, grd, ws, e->wstream);
+  int rc = latent_losses(e, prm, grd, ws, e->lstream);
   if (rc) return rc;
   e->latent_event = e->take_event();
-  if (hipEventRecord(e->latent_event, e->wstream) != hipSuccess) {
+  if (hipEventRecord(e->latent_event, e->lstream) != hipSuccess) {
     set_last_error("engine: event record failed");
     return LSHM_ERR_ARG;
   }
@@ -535,13 +548,13 @@ static int start_similarity(lshm_engine* e, const float* prm, float* grd, float*
   const lshm_step_config& c = e->cfg;
   const double world = c.world > 0 ? c.world : 1;
   hipEvent_t ev = e->take_event();
-  if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->wstream, ev, 0) != hipSuccess) {
+  if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->lstream, ev, 0) != hipSuccess) {
     set_last_error("engine: stream fork failed");
     return LSHM_ERR_ARG;
   }
   double* scal = reinterpret_cast<double*>(ws + e->o_scal);
   float* dM = grd ? grd + e->Moff : ws + e->o_dMscratch;
-  int rc = cluster_sim_fwd_bwd(prm + e->Moff, c.K, e->D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 0, e->wstream);
+  int rc = cluster_sim_fwd_bwd(prm + e->Moff, c.K, e->D, 1e-9f, (float)(c.beta / world), scal + 8, dM, 0, e->lstream);
   if (rc) return rc;
   e->sim_started = true;
   return LSHM_OK;
@@ -572,16 +585,24 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
                                  grd ? ws + e->o_gx3c : nullptr, ws + e->lane[0].o_part, st, (float)(1.0 / world), e->bf))) return rc;
   const double inv_count = 1.0 / (world * (double)B * c.K * D);
   double* rica_part = scal + 16 + (B + c.bpb - 1) / c.bpb;  // [LOGCOSH3_BLOCKS][3]
-  if (e->latent_event) {  // the latent-space terms ran beside the decoders
-    if (hipStreamWaitEvent(st, e->latent_event, 0) != hipSuccess) {
-      set_last_error("engine: stream join failed");
-      return LSHM_ERR_ARG;
+  // The latent-space terms ran beside the decoders (their own stream).  Their scalars close the loss terms and
+  // their gradient enters the backward pass at the dense layers: the 1-D decoders' convolution gradients,
+  // which need neither, start before that chain has finished (it ends ~30 us after the decoders).
+  const std::function<int()> join_latent = [&]() -> int {
+    if (e->latent_event) {
+      if (hipStreamWaitEvent(st, e->latent_event, 0) != hipSuccess) {
+        set_last_error("engine: stream join failed");
+        return LSHM_ERR_ARG;
+      }
+      e->latent_event = nullptr;
     }
-    e->latent_event = nullptr;
-  }
-  hipLaunchKernelGGL(finalize_terms_kernel, dim3(1), dim3(64), 0, st, scal, terms, n_global, (double)c.rho,
-                     (double)c.alpha * inv_count, c.rica, rica_part, LOGCOSH3_BLOCKS * 3);
-  if ((rc = check_launch("finalize_terms"))) return rc;
+    hipLaunchKernelGGL(finalize_terms_kernel, dim3(1), dim3(64), 0, st, scal, terms, n_global, (double)c.rho,
+                       (double)c.alpha * inv_count, c.rica, rica_part, LOGCOSH3_BLOCKS * 3);
+    return check_launch("finalize_terms");
+  };
+  static const bool late_join = getenv("LSHM_LATENT_JOIN_EARLY") == nullptr;
+  const bool deferred = grd && late_join && (e->pair_mode || !e->side_ok);
+  if (!deferred && (rc = join_latent())) return rc;
   if (!grd)  // gradient-free closure (line search): every rank needs the global loss to take the same branch
     return e->comm ? comm_allreduce_segments(e->comm, nullptr, nullptr, 0, terms, 10, st) : LSHM_OK;
   // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
@@ -592,7 +613,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     const float* dz12[2] = {ws + e->o_gx2, ws + e->o_gx3c};
     float* di12[2] = {ws + e->o_gT, ws + e->o_gFc};
     if (e->pair_mode || !e->side_ok) {
-      if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, 0, st, wgs))) return rc;
+      if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, 0, st, wgs, deferred ? &join_latent : nullptr))) return rc;
     } else {
       hipEvent_t evf = e->take_event();
       if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(e->wstream, evf, 0) != hipSuccess) {
@@ -815,6 +836,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDevice(&e->device) != hipSuccess) e->device = -1;
     if (e->device >= 0 && (!e->pair_mode || e->side_wgrad)) {
       bool ok = hipStreamCreateWithFlags(&e->wstream, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipStreamCreateWithFlags(&e->lstream, hipStreamNonBlocking) == hipSuccess;
       e->events.resize(128);
       for (size_t i = 0; i < e->events.size() && ok; ++i)
         ok = ok && hipEventCreateWithFlags(&e->events[i], hipEventDisableTiming) == hipSuccess;
@@ -835,6 +857,7 @@ void lshm_engine_destroy(lshm_engine* e) {
     EngineCall scope(e);
     if (e->cstream) (void)hipStreamDestroy(e->cstream);
     (void)hipStreamDestroy(e->wstream);
+    if (e->lstream) (void)hipStreamDestroy(e->lstream);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   }
   delete e;
