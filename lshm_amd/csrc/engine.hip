@@ -290,7 +290,6 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   };
   // The small layers' weight gradients are released in groups: every release costs a barrier packet
   // on both queues (a few microseconds each), which for 5-10 us kernels is most of their run time.
-  static const bool tail_inline = getenv("LSHM_WGRAD_TAIL_SIDE") == nullptr;
   static const int group = [] { const char* v = getenv("LSHM_WGRAD_GROUP"); return v ? atoi(v) : 3; }();
   std::vector<std::function<int()>> pending;
   auto release = [&](bool force) -> int {
@@ -387,14 +386,6 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       dx[g] = (i == 0) ? dinput[g] : ws + LA(g).o_genc[i];
       wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).cw[i], grd + A(g).cb[i]};
       dg[g] = ConvDgradIO{dz[g], prm + A(g).cw[i], dx[g], i == 0 ? nullptr : xin};
-    }
-    if (i == 0 && side && !dinput[0] && tail_inline) {
-      // The first layer has no data gradient to compute: the data-gradient stream would idle from here to the
-      // join while the other one still holds two of the largest weight gradients.  This one runs on `st`
-      // (its dz was produced there: no event), and the closing sums wait for it.
-      if ((rc = conv_layer_wgrad(a0.enc[0], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs))) return rc;
-      if ((rc = dz_ready())) return rc;
-      break;
     }
     pending.push_back([&, i, w0 = wg[0], w1 = wg[1]]() {
       return conv_layer_wgrad(a0.enc[i], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
