@@ -418,51 +418,92 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
   const int tiles_x = Ws / TW, tiles_y = Hs / TH;
   const int Hb = 2 * Hs, Wb = 2 * Ws;
   const int ky = lm >> 2, kx = lm & 3;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Software pipeline over the tiles of this (persistent) workgroup: the next tile's global loads are issued
+  // into registers before the MFMA loop of the current one and written to LDS after it, so the HBM latency
+  // of a tile hides behind the matrix work of its predecessor.
+  constexpr int NHL = (CB * PH * 2 + 255) / 256;  // halo-column scalars per thread
+  f32x4 rs[NQS], rb[NQB];
+  float rh[NHL];
+  auto fetch = [&](int tile) {
     const int b = tile / (tiles_x * tiles_y);
     const int tr_ = tile - b * (tiles_x * tiles_y);
     const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
     const float* sb = small + (long)b * s_bs;
     const TB* bb = big + (long)b * big_bs;
-    __syncthreads();
     // small tile: [cs][TH*TW] as float4 rows of TW
 #pragma unroll
     for (int qq = 0; qq < NQS; ++qq) {
       const int i = t + 256 * qq;
+      rs[qq] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (i < CS * TH * (TW / 4)) {
         const int c4 = i % (TW / 4), rr = i / (TW / 4);
         const int row = rr % TH, cs = rr / TH;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + m0 + row) * Ws + n0 + 4 * c4);
-        float* d = &stile[cs * LDS_S + row * TW + 4 * c4];
-        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-        bs_small[qq] += (v[0] + v[1]) + (v[2] + v[3]);
+        rs[qq] = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + m0 + row) * Ws + n0 + 4 * c4);
       }
     }
     // big patch: rows 2*m0-1 .. 2*m0+2*TH, cols 2*n0-1 .. 2*n0+2*TW (zero outside the image)
 #pragma unroll
     for (int qq = 0; qq < NQB; ++qq) {
       const int i = t + 256 * qq;
+      rb[qq] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (i < CB * PH * (2 * TW / 4)) {
         const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
         const int prow = rr % PH, cb = rr / PH;
         const int iy = 2 * m0 - 1 + prow;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if ((unsigned)iy < (unsigned)Hb) v = Elem<TB>::ld4(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
+        if ((unsigned)iy < (unsigned)Hb) rb[qq] = Elem<TB>::ld4(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
+      }
+    }
+#pragma unroll
+    for (int qq = 0; qq < NHL; ++qq) {
+      const int i = t + 256 * qq;
+      rh[qq] = 0.f;
+      if (i < CB * PH * 2) {
+        const int side = i & 1, rr = i >> 1;
+        const int prow = rr % PH, cb = rr / PH;
+        const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
+        if ((unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb) rh[qq] = Elem<TB>::ld(bb + ((long)cb * Hb + iy) * Wb + ix);
+      }
+    }
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // the previous tile's MFMA loop has finished reading LDS
+#pragma unroll
+    for (int qq = 0; qq < NQS; ++qq) {
+      const int i = t + 256 * qq;
+      if (i < CS * TH * (TW / 4)) {
+        const int c4 = i % (TW / 4), rr = i / (TW / 4);
+        const int row = rr % TH, cs = rr / TH;
+        const f32x4 v = rs[qq];
+        float* d = &stile[cs * LDS_S + row * TW + 4 * c4];
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        bs_small[qq] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+#pragma unroll
+    for (int qq = 0; qq < NQB; ++qq) {
+      const int i = t + 256 * qq;
+      if (i < CB * PH * (2 * TW / 4)) {
+        const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+        const int prow = rr % PH, cb = rr / PH;
+        const f32x4 v = rb[qq];
         float* d = &patch[(cb * PH + prow) * PW + 1 + 4 * c4];
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         // halo rows belong to the neighbouring tiles: only the 2*TH interior rows count towards the bias sum
         if (prow >= 1 && prow <= 2 * TH) bs_big[qq] += (v[0] + v[1]) + (v[2] + v[3]);
       }
     }
-    for (int i = t; i < CB * PH * 2; i += 256) {
-      const int side = i & 1, rr = i >> 1;
-      const int prow = rr % PH, cb = rr / PH;
-      const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
-      float v = 0.f;
-      if ((unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb) v = Elem<TB>::ld(bb + ((long)cb * Hb + iy) * Wb + ix);
-      patch[(cb * PH + prow) * PW + (side ? PW - 1 : 0)] = v;
+#pragma unroll
+    for (int qq = 0; qq < NHL; ++qq) {
+      const int i = t + 256 * qq;
+      if (i < CB * PH * 2) {
+        const int side = i & 1, rr = i >> 1;
+        const int prow = rr % PH, cb = rr / PH;
+        patch[(cb * PH + prow) * PW + (side ? PW - 1 : 0)] = rh[qq];
+      }
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
     // K loop: groups of 4 consecutive positions, every 4th group per wave
 #pragma unroll 4
     for (int s = wave; s < TP / 4; s += 4) {
@@ -943,17 +984,43 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mid_kernel(const float* __re
   const int tiles_per = Ls / TP;
   // lane (lm, lk) of a B fragment: big channel 4 jt + (lm >> 2), tap lm & 3, position 4 s + lk
   const int bofs = (lm >> 2) * BP + (lm & 3) + 1 - pad;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // software pipeline over the tiles (see conv2d_wgrad_direct_kernel): loads of tile i+1 fly during the MFMAs of tile i
+  f32x4 rs[NQS], rb[NQB];
+  float rh = 0.f;
+  auto fetch = [&](int tile) {
     const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * TP;
     const float* sb = small + (long)b * s_bs + j0;
     const float* bb = big + (long)b * big_bs + 4L * j0;
+#pragma unroll
+    for (int q = 0; q < NQS; ++q) {
+      const int i = t + 256 * q;
+      rs[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CS * (TP / 4)) {
+        const int c4 = i % (TP / 4), cs = i / (TP / 4);
+        rs[q] = *reinterpret_cast<const f32x4*>(sb + (long)cs * Ls + 4 * c4);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+      const int i = t + 256 * q;
+      rb[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CB * TP) {
+        const int c4 = i % TP, cb = i / TP;
+        rb[q] = *reinterpret_cast<const f32x4*>(bb + (long)cb * Lb + 4 * c4);
+      }
+    }
+    // the element before the segment (pad = 1: tap 0 of the first position; zero at the row start)
+    rh = (t < CB && pad && j0 > 0) ? bb[(long)t * Lb - 1] : 0.f;
+  };
+  if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NQS; ++q) {
       const int i = t + 256 * q;
       if (i < CS * (TP / 4)) {
         const int c4 = i % (TP / 4), cs = i / (TP / 4);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + (long)cs * Ls + 4 * c4);
+        const f32x4 v = rs[q];
         float* d = &stile[cs * LDS_S + 4 * c4];
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         bs_small[q] += (v[0] + v[1]) + (v[2] + v[3]);
@@ -964,15 +1031,15 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mid_kernel(const float* __re
       const int i = t + 256 * q;
       if (i < CB * TP) {
         const int c4 = i % TP, cb = i / TP;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(bb + (long)cb * Lb + 4 * c4);
+        const f32x4 v = rb[q];
         float* d = &bimg[cb * BP + 1 + 4 * c4];
         d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         bs_big[q] += (v[0] + v[1]) + (v[2] + v[3]);
       }
     }
-    if (t < CB)  // the element before the segment (pad = 1: tap 0 of the first position; zero at the row start)
-      bimg[t * BP] = (pad && j0 > 0) ? bb[(long)t * Lb - 1] : 0.f;
+    if (t < CB) bimg[t * BP] = rh;
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 #pragma unroll 4
     for (int s = wave; s < TP / 4; s += 4) {
       const int p = 4 * s + lk;
