@@ -596,7 +596,7 @@ bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws) {
 }
 static int wgrad_bias_pad(int Cs, int Cb) { return ((Cs > Cb ? Cs : Cb) + 15) / 16 * 16; }
 size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) {
-  return (size_t)768 * (Cs * Cb * 16 + wgrad_bias_pad(Cs, Cb));
+  return (size_t)1024 * (Cs * Cb * 16 + wgrad_bias_pad(Cs, Cb));
 }
 
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
@@ -608,7 +608,7 @@ int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
   int grid;
   if (Cs == 8 && Cb == 4) {
     const int ntiles = (Ws / 64) * (Hs / 4) * B;
-    grid = ntiles < 768 ? ntiles : 768;
+    grid = ntiles < 1024 ? ntiles : 1024;  // 112 VGPRs, 37 KB of LDS: four workgroups per CU; 4096 tiles at B = 256 -> 4 full rounds
     if (big_bf16)
       hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<8, 4, 4, 64, bf16>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
                          big_bs, ws, Hs, Ws, ntiles, bias_from);
@@ -655,7 +655,7 @@ namespace lshm {
 // patch[ci][2oy+ky][2ox+kx] (bank = 2*lane + kx: conflict-free); weights live in registers.
 // ----------------------------------------------------------------------------------------------
 template <int CIN, int COUT, int TH, int TW>
-__global__ __launch_bounds__(256) void conv2d_direct_kernel(const float* __restrict__ x, long x_bs,
+__global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __restrict__ x, long x_bs,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ y, long y_bs,
@@ -916,7 +916,9 @@ int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, 
                          bias, y, y_bs, dact, Ho, Wo, act, ntiles);
   } else if (Cin == 8 && Cout == 12) {
     const int ntiles = (Wo / 32) * (Ho / 8) * B;
-    hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x,
+    // 38 KB of LDS and <= 128 VGPRs: four workgroups per CU, so the 1024 tiles of B = 256 are resident at once
+    // (768 workgroups left a second round with a third of the machine busy)
+    hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, x,
                        x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
   } else {
     set_last_error("conv2d_direct: unsupported shape");
