@@ -118,14 +118,29 @@ __global__ __launch_bounds__(256) void conv1d_stream_kernel(const Conv1dFwdParam
 // the next tile's loads in flight while the current tile's MFMAs run.  Each slot accumulates its own
 // positions; slots, wavefronts and workgroups are combined at the end in a fixed order.
 // ----------------------------------------------------------------------------------------------
-template <int CS, int CB, class TB = float>
-__global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* __restrict__ small0,
-                                                                  const float* __restrict__ small1, long s_bs,
-                                                                  const float* __restrict__ big0_,
-                                                                  const float* __restrict__ big1_, long big_bs,
-                                                                  float* __restrict__ partial0,
-                                                                  float* __restrict__ partial1, int Ls, int Lb,
-                                                                  int pad, int bias_from, int ntiles) {
+// DG (fused data gradient; transposed conv only, pad 0, CB == 4): the registers that feed the weight gradient of
+// a transposed layer -- its input `small` (an ELU output) and the gradient `big` of its output -- are everything
+// the layer's data gradient needs too:
+//   dsmall[cs, j] = ELU'(small[cs, j]) * sum_{cb,t} w[cs, cb, t] * big[cb, 4j + t]
+// A lane holds one big channel (cb = q) of its 4 positions: it forms the partial sums of all CS channels over its
+// taps on the vector ALU, the four lanes of a quad exchange them reduce-scatter fashion (two DPP quad
+// permutations: 24 moves for 32 values), and every lane ends with exactly the (channel, positions) float4s it
+// loaded from `small` -- multiplied by ELU' and stored where they came from in the gradient tensor.  One pass over
+// `big` and `small` instead of two (src/lofar_models.py:141-142 backward: 469 -> 268 MB for the pair at B = 256).
+struct DgradArgs { const float* w0; const float* w1; float* d0; float* d1; long d_bs; };
+template <int CTRL>
+__device__ __forceinline__ float quad_swap(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CS, int CB, class TB, bool DG>
+__device__ __forceinline__ void conv1d_wgrad_stream_body(const float* __restrict__ small0,
+                                                         const float* __restrict__ small1, long s_bs,
+                                                         const float* __restrict__ big0_,
+                                                         const float* __restrict__ big1_, long big_bs,
+                                                         float* __restrict__ partial0,
+                                                         float* __restrict__ partial1, int Ls, int Lb,
+                                                         int pad, int bias_from, int ntiles, DgradArgs dg) {
+  static_assert(!DG || (CB == 4 && CS == 8), "fused data gradient: 8 -> 4 channel layers");
   const float* small = blockIdx.y ? small1 : small0;
   const TB* big = reinterpret_cast<const TB*>(blockIdx.y ? big1_ : big0_);  // TB: element type of `big`
   float* partial = blockIdx.y ? partial1 : partial0;
@@ -147,6 +162,14 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* _
 
   const int tiles_per = Ls / 64;
   const int nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+  f32x4 wq[DG ? CS : 1];  // w[cs][cb = q][0..3]
+  float* dsmall = nullptr;
+  if constexpr (DG) {
+    const float* w = blockIdx.y ? dg.w1 : dg.w0;
+    dsmall = blockIdx.y ? dg.d1 : dg.d0;
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs) wq[cs] = *reinterpret_cast<const f32x4*>(w + ((long)cs * CB + q) * 4);
+  }
   f32x4 ra[GA], rb[GB][4];
   auto load_tile = [&](int tile) {
     const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * 64;
@@ -218,6 +241,39 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* _
 #pragma unroll
           for (int g = 0; g < GB; ++g)
             acc[a][g][tp] = __builtin_amdgcn_mfma_f32_4x4x1f32(ca[a][st], cb_[g][st][tp], acc[a][g][tp], 0, 0, 0);
+    if constexpr (DG) {
+      const bool odd = q & 1, hi = q & 2;
+      f32x4 r2[2];  // channel 4m + q, this lane's 4 positions
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        float pc[CS];
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+          const f32x4 gq = cb_[0][st];
+          pc[cs] = fmaf(wq[cs][3], gq[3], fmaf(wq[cs][2], gq[2], fmaf(wq[cs][1], gq[1], wq[cs][0] * gq[0])));
+        }
+        float r1[4];  // after the pair exchange: channel 2k + (q & 1), summed over two big channels
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float send = odd ? pc[2 * k] : pc[2 * k + 1], keep = odd ? pc[2 * k + 1] : pc[2 * k];
+          r1[k] = keep + quad_swap<0xB1>(send);  // quad_perm [1,0,3,2]
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          const float send = hi ? r1[2 * m] : r1[2 * m + 1], keep = hi ? r1[2 * m + 1] : r1[2 * m];
+          r2[m][st] = keep + quad_swap<0x4E>(send);  // quad_perm [2,3,0,1]
+        }
+      }
+      const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * 64;
+      float* db_ = dsmall + (long)b * dg.d_bs + j0 + 4 * slot;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x4 o;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) o[st] = r2[m][st] * elu_grad_from_out(ca[m][st]);
+        *reinterpret_cast<f32x4*>(db_ + (long)(4 * m + q) * Ls) = o;
+      }
+    }
   }
   // ---- 16 slots -> lane q of slot 0 (butterflies over lane bits 2..5), then the 4 waves through LDS
 #pragma unroll
@@ -247,6 +303,31 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* _
   }
 }
 
+template <int CS, int CB, class TB = float>
+__global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* __restrict__ small0,
+                                                                  const float* __restrict__ small1, long s_bs,
+                                                                  const float* __restrict__ big0,
+                                                                  const float* __restrict__ big1, long big_bs,
+                                                                  float* __restrict__ partial0,
+                                                                  float* __restrict__ partial1, int Ls, int Lb,
+                                                                  int pad, int bias_from, int ntiles) {
+  conv1d_wgrad_stream_body<CS, CB, TB, false>(small0, small1, s_bs, big0, big1, big_bs, partial0, partial1, Ls, Lb, pad,
+                                              bias_from, ntiles, DgradArgs{});
+}
+// weight + bias + data gradient of the 8 -> 4 channel transposed layer (204 registers: two wavefronts per SIMD; capped
+// at 168 for three it spills 10 and runs 81 us instead of 61)
+template <class TB>
+__global__ __launch_bounds__(256) void conv1d_bwd_fused_kernel(const float* __restrict__ small0,
+                                                                  const float* __restrict__ small1, long s_bs,
+                                                                  const float* __restrict__ big0,
+                                                                  const float* __restrict__ big1, long big_bs,
+                                                                  float* __restrict__ partial0,
+                                                                  float* __restrict__ partial1, int Ls, int Lb,
+                                                                  int bias_from, int ntiles, DgradArgs dg) {
+  conv1d_wgrad_stream_body<8, 4, TB, true>(small0, small1, s_bs, big0, big1, big_bs, partial0, partial1, Ls, Lb, 0,
+                                           bias_from, ntiles, dg);
+}
+
 bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
                                    const float* small, const float* big) {
   const bool shape = (Cs == 8 && Cb == 4) || (Cs == 12 && Cb == 8);
@@ -254,10 +335,24 @@ bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int 
          s_bs % 4 == 0 && big_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(small) & 15) == 0 &&
          (reinterpret_cast<uintptr_t>(big) & 15) == 0;
 }
+bool conv1d_bwd_fused_supported(int Cs, int Cb, int pad) { return Cs == 8 && Cb == 4 && pad == 0; }
 // one slab of Cs*Cb*4 + 16 floats per workgroup at ws (and ws2 for the second problem); returns the grid size
 int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
-                        int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16) {
+                        int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16,
+                        const FusedDgrad* fd) {
+  const float* w = fd ? fd->w : nullptr;
+  const float* w2 = fd ? fd->w2 : nullptr;
+  float* dsmall = fd ? fd->dx : nullptr;
+  float* dsmall2 = fd ? fd->dx2 : nullptr;
+  const long d_bs = fd ? fd->dx_bs : 0;
+  const DgradArgs dg{w, w2, dsmall, dsmall2, d_bs};
+  if (dsmall && !(Cs == 8 && Cb == 4 && pad == 0 && w && (!small2 || (w2 && dsmall2)) && d_bs % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(dsmall) & 15) == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0 &&
+                  (!small2 || ((reinterpret_cast<uintptr_t>(dsmall2) & 15) == 0 && (reinterpret_cast<uintptr_t>(w2) & 15) == 0)))) {
+    set_last_error("conv1d_wgrad_stream: fused data gradient needs the 8 -> 4 channel transposed layer, 16-byte aligned");
+    return LSHM_ERR_UNSUPPORTED;
+  }
   const int ntiles = (Ls / 64) * B;
   // measured at B=256: 4..8 tiles per wavefront and at most 512 workgroups per problem (more workgroups
   // only add closing butterflies and partial slabs)
@@ -268,7 +363,13 @@ int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, cons
   *grid_out = grid;
   const dim3 g(grid, small2 ? 2 : 1);
   if (big_bf16 && Cs != 8) { set_last_error("conv1d_wgrad_stream: bf16 storage only for the outermost layers"); return LSHM_ERR_UNSUPPORTED; }
-  if (Cs == 8 && big_bf16)
+  if (dsmall && big_bf16)
+    hipLaunchKernelGGL((conv1d_bwd_fused_kernel<bf16>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs, ws, ws2,
+                       Ls, Lb, bias_from, ntiles, dg);
+  else if (dsmall)
+    hipLaunchKernelGGL((conv1d_bwd_fused_kernel<float>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs, ws, ws2,
+                       Ls, Lb, bias_from, ntiles, dg);
+  else if (Cs == 8 && big_bf16)
     hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<8, 4, bf16>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs,
                        ws, ws2, Ls, Lb, pad, bias_from, ntiles);
   else if (Cs == 8)

@@ -1163,7 +1163,7 @@ size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)204
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
                         size_t wsf, int accumulate, hipStream_t st, const float* small2, const float* big2,
-                        float* dw2, float* db2, GradJobs* defer, int big_bf16) {
+                        float* dw2, float* db2, GradJobs* defer, int big_bf16, const FusedDgrad* fd) {
   const int G = small2 ? 2 : 1;
   if (wsf < G * conv1d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv1d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   if (!db) bias_from = 0;
@@ -1176,7 +1176,7 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
   const int slab = Cs * Cb * 4 + 16;
   int grid = 0;
   int rc = conv1d_wgrad_stream(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, bias_from,
-                               2048 / G, st, &grid, big_bf16);
+                               2048 / G, st, &grid, big_bf16, fd);
 
   if (rc) return rc;
   if (defer) {

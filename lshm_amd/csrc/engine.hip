@@ -313,6 +313,14 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       // previous activation is an ELU output (except fc3's output feeding tconv0)
       dg[g] = ConvDgradIO{dz[g], prm + A(g).tw[i], dx[g], i == 0 ? nullptr : xin};
     }
+    if (conv_layer_bwd_fusable(a0.dec[i], wg[0], dg[0]) && (G < 2 || conv_layer_bwd_fusable(a0.dec[i], wg[1], dg[1]))) {
+      // outermost 1-D decoder layer: weight, bias and data gradient from one pass over dz and the saved input, on
+      // the data-gradient stream (the closing sums still run on the other one, behind the next "dz ready" event)
+      if ((rc = conv_layer_wgrad(a0.dec[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs, &dg[0],
+                                 G > 1 ? &dg[1] : nullptr))) return rc;
+      for (int g = 0; g < G; ++g) dz[g] = dx[g];
+      continue;
+    }
     pending.push_back([&, i, w0 = wg[0], w1 = wg[1]]() {
       return conv_layer_wgrad(a0.dec[i], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
     });

@@ -136,9 +136,14 @@ bool conv1d_stream_supported(const Conv1dFwdParams& p);
 int conv1d_stream(const Conv1dFwdParams& p, const Conv1dFwdParams* p1, hipStream_t st);
 bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
                                    const float* small, const float* big);
+// fd (optional; the 8 -> 4 channel transposed layer only): the layer's data gradient in the same pass over `big`
+// and `small`: dx = ELU'(small) * conv(big, w), written to dx / dx2 (batch stride dx_bs)
+struct FusedDgrad { const float* w; const float* w2; float* dx; float* dx2; long dx_bs; };
+bool conv1d_bwd_fused_supported(int Cs, int Cb, int pad);
 int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
-                        int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16 = 0);
+                        int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16 = 0,
+                        const FusedDgrad* fd = nullptr);
 bool tconv1d_stream_supported(const Conv1dDgradParams& p);
 int tconv1d_stream(const Conv1dDgradParams& p, const Conv1dDgradParams* p1, hipStream_t st);
 // mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
@@ -187,7 +192,7 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
                         size_t wsf, int accumulate, hipStream_t st, const float* small2 = nullptr,
                         const float* big2 = nullptr, float* dw2 = nullptr, float* db2 = nullptr,
-                        GradJobs* defer = nullptr, int big_bf16 = 0);
+                        GradJobs* defer = nullptr, int big_bf16 = 0, const FusedDgrad* fd = nullptr);
 
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
@@ -217,8 +222,12 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
                      const ConvDgradIO* io2 = nullptr);
 // dw, db overwritten (accumulate=0) or accumulated (accumulate=1); ws required
 // defer: scratch is taken from the job list instead of ws and the closing sums are queued on it
+// fuse / fuse2 (only when conv_layer_bwd_fusable): the data gradient of the same layer is computed in the same pass
 int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_t ws_floats, int accumulate,
-                     hipStream_t st, const ConvWgradIO* io2 = nullptr, GradJobs* defer = nullptr);
+                     hipStream_t st, const ConvWgradIO* io2 = nullptr, GradJobs* defer = nullptr,
+                     const ConvDgradIO* fuse = nullptr, const ConvDgradIO* fuse2 = nullptr);
+// one kernel can produce the weight, bias AND data gradient of this layer (outermost 1-D transposed layer)
+bool conv_layer_bwd_fusable(const ConvLayer& L, const ConvWgradIO& io, const ConvDgradIO& dio);
 
 size_t conv_wgrad_defer_floats(const ConvLayer& L, int G);
 size_t linear_wgrad_defer_floats(int B, int K, int N, int G);

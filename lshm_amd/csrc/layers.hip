@@ -226,8 +226,17 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
   }
 }
 
+bool conv_layer_bwd_fusable(const ConvLayer& L, const ConvWgradIO& io, const ConvDgradIO& dio) {
+  static const bool on = getenv("LSHM_BWD_FUSED_OFF") == nullptr;
+  if (!on || L.kind != 3 || !transposed(L)) return false;
+  // the ELU' reference of the data gradient must be the layer's own input (it is, for every layer behind an ELU)
+  return conv1d_bwd_fused_supported(L.Cin, L.Cout, 0) && dio.dact_in == io.x && dio.dz == io.dz && L.in_bs % 4 == 0 &&
+         conv1d_wgrad_direct_supported(L.Cin, L.Cout, L.Win);
+}
+
 int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_t ws_floats, int accumulate,
-                     hipStream_t st, const ConvWgradIO* io2, GradJobs* defer) {
+                     hipStream_t st, const ConvWgradIO* io2, GradJobs* defer, const ConvDgradIO* fuse,
+                     const ConvDgradIO* fuse2) {
   const int G = io2 ? 2 : 1;
   if (defer) {  // private scratch that survives until grad_jobs_finish
     ws_floats = conv_workspace_floats(L) * G;
@@ -255,6 +264,7 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
   const int big_bf16 = tr ? L.out_bf16 : L.in_bf16;
   if ((tr ? L.in_bf16 : L.out_bf16)) return bf16_unsupported();  // `small` side: never stored as bf16
   if (L.kind < 2) {
+    if (fuse) { set_last_error("conv wgrad: fused data gradient not available for this layer"); return LSHM_ERR_UNSUPPORTED; }
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
     if (!io2 && conv2d_wgrad_direct_supported(Cs, Cb, Hs, Ws) &&
         gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
@@ -281,12 +291,16 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
         conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(io), big_of(io)) &&
         (!io2 || conv1d_wgrad_stream_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(*io2),
                                                big_of(*io2)));
-    if (stream_ok)
+    if (stream_ok) {
       // weight and bias gradient in one pass (dz is `big` for the transposed conv, `small` otherwise)
+      FusedDgrad fd{};
+      if (fuse) fd = FusedDgrad{fuse->w, fuse2 ? fuse2->w : nullptr, fuse->dx, fuse2 ? fuse2->dx : nullptr, L.in_bs};
       return conv1d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.Cout, L.B, Cs,
                                  Cb, Ls, Lb, tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st,
                                  io2 ? small_of(*io2) : nullptr, io2 ? big_of(*io2) : nullptr,
-                                 io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr, defer, big_bf16);
+                                 io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr, defer, big_bf16, fuse ? &fd : nullptr);
+    }
+    if (fuse) { set_last_error("conv wgrad: fused data gradient not available for this layer"); return LSHM_ERR_UNSUPPORTED; }
     if (big_bf16) return bf16_unsupported();
     static const bool use_mid = getenv("LSHM_WGRAD_MID_OFF") == nullptr;
     if (use_mid && gemm_wsf >= G * conv1d_wgrad_mid_workspace_floats(Cs, Cb) &&
