@@ -227,8 +227,7 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
 }
 
 bool conv_layer_bwd_fusable(const ConvLayer& L, const ConvWgradIO& io, const ConvDgradIO& dio) {
-  static const bool on = getenv("LSHM_BWD_FUSED_OFF") == nullptr;
-  if (!on || L.kind != 3 || !transposed(L)) return false;
+  if (getenv("LSHM_BWD_FUSED_OFF") || L.kind != 3 || !transposed(L)) return false;
   // the ELU' reference of the data gradient must be the layer's own input (it is, for every layer behind an ELU)
   return conv1d_bwd_fused_supported(L.Cin, L.Cout, 0) && dio.dact_in == io.x && dio.dz == io.dz && L.in_bs % 4 == 0 &&
          conv1d_wgrad_direct_supported(L.Cin, L.Cout, L.Win);

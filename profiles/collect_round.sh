@@ -11,6 +11,9 @@ RAW=gpurun_out/$R/raw
 mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 STEP="--steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-reuse-mode --no-lbfgs --no-rica"
+# PART=a: items 1-4, PART=b: items 5-7 (a gpurun call is limited to 20 minutes); default both
+PART=${PART:-ab}
+if [[ $PART == *a* ]]; then
 # 1. the default bench line under the profiler: per-kernel statistics of the whole command
 rocprofv3 --kernel-trace --stats -d $RAW/default --output-format csv -- python3 bench.py > $OUT/bench_default_output.json 2> $RAW/default.err
 cp $(ls $RAW/default/*/*kernel_stats.csv | head -1) $OUT/bench_default_kernel_stats.csv
@@ -30,6 +33,8 @@ done
 python3 profiles/pmc_traffic.py $OUT/hbm_traffic.json step:$RAW/pmc_step_FETCH_SIZE:$RAW/pmc_step_WRITE_SIZE \
   khm_N1048576_K10:$RAW/pmc_khm10_FETCH_SIZE:$RAW/pmc_khm10_WRITE_SIZE khm_N1048576_K64:$RAW/pmc_khm64_FETCH_SIZE:$RAW/pmc_khm64_WRITE_SIZE
 python3 profiles/pmc_traffic.py $OUT/bf16_hbm_traffic.json step:$RAW/pmc_bf16_FETCH_SIZE:$RAW/pmc_bf16_WRITE_SIZE
+fi
+if [[ $PART == *b* ]]; then
 # 5. matrix-pipe utilisation per kernel of the step
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_BUSY_CYCLES --kernel-trace -d $RAW/pmc_mfma --output-format csv -- python3 bench.py $STEP > /dev/null 2> $RAW/pmc_mfma.err
 rocprofv3 --kernel-trace --stats -d $RAW/stepstats --output-format csv -- python3 bench.py $STEP > /dev/null 2> $RAW/stepstats.err
@@ -44,5 +49,6 @@ python3 profiles/step_trace.py $RAW/bf16step > $OUT/bf16_step_timeline.txt
 python3 bench.py --K 64 --no-cpu-baseline --no-rica > $OUT/k64_bench_output.json 2> $RAW/k64.err
 rocprofv3 --kernel-trace -d $RAW/k64step --output-format csv -- python3 bench.py $STEP --K 64 > /dev/null 2> $RAW/k64step.err
 python3 profiles/step_trace.py $RAW/k64step > $OUT/step_timeline_k64.txt
+fi
 rm -rf $RAW
 ls -la $OUT

@@ -8,8 +8,11 @@ across them.  The label `step` (bench.py --no-roofline ...) also yields the traf
 all bytes of the run divided by its number of iterations (= adam_kernel launches).
 
 Usage: pmc_traffic.py OUT.json LABEL:FETCH_DIR:WRITE_DIR [LABEL:FETCH_DIR:WRITE_DIR ...]"""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from names import short  # noqa: E402
 
 
 def collect(d, counter):

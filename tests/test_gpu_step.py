@@ -1,5 +1,7 @@
 """GPU parity of the fused step engine (one ADMM iteration) vs the CPU oracle and vs the
 golden trajectory recorded from the reference modules + torch.optim.Adam."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -300,6 +302,39 @@ def test_full_size_two_stream_schedule_equals_single_stream():
         del tr
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16s"], ids=["fp32", "bf16-storage"])
+def test_fused_backward_of_outer_1d_layer_matches_separate_kernels(precision):
+    """conv1d_bwd_fused_kernel (weight + bias + data gradient of netT / netF's last decoder layer from one pass,
+    src/lofar_models.py:141-142 backward) against the two kernels it replaces (LSHM_BWD_FUSED_OFF=1), full size:
+    the weight and bias gradients of that layer come from the same MFMA sequence (bitwise equal); everything
+    upstream of its data gradient agrees to fp32 rounding (another summation order over the 16 taps x channels)."""
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn(256, 4, 128, 128, generator=g)
+    uv = 1000.0 * torch.randn(256, 2, generator=g)
+    tr = _full_trainer(precision=precision)
+    tr.new_minibatch(x.to(DEV), uv.to(DEV))
+    for k in range(3):
+        tr.y[k].normal_(0.0, 0.01)
+    grads = []
+    for off in (False, True):
+        if off:
+            os.environ["LSHM_BWD_FUSED_OFF"] = "1"
+        try:
+            tr.closure_only()
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("LSHM_BWD_FUSED_OFF", None)
+        grads.append(tr.grads.clone())
+    for net in ("netT", "netF"):
+        for leaf in ("tconv5.weight", "tconv5.bias"):
+            name = f"{net}.{leaf}"
+            assert torch.equal(tr.view(name, grads[0]), tr.view(name, grads[1])), name
+    assert not torch.equal(grads[0], grads[1])  # the switch did select another kernel
+    assert rel_err(grads[0], grads[1]) < 2e-6
+    for name in tr.layout:
+        assert rel_err(tr.view(name, grads[0]), tr.view(name, grads[1])) < 2e-5, name
 
 
 @pytest.mark.parametrize("K,precision,tol", [(10, "fp32", 5e-5), (64, "fp32", 5e-5), (10, "bf16", 5e-5), (10, "bf16s", 5e-5)],
