@@ -236,6 +236,21 @@ int lshm_dot_flat(const float* a, const float* b, long n, double* out, float* wo
                   lshm_stream_t stream);
 /* out[0] = sum |a_i| (double); workspace >= 512 floats          src/lbfgsnew.py:531 (flat_grad.abs().sum()) */
 int lshm_asum_flat(const float* a, long n, double* out, float* workspace, lshm_stream_t stream);
+/* out[i] = a[i].b[i] (double), i < count <= 16, in one launch pair (one host read instead of `count`): the curvature
+ * products ys, ss, yy of src/lbfgsnew.py:604-624.  a / b: HOST arrays of device pointers.
+ * workspace >= lshm_multi_dot_workspace_doubles(count) doubles. */
+size_t lshm_multi_dot_workspace_doubles(int count);
+int lshm_multi_dot_flat(const float* const* a, const float* const* b, int count, long n, double* out,
+                        double* workspace, size_t workspace_doubles, lshm_stream_t stream);
+/* L-BFGS search direction (two-loop recursion, src/lbfgsnew.py:632-651) entirely on the device:
+ *   q = -grad; for i = m-1..0: al_i = <s_i,q>/<y_i,s_i>, q -= al_i y_i;  q *= h_diag;
+ *   for i = 0..m-1: be_i = <y_i,q>/<y_i,s_i>, q += (al_i - be_i) s_i;   d = q
+ * y = old_dirs, s = old_stps (HOST arrays of m <= 16 device pointers, oldest first), d must not alias them.
+ * 2m + 2 launches and no host round trip (the host loop needs 3m synchronisations per direction); every inner
+ * product is a fixed-order two-stage sum in double: results are reproducible bit for bit. */
+size_t lshm_lbfgs_direction_workspace_doubles(int m);
+int lshm_lbfgs_direction(const float* const* y, const float* const* s, int m, const float* grad, double h_diag,
+                         float* d, long n, double* workspace, size_t workspace_doubles, lshm_stream_t stream);
 
 /* ---- FFT feature step: fftn(dims 2,3, ortho) -> fftshift -> cat(Re,Im) -> clamp
  *      Demo.ipynb:169-175, src/lofar_tools.py:24-30.  x (B,C,128,128) -> out (B,2C,128,128) */

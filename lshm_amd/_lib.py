@@ -95,6 +95,11 @@ _SIGNATURES = {
     "lshm_scale_flat": (c_int, [c_void_p, c_float, c_long, c_void_p]),
     "lshm_dot_flat": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
     "lshm_asum_flat": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p]),
+    "lshm_multi_dot_workspace_doubles": (c_size_t, [c_int]),
+    "lshm_multi_dot_flat": (c_int, [c_void_p, c_void_p, c_int, c_long, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lshm_lbfgs_direction_workspace_doubles": (c_size_t, [c_int]),
+    "lshm_lbfgs_direction": (c_int, [c_void_p, c_void_p, c_int, c_void_p, C.c_double, c_void_p, c_long, c_void_p,
+                                     c_size_t, c_void_p]),
     "lshm_patches_workspace_floats": (c_size_t, []),
     "lshm_patches_from_vis": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                       c_void_p, c_void_p, c_void_p]),

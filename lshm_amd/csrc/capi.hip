@@ -238,6 +238,24 @@ int lshm_asum_flat(const float* a, long n, double* out, float* ws, lshm_stream_t
   return asum_flat(a, n, out, ws, ST(s));
 }
 
+size_t lshm_multi_dot_workspace_doubles(int count) { return count > 0 ? multi_dot_workspace_doubles(count) : 0; }
+int lshm_multi_dot_flat(const float* const* a, const float* const* b, int count, long n, double* out, double* ws,
+                        size_t wsd, lshm_stream_t s) {
+  REQUIRE(a && b && out && ws && n >= 0 && count >= 1 && count <= kMaxDots, "multi_dot: bad argument");
+  for (int i = 0; i < count; ++i) REQUIRE(a[i] && b[i], "multi_dot: null vector");
+  if (wsd < multi_dot_workspace_doubles(count)) { set_last_error("multi_dot: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  return multi_dot_flat(a, b, count, n, out, ws, ST(s));
+}
+size_t lshm_lbfgs_direction_workspace_doubles(int m) { return m >= 0 ? lbfgs_direction_workspace_doubles(m) : 0; }
+int lshm_lbfgs_direction(const float* const* y, const float* const* s_, int m, const float* grad, double h_diag, float* d,
+                         long n, double* ws, size_t wsd, lshm_stream_t s) {
+  REQUIRE(grad && d && ws && n >= 0 && m >= 0 && m <= kMaxDots && (m == 0 || (y && s_)), "lbfgs_direction: bad argument");
+  for (int i = 0; i < m; ++i) REQUIRE(y[i] && s_[i] && y[i] != d && s_[i] != d, "lbfgs_direction: null or aliased vector");
+  if (wsd < lbfgs_direction_workspace_doubles(m)) { set_last_error("lbfgs_direction: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  if (n == 0) return LSHM_OK;
+  return lbfgs_direction(y, s_, m, grad, h_diag, d, n, ws, ST(s));
+}
+
 size_t lshm_patches_workspace_floats(void) { return patches_workspace_floats(); }
 int lshm_patches_from_vis(const int8_t* vis, const float* scale, int nb, int ntime, int nfreq, int patch,
                           float clampv, int normalize, float* y, double* mean_std, float* ws, lshm_stream_t s) {

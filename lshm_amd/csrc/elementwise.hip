@@ -573,6 +573,185 @@ int dot_flat(const float* a, const float* b, long n, double* out, float* ws, hip
 }
 
 // --------------------------------------------------------------------------
+// Several inner products in one launch pair: out[i] = <a_i, b_i>, i < count <= kMaxDots (grid.y = i).
+// --------------------------------------------------------------------------
+struct DotList { const float* a[kMaxDots]; const float* b[kMaxDots]; };
+__device__ __forceinline__ double dot_chunk(const float* __restrict__ a, const float* __restrict__ b, long n, int vec) {
+  double acc = 0.0;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  if (vec) {
+    const long n4 = n >> 2;
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+    for (long i = gid; i < n4; i += stride) {
+      const f32x4 x = a4[i], y = b4[i];
+      acc += ((double)x[0] * (double)y[0] + (double)x[1] * (double)y[1]) +
+             ((double)x[2] * (double)y[2] + (double)x[3] * (double)y[3]);
+    }
+    if (gid < (n & 3)) acc += (double)a[4 * n4 + gid] * (double)b[4 * n4 + gid];
+  } else {
+    for (long i = gid; i < n; i += stride) acc += (double)a[i] * (double)b[i];
+  }
+  return acc;
+}
+__global__ __launch_bounds__(256) void multi_dot_stage1(const DotList L, long n, double* __restrict__ part, int vec) {
+  __shared__ double red[16];
+  const int j = blockIdx.y;
+  const double tot = block_sum<double>(dot_chunk(L.a[j], L.b[j], n, vec), red);
+  if (threadIdx.x == 0) part[(long)j * DOT_BLOCKS + blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(256) void multi_dot_stage2(const double* __restrict__ part, double* __restrict__ out) {
+  __shared__ double red[16];
+  const double tot = block_sum<double>(part[(long)blockIdx.x * DOT_BLOCKS + threadIdx.x], red);
+  if (threadIdx.x == 0) out[blockIdx.x] = tot;
+}
+static int all_aligned16(const float* const* p, int n) {
+  uintptr_t m = 0;
+  for (int i = 0; i < n; ++i) m |= reinterpret_cast<uintptr_t>(p[i]);
+  return (m & 15) == 0;
+}
+size_t multi_dot_workspace_doubles(int count) { return (size_t)count * DOT_BLOCKS; }
+int multi_dot_flat(const float* const* a, const float* const* b, int count, long n, double* out, double* ws,
+                   hipStream_t st) {
+  DotList L;
+  for (int i = 0; i < kMaxDots; ++i) { L.a[i] = a[i < count ? i : 0]; L.b[i] = b[i < count ? i : 0]; }
+  const int vec = all_aligned16(a, count) && all_aligned16(b, count);
+  hipLaunchKernelGGL(multi_dot_stage1, dim3(DOT_BLOCKS, count), dim3(256), 0, st, L, n, ws, vec);
+  int rc = check_launch("multi_dot1");
+  if (rc) return rc;
+  hipLaunchKernelGGL(multi_dot_stage2, dim3(count), dim3(DOT_BLOCKS), 0, st, ws, out);
+  return check_launch("multi_dot2");
+}
+
+// --------------------------------------------------------------------------
+// L-BFGS two-loop recursion (src/lbfgsnew.py:632-651) without host round trips.  The host version needs the value
+// of every inner product before it can enqueue the next update: 3 m synchronisations per search direction.  Here
+// each link of the chain is ONE launch: every workgroup first adds up the DOT_BLOCKS stage-1 partials the previous
+// link left behind (all workgroups in the same order: the same coefficient, bitwise), updates its share of the
+// vector and leaves the stage-1 partial of the NEXT inner product over the updated share.
+//   first loop  (i = m-1 .. 0):  al_i = <s_i, q> / <y_i, s_i>;  q -= al_i y_i          [after i = 0: q *= H_diag]
+//   second loop (i = 0 .. m-1):  be_i = <y_i, r> / <y_i, s_i>;  r += (al_i - be_i) s_i
+// Coefficients are formed in double and rounded to float for the update, as the host version's axpy does.
+// --------------------------------------------------------------------------
+struct LbfgsLink {
+  float* q;                 // updated in place
+  const float* upd;         // q += coef * upd
+  const float* nxt;         // stage-1 partial of <nxt, q> is left in part_out (null: none)
+  const double* prev_part;  // partials of the inner product that defines coef
+  const double* ys_part;    // partials of <y_i, s_i>
+  double* al;               // al[i]: written by the first loop (workgroup 0), read by the second
+  double* part_out;
+  float post_scale;         // q *= post_scale after the update (H_diag behind the first loop, else 1)
+  int second;               // 0: coef = -al_i;  1: coef = al_i - be_i
+};
+__global__ __launch_bounds__(256) void lbfgs_link_kernel(const LbfgsLink k, long n, int vec) {
+  __shared__ double red[16];
+  __shared__ double sc[2];
+  const double dot = block_sum<double>(k.prev_part[threadIdx.x], red);
+  if (threadIdx.x == 0) sc[0] = dot;
+  const double ys = block_sum<double>(k.ys_part[threadIdx.x], red);
+  if (threadIdx.x == 0) sc[1] = ys;
+  __syncthreads();
+  const double ratio = sc[0] * (1.0 / sc[1]);  // dot * ro_i, ro_i = 1 / <y_i, s_i>
+  double coef;
+  if (k.second) {
+    coef = *k.al - ratio;
+  } else {
+    coef = -ratio;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *k.al = ratio;
+  }
+  const float c = (float)coef, ps = k.post_scale;
+  double acc = 0.0;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+  if (vec) {
+    const long n4 = n >> 2;
+    f32x4* q4 = reinterpret_cast<f32x4*>(k.q);
+    const f32x4* u4 = reinterpret_cast<const f32x4*>(k.upd);
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(k.nxt);
+    for (long i = gid; i < n4; i += stride) {
+      f32x4 v = q4[i];
+      const f32x4 u = u4[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (v[e] + c * u[e]) * ps;
+      q4[i] = v;
+      if (x4) {
+        const f32x4 x = x4[i];
+        acc += ((double)x[0] * (double)v[0] + (double)x[1] * (double)v[1]) +
+               ((double)x[2] * (double)v[2] + (double)x[3] * (double)v[3]);
+      }
+    }
+    if (gid < (n & 3)) {
+      const long i = 4 * n4 + gid;
+      const float v = (k.q[i] + c * k.upd[i]) * ps;
+      k.q[i] = v;
+      if (k.nxt) acc += (double)k.nxt[i] * (double)v;
+    }
+  } else {
+    for (long i = gid; i < n; i += stride) {
+      const float v = (k.q[i] + c * k.upd[i]) * ps;
+      k.q[i] = v;
+      if (k.nxt) acc += (double)k.nxt[i] * (double)v;
+    }
+  }
+  if (k.nxt) {
+    const double tot = block_sum<double>(acc, red);
+    if (threadIdx.x == 0) k.part_out[blockIdx.x] = tot;
+  }
+}
+// q = -g (times post_scale) and the stage-1 partial of <nxt, q>
+__global__ __launch_bounds__(256) void lbfgs_start_kernel(const float* __restrict__ g, float* __restrict__ q,
+                                                          const float* __restrict__ nxt, double* __restrict__ part_out,
+                                                          float post_scale, long n) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = -g[i] * post_scale;
+    q[i] = v;
+    if (nxt) acc += (double)nxt[i] * (double)v;
+  }
+  if (nxt) {
+    const double tot = block_sum<double>(acc, red);
+    if (threadIdx.x == 0) part_out[blockIdx.x] = tot;
+  }
+}
+size_t lbfgs_direction_workspace_doubles(int m) { return (size_t)(m + 2) * DOT_BLOCKS + (size_t)m; }
+int lbfgs_direction(const float* const* y, const float* const* s, int m, const float* g, double h_diag, float* d, long n,
+                    double* ws, hipStream_t st) {
+  if (m == 0) {
+    hipLaunchKernelGGL(lbfgs_start_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, g, d, (const float*)nullptr,
+                       (double*)nullptr, (float)h_diag, n);
+    return check_launch("lbfgs_start");
+  }
+  double* ys_part = ws;                              // [m][DOT_BLOCKS]
+  double* ping = ws + (size_t)m * DOT_BLOCKS;        // [2][DOT_BLOCKS]
+  double* al = ping + 2 * DOT_BLOCKS;                // [m]
+  DotList L;
+  for (int i = 0; i < kMaxDots; ++i) { L.a[i] = y[i < m ? i : 0]; L.b[i] = s[i < m ? i : 0]; }
+  const int vec = all_aligned16(y, m) && all_aligned16(s, m) && (reinterpret_cast<uintptr_t>(d) & 15) == 0;
+  hipLaunchKernelGGL(multi_dot_stage1, dim3(DOT_BLOCKS, m), dim3(256), 0, st, L, n, ys_part, vec);
+  int rc = check_launch("lbfgs_ys");
+  if (rc) return rc;
+  hipLaunchKernelGGL(lbfgs_start_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, g, d, s[m - 1], ping, 1.f, n);
+  if ((rc = check_launch("lbfgs_start"))) return rc;
+  int cur = 0;
+  for (int i = m - 1; i >= 0; --i) {  // q -= al_i y_i; next: <s_{i-1}, q>, or <y_0, H q> behind the last link
+    LbfgsLink k{d, y[i], i > 0 ? s[i - 1] : y[0], ping + cur * DOT_BLOCKS, ys_part + (size_t)i * DOT_BLOCKS, al + i,
+                ping + (cur ^ 1) * DOT_BLOCKS, i == 0 ? (float)h_diag : 1.f, 0};
+    hipLaunchKernelGGL(lbfgs_link_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, k, n, vec);
+    if ((rc = check_launch("lbfgs_link"))) return rc;
+    cur ^= 1;
+  }
+  for (int i = 0; i < m; ++i) {       // r += (al_i - be_i) s_i; next: <y_{i+1}, r>
+    LbfgsLink k{d, s[i], i + 1 < m ? y[i + 1] : nullptr, ping + cur * DOT_BLOCKS, ys_part + (size_t)i * DOT_BLOCKS,
+                al + i, ping + (cur ^ 1) * DOT_BLOCKS, 1.f, 1};
+    hipLaunchKernelGGL(lbfgs_link_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, k, n, vec);
+    if ((rc = check_launch("lbfgs_link"))) return rc;
+    cur ^= 1;
+  }
+  return LSHM_OK;
+}
+
+// --------------------------------------------------------------------------
 // RICA penalty: loss = scale * sum log cosh(z);  dz (+)= scale * tanh(z)
 // (src/kharmonic_lofar.py:169-171).  One workgroup: the latents are tiny.
 // --------------------------------------------------------------------------

@@ -308,6 +308,12 @@ int adam_step_flat(float* p, const float* g, float* m, float* v, long n, float l
 int axpy_flat(float* y, const float* x, float alpha, long n, hipStream_t st);
 int dot_flat(const float* a, const float* b, long n, double* out, float* ws, hipStream_t st);
 int scale_flat(float* x, float alpha, long n, hipStream_t st);
+constexpr int kMaxDots = 16;  // pairs per multi_dot_flat launch; stored (y, s) pairs per lbfgs_direction call
+size_t multi_dot_workspace_doubles(int count);
+int multi_dot_flat(const float* const* a, const float* const* b, int count, long n, double* out, double* ws, hipStream_t st);
+size_t lbfgs_direction_workspace_doubles(int m);
+int lbfgs_direction(const float* const* y, const float* const* s, int m, const float* g, double h_diag, float* d, long n,
+                    double* ws, hipStream_t st);
 int asum_flat(const float* a, long n, double* out, float* ws, hipStream_t st);
 int logcosh_mean_fwd_bwd(const float* z, long ldz, int rows, int cols, float scale, double* loss,
                          float* dz, long lddz, int accumulate, hipStream_t st);

@@ -41,6 +41,29 @@ class _TorchVec:
     def scale(self, x, alpha):
         x.mul_(alpha)
 
+    def dots(self, pairs):
+        return [self.dot(a, b) for a, b in pairs]
+
+    def direction(self, old_dirs, old_stps, flat_grad, h_diag):
+        return _two_loop(self, old_dirs, old_stps, flat_grad, h_diag)
+
+
+def _two_loop(vec, old_dirs, old_stps, flat_grad, h_diag):
+    """The two-loop recursion of src/lbfgsnew.py:632-651 on top of a vector backend's dot / axpy / scale."""
+    num_old = len(old_dirs)
+    ro = [1.0 / vec.dot(old_dirs[i], old_stps[i]) for i in range(num_old)]
+    al = [0.0] * num_old
+    q = flat_grad.neg()
+    for i in range(num_old - 1, -1, -1):
+        al[i] = vec.dot(old_stps[i], q) * ro[i]
+        vec.axpy(q, -al[i], old_dirs[i])
+    vec.scale(q, float(h_diag))
+    d = q
+    for i in range(num_old):
+        be_i = vec.dot(old_dirs[i], d) * ro[i]
+        vec.axpy(d, al[i] - be_i, old_stps[i])
+    return d
+
 
 class _HipVec:
     """Vector algebra through the C ABI (deterministic two-stage reductions on the device)."""
@@ -51,6 +74,8 @@ class _HipVec:
         self.lib = L.load()
         self.ws = torch.empty(1024, device=device, dtype=torch.float32)
         self.out = torch.empty(1, device=device, dtype=torch.float64)
+        self.outs = torch.empty(self.MAX_PAIRS, device=device, dtype=torch.float64)
+        self.dws = torch.empty(0, device=device, dtype=torch.float64)
 
     def dot(self, a, b) -> float:
         L = self.L
@@ -73,6 +98,44 @@ class _HipVec:
         L = self.L
         with L.on_device(x.device):
             L.check(self.lib.lshm_scale_flat(L.ptr(x), float(alpha), x.numel(), L.stream(x.device)))
+
+    MAX_PAIRS = 16  # kMaxDots of the C ABI
+
+    def _ptr_array(self, vs):
+        import ctypes as C
+        return (C.c_void_p * len(vs))(*[v.data_ptr() for v in vs])
+
+    def dots(self, pairs) -> List[float]:
+        """[a.b for a, b in pairs] with ONE host read (lshm_multi_dot_flat)."""
+        if not 1 <= len(pairs) <= self.MAX_PAIRS:
+            return [self.dot(a, b) for a, b in pairs]
+        L = self.L
+        a0 = pairs[0][0]
+        need = int(self.lib.lshm_multi_dot_workspace_doubles(len(pairs)))
+        if self.dws.numel() < need:
+            self.dws = torch.empty(need, device=a0.device, dtype=torch.float64)
+        with L.on_device(a0.device):
+            L.check(self.lib.lshm_multi_dot_flat(self._ptr_array([a for a, _ in pairs]), self._ptr_array([b for _, b in pairs]),
+                                                 len(pairs), a0.numel(), L.ptr(self.outs), L.ptr(self.dws),
+                                                 self.dws.numel(), L.stream(a0.device)), "multi_dot")
+        return self.outs[:len(pairs)].tolist()
+
+    def direction(self, old_dirs, old_stps, flat_grad, h_diag):
+        """Two-loop recursion on the device (lshm_lbfgs_direction): no host round trip per inner product."""
+        m = len(old_dirs)
+        if m > self.MAX_PAIRS:
+            return _two_loop(self, old_dirs, old_stps, flat_grad, h_diag)
+        L = self.L
+        d = torch.empty_like(flat_grad)
+        need = int(self.lib.lshm_lbfgs_direction_workspace_doubles(m))
+        if self.dws.numel() < need:
+            self.dws = torch.empty(need, device=flat_grad.device, dtype=torch.float64)
+        with L.on_device(flat_grad.device):
+            L.check(self.lib.lshm_lbfgs_direction(self._ptr_array(old_dirs) if m else None,
+                                                  self._ptr_array(old_stps) if m else None, m, L.ptr(flat_grad),
+                                                  float(h_diag), L.ptr(d), flat_grad.numel(), L.ptr(self.dws),
+                                                  self.dws.numel(), L.stream(flat_grad.device)), "lbfgs_direction")
+        return d
 
 
 class LBFGSNew(Optimizer):
@@ -335,8 +398,8 @@ class LBFGSNew(Optimizer):
                 vec.scale(s, t)
                 if batch_mode:
                     vec.axpy(y, lm0, s)  # trust region
-                ys = vec.dot(y, s)
-                sn = math.sqrt(vec.dot(s, s))
+                ys, ss, yy = vec.dots([(y, s), (s, s), (y, y)])  # one host read for the three curvature products
+                sn = math.sqrt(ss)
                 batch_changed = batch_mode and (n_iter == 1 and st["n_iter"] > 1)
                 if batch_changed:
                     # online inter-batch mean / second moment of the gradient -> bound on the step
@@ -351,21 +414,10 @@ class LBFGSNew(Optimizer):
                         old_stps.pop(0)
                     old_dirs.append(y)
                     old_stps.append(s)
-                    H_diag = ys / vec.dot(y, y)
+                    H_diag = ys / yy
                 if isinstance(H_diag, float) and math.isnan(H_diag):
                     print("Warning H_diag nan")
-                num_old = len(old_dirs)
-                ro = [1.0 / vec.dot(old_dirs[i], old_stps[i]) for i in range(num_old)]
-                al = [0.0] * num_old
-                q = flat_grad.neg()
-                for i in range(num_old - 1, -1, -1):
-                    al[i] = vec.dot(old_stps[i], q) * ro[i]
-                    vec.axpy(q, -al[i], old_dirs[i])
-                vec.scale(q, float(H_diag))
-                d = q
-                for i in range(num_old):
-                    be_i = vec.dot(old_dirs[i], d) * ro[i]
-                    vec.axpy(d, al[i] - be_i, old_stps[i])
+                d = vec.direction(old_dirs, old_stps, flat_grad, H_diag)
             if prev_flat_grad is None:
                 prev_flat_grad = flat_grad.clone()
             else:

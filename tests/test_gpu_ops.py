@@ -608,6 +608,52 @@ def test_flat_dot_alignment_and_tail():
         assert abs(float(out[0]) - want) <= 1e-9 * max(1.0, abs(want))
 
 
+@pytest.mark.parametrize("n,off", [(100003, 0), (100003, 1), (4096, 0), (7, 0)])
+def test_multi_dot_and_device_two_loop_recursion(n, off):
+    """lshm_multi_dot_flat and lshm_lbfgs_direction (src/lbfgsnew.py:632-651 on the device) against the host loop
+    in fp64, for m = 0, 1, 3, 7 stored pairs, aligned and unaligned vectors, an n % 4 tail, and through the
+    optimiser's own vector backends (the device backend and the host-loop backend must agree)."""
+    from lshm_amd import lbfgsnew as LB
+    g = torch.Generator().manual_seed(31 + n + off)
+    mk = lambda: torch.randn(n + off, generator=g).to(DEV)[off:]
+    vec = LB._HipVec(torch.device(DEV))
+    pairs = [(mk(), mk()) for _ in range(5)]
+    got = vec.dots(pairs)
+    for (a, b), v in zip(pairs, got):
+        want = float((a.double() * b.double()).sum())
+        assert abs(v - want) <= 1e-9 * max(1.0, abs(want))
+    for m in (0, 1, 3, 7):
+        ys = [mk() for _ in range(m)]
+        ss = [y * 0.3 + 0.1 * mk() for y in ys]  # <y_i, s_i> > 0, as the curvature test guarantees
+        grad = mk()
+        h = 0.37
+        d = vec.direction(ys, ss, grad, h)
+        # the host loop of the reference, in fp64
+        q = -grad.double()
+        ro = [1.0 / float((y.double() * s_.double()).sum()) for y, s_ in zip(ys, ss)]
+        al = [0.0] * m
+        for i in range(m - 1, -1, -1):
+            al[i] = float((ss[i].double() * q).sum()) * ro[i]
+            q -= al[i] * ys[i].double()
+        q *= h
+        for i in range(m):
+            be = float((ys[i].double() * q).sum()) * ro[i]
+            q += (al[i] - be) * ss[i].double()
+        assert rel_err(d, q.float()) < 5e-6, m
+        # and the fp32 host loop on the device primitives (what the optimiser ran before): same numbers
+        d_loop = LB._two_loop(vec, ys, ss, grad, h)
+        assert rel_err(d, d_loop) < 5e-6, m
+        assert ys[0].data_ptr() != d.data_ptr() if m else True
+    # argument checks: too many pairs, aliasing
+    lib = vec.lib
+    import ctypes as C
+    big = (C.c_void_p * 17)(*[grad.data_ptr()] * 17)
+    ws = torch.empty(int(lib.lshm_lbfgs_direction_workspace_doubles(16)), device=DEV, dtype=torch.float64)
+    assert lib.lshm_lbfgs_direction(big, big, 17, grad.data_ptr(), 1.0, d.data_ptr(), n, ws.data_ptr(), ws.numel(), None) != 0
+    one = (C.c_void_p * 1)(d.data_ptr())
+    assert lib.lshm_lbfgs_direction(one, one, 1, grad.data_ptr(), 1.0, d.data_ptr(), n, ws.data_ptr(), ws.numel(), None) != 0
+
+
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(t.dtype)
 

@@ -333,8 +333,11 @@ def test_fused_backward_of_outer_1d_layer_matches_separate_kernels(precision):
             assert torch.equal(tr.view(name, grads[0]), tr.view(name, grads[1])), name
     assert not torch.equal(grads[0], grads[1])  # the switch did select another kernel
     assert rel_err(grads[0], grads[1]) < 2e-6
+    # with bf16 storage a last-bit fp32 difference upstream can flip the rounding of a bf16 gradient image element
+    # (4e-3 of that element); tensors whose gradient is a cancelling sum (fcuv3.weight, 1e-8) moved by 1.7e-4
+    tol = 2e-5 if precision == "fp32" else 1e-3
     for name in tr.layout:
-        assert rel_err(tr.view(name, grads[0]), tr.view(name, grads[1])) < 2e-5, name
+        assert rel_err(tr.view(name, grads[0]), tr.view(name, grads[1])) < tol, name
 
 
 @pytest.mark.parametrize("K,precision,tol", [(10, "fp32", 5e-5), (64, "fp32", 5e-5), (10, "bf16", 5e-5), (10, "bf16s", 5e-5)],
