@@ -635,6 +635,23 @@ def main():
             dt3 = tt.item()
         out["lbfgs_iteration"] = {"value": round(world * B * nl / dt3, 1), "unit": "patches/s", "ms_per_step": round(dt3 / nl * 1e3, 3),
                                   "steps": nl, "note": "one ADMM iteration with LBFGSNew.step(closure) instead of Adam"}
+        # not upstream's evaluation pattern (secondary figure, like reuse_forward_mode): the line search starts from the
+        # loss step() has just computed at the same point instead of re-evaluating the deterministic closure there
+        opt = tr.make_lbfgs(reuse_known_loss=True)
+        tr.invalidate_forward()
+        for _ in range(3):
+            tr.step_lbfgs(opt)
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(nl):
+            tr.step_lbfgs(opt)
+        barrier()
+        dt4 = time.perf_counter() - t2
+        if world > 1:
+            tt = torch.tensor([dt4], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt4 = tt.item()
+        out["lbfgs_iteration"]["reuse_known_loss"] = {"value": round(world * B * nl / dt4, 1), "ms_per_step": round(dt4 / nl * 1e3, 3)}
     if rank == 0 and not args.no_roofline:
         out["gemm_family_roofline"] = gemm_family_roofline(tr, dev)
         out["stream_kernel_roofline"] = stream_kernel_roofline(tr, dev)

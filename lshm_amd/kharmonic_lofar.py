@@ -391,7 +391,9 @@ class KHarmonicTrainer:
     # ------------------------------------------------------------------ LBFGS (src/kharmonic_lofar.py:93)
     def make_lbfgs(self, history_size=7, max_iter=4, line_search_fn=True, batch_mode=True, **kw):
         """LBFGSNew over the flat arena (defaults = the commented-out line 93 of the upstream script).
-        The arena is exposed as ONE parameter whose .grad is the engine's gradient buffer."""
+        The arena is exposed as ONE parameter whose .grad is the engine's gradient buffer.
+        `reuse_known_loss=True` (LBFGSNew option, off by default as upstream re-evaluates): the engine's closure is
+        deterministic, so the line search may start from the loss step() has just computed at the same point."""
         from .lbfgsnew import LBFGSNew
         self._flat_param = torch.nn.Parameter(self.params, requires_grad=True)
         self._flat_param.grad = self.grads

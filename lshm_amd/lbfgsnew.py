@@ -140,7 +140,13 @@ class _HipVec:
 
 class LBFGSNew(Optimizer):
     def __init__(self, params, lr=1, max_iter=10, max_eval=None, tolerance_grad=1e-5, tolerance_change=1e-9,
-                 history_size=7, line_search_fn=False, batch_mode=False, cost_use_gradient=False):
+                 history_size=7, line_search_fn=False, batch_mode=False, cost_use_gradient=False,
+                 reuse_known_loss=False):
+        """reuse_known_loss (not upstream; off by default): the line searches start by evaluating the closure at the
+        point where step() has just evaluated it (src/lbfgsnew.py:277, :472).  For a deterministic closure that value
+        is known: with the option on it is reused instead of recomputed (one gradient-free evaluation less per inner
+        iteration; evaluation counters unchanged -- upstream does not count these either)."""
+        self._reuse_known_loss = bool(reuse_known_loss)
         if max_eval is None:
             max_eval = max_iter * 5 // 4
         defaults = dict(lr=lr, max_iter=max_iter, max_eval=max_eval, tolerance_grad=tolerance_grad,
@@ -195,12 +201,12 @@ class LBFGSNew(Optimizer):
         return self.state[self._params[0]]
 
     # ------------------------------------------------------------------ line searches
-    def _linesearch_backtrack(self, closure, pk, gk, alphabar):
+    def _linesearch_backtrack(self, closure, pk, gk, alphabar, f_known=None):
         """Armijo backtracking from alphabar; if the decrease is too small also try negative steps."""
         c1, citer = 1e-4, 35
         alphak = alphabar
         xk = self._snapshot()
-        f_old = float(closure())
+        f_old = float(closure()) if f_known is None else f_known
         self._move(alphak, pk)
         f_new = float(closure())
         prodterm = c1 * self._vec.dot(gk, pk)
@@ -298,13 +304,13 @@ class LBFGSNew(Optimizer):
         st["func_evals"] += evals
         return alphaj
 
-    def _linesearch_cubic(self, closure, pk, step):
+    def _linesearch_cubic(self, closure, pk, step, phi_known=None):
         lr = self.param_groups[0]["lr"]
         alpha1, sigma, rho, t1, t2, t3 = 10 * lr, 0.1, 0.01, 9, 0.1, 0.5
         alphak = lr
         st = self._st()
         xk = self._snapshot()
-        phi_0 = float(closure())
+        phi_0 = float(closure()) if phi_known is None else phi_known
         tol = min(phi_0 * 0.01, 1e-6)
         gphi_0 = self._slope_here(closure, pk, step)
         if abs(gphi_0) < 1e-12:
@@ -434,10 +440,11 @@ class LBFGSNew(Optimizer):
                 if not cost_use_gradient:
                     torch.set_grad_enabled(False)
                 try:
+                    known = loss if self._reuse_known_loss else None  # the closure value at the current point
                     if batch_mode:
-                        t = self._linesearch_backtrack(closure, d, flat_grad, alphabar)
+                        t = self._linesearch_backtrack(closure, d, flat_grad, alphabar, known)
                     else:
-                        t = self._linesearch_cubic(closure, d, 1e-6)
+                        t = self._linesearch_cubic(closure, d, 1e-6, known)
                 finally:
                     torch.set_grad_enabled(grad_was)
                 if math.isnan(t):

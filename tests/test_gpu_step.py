@@ -217,6 +217,31 @@ def test_lbfgs_step_matches_oracle_driven_lbfgs():
         assert rel_err(tr.y[k], y_new[k]) < 2e-3
 
 
+def test_lbfgs_reuse_known_loss_is_the_same_trajectory():
+    """LBFGSNew(reuse_known_loss=True): the line search takes the loss step() has just computed instead of evaluating
+    the (deterministic) closure again at the same point.  The gradient-free and the gradient closure of the engine
+    give the same loss to the last bits of fp64 accumulation, so the trajectory is the same to rounding."""
+    outs = []
+    for reuse in (False, True):
+        tr, ocfg, params, M, x, uv = _trainer(4, 4, 2, 2)
+        opt = tr.make_lbfgs(history_size=7, max_iter=3, line_search_fn=True, batch_mode=True, reuse_known_loss=reuse)
+        calls = [0]
+        orig = tr.lbfgs_closure
+
+        def counting():
+            calls[0] += 1
+            return orig()
+        tr.lbfgs_closure = counting
+        for _ in range(2):
+            tr.step_lbfgs(opt)
+        torch.cuda.synchronize()
+        outs.append((tr.params.clone(), tr.read_terms()["total"], calls[0], opt.state[opt._params[0]]["func_evals"]))
+    assert rel_err(outs[0][0], outs[1][0]) < 1e-6
+    assert abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[0][1])
+    assert outs[1][2] < outs[0][2]           # fewer closure evaluations ...
+    assert outs[0][3] == outs[1][3]          # ... and the same evaluation counter (upstream does not count these)
+
+
 def test_step_with_k64_clusters():
     """Config 5's K=64 (generic KHM path, one wave per row)."""
     tr, ocfg, params, M, x, uv = _trainer(4, 64, 2, 2)
