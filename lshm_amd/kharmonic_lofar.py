@@ -161,9 +161,17 @@ class KHarmonicTrainer:
             import torch.distributed as dist
             if dist.get_backend(process_group) == "nccl" and self.lib.lshm_comm_available():
                 from .dist import Communicator
-                self._comm = Communicator(process_group, self.device)
-                with L.on_device(self.device):
-                    L.check(self.lib.lshm_engine_set_comm(self._h, self._comm.handle), "engine_set_comm")
+                try:
+                    self._comm = Communicator(process_group, self.device)
+                    with L.on_device(self.device):
+                        L.check(self.lib.lshm_engine_set_comm(self._h, self._comm.handle), "engine_set_comm")
+                except Exception as e:  # still RCCL, through torch.distributed after the closure (same sums)
+                    import sys
+                    print(f"lshm_amd: engine-side RCCL communicator unavailable ({e}); using torch.distributed "
+                          "all-reduces after the closure", file=sys.stderr)
+                    if self._comm is not None:
+                        self._comm.close()
+                    self._comm = None
         self._graph = None
         self._saved_forward = False  # the workspace holds the forward of the current params / x / uv
         self._recon_ready = False    # ... and the reconstruction terms of the next closure (share_recon_pass)
