@@ -525,10 +525,11 @@ def main():
             tr._graph = None
 
     def barrier():
+        torch.cuda.synchronize()  # this rank's queued work first: the barrier then marks "every rank's GPU is idle"
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         tr.step()
