@@ -836,7 +836,11 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     if (e->device >= 0 && (!e->pair_mode || e->side_wgrad)) {
       bool ok = hipStreamCreateWithFlags(&e->wstream, hipStreamNonBlocking) == hipSuccess;
       ok = ok && hipStreamCreateWithFlags(&e->lstream, hipStreamNonBlocking) == hipSuccess;
-      e->events.resize(128);
+      {
+        const char* v = getenv("LSHM_EVENT_POOL");
+        const int n = v ? atoi(v) : 128;
+        e->events.resize(n >= 32 ? n : 32);
+      }
       for (size_t i = 0; i < e->events.size() && ok; ++i)
         ok = ok && hipEventCreateWithFlags(&e->events[i], hipEventDisableTiming) == hipSuccess;
       e->side_ok = ok;
