@@ -18,7 +18,11 @@ import os
 import sys
 import time
 
-import torch
+# the host driver of this pool only supports dmabuf IPC (RCCL, tensor sharing): must be in the environment before the
+# HIP runtime initialises, i.e. before the first torch.cuda call of this process
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
