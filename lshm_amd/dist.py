@@ -19,6 +19,7 @@ import torch.distributed as dist
 def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] = None):
     """Initialise the default process group from torchrun's environment (RANK, WORLD_SIZE,
     LOCAL_RANK, MASTER_ADDR/PORT).  Returns (rank, world, local_rank, group-or-None)."""
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver; before HIP initialises
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -28,7 +29,6 @@ def init_from_env(backend: Optional[str] = None, device: Optional[torch.device] 
     if world == 1:
         return rank, world, local, None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if not dist.is_initialized():
