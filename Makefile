@@ -8,7 +8,7 @@ SRCS := $(wildcard $(CSRC)/*.hip)
 OBJS := $(patsubst $(CSRC)/%.hip,$(OBJDIR)/%.o,$(SRCS))
 HIPFLAGS := -O3 --offload-arch=$(ARCH) -fPIC -std=c++17 -Wall -Wno-unused-function
 
-all: $(LIB) oracle
+all: $(LIB) oracle testlibs
 
 $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h include/lshm.h
 	@mkdir -p $(OBJDIR)
@@ -24,7 +24,13 @@ oracle/_build/liblshm_oracle_c.so: oracle/lshm_oracle_c.c
 	@mkdir -p oracle/_build
 	gcc -O2 -fPIC -shared -fopenmp -o $@ $< -lm
 
-clean:
-	rm -rf build lshm_amd/lib oracle/_build
+# test infrastructure: a host-shared-memory stand-in for RCCL (two ranks on one GPU, tests/test_gpu_dp.py)
+testlibs: tests/fake_rccl/libfake_rccl.so
 
-.PHONY: all oracle clean
+tests/fake_rccl/libfake_rccl.so: tests/fake_rccl/fake_rccl.cpp
+	$(HIPCC) -O2 -fPIC -shared -std=c++17 --offload-arch=$(ARCH) -o $@ $< -lrt
+
+clean:
+	rm -rf build lshm_amd/lib oracle/_build tests/fake_rccl/libfake_rccl.so
+
+.PHONY: all oracle testlibs clean

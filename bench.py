@@ -60,6 +60,10 @@ def parse():
     ap.add_argument("--bf16-operands-only", action="store_true",
                     help="with --bf16: keep every tensor in HBM fp32 (round the GEMM operands only)")
     ap.add_argument("--only-khm", action="store_true", help="time only the K-harmonic kernel (dev aid)")
+    ap.add_argument("--no-extra-modes", action="store_true",
+                    help="skip the secondary objects (sequential_forwards_mode, bf16_mode, k64_mode, admm10_loop)")
+    ap.add_argument("--sequential-forwards", action="store_true",
+                    help="headline with TrainConfig.overlap_forwards=False (the round-2 schedule), for A/B")
     return ap.parse_args()
 
 
@@ -135,7 +139,20 @@ def khm_distance_roofline(dev, N=1 << 20, D=256, K=10, p=4.0):
             "frac": round(ach / HBM_PEAK_GBS, 4), "ms": round(ms, 4)}
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r02", "hbm_traffic.json")
+PMC_FILE = next((q for q in (os.path.join(ROOT, "profiles", r, "hbm_traffic.json") for r in ("r03", "r02"))
+                 if os.path.exists(q)), os.path.join(ROOT, "profiles", "r03", "hbm_traffic.json"))
+
+
+def _pmc_file_id():
+    """Which committed PMC file `traffic` figures come from, and its git blob id (sha1 of "blob <size>\0" + content):
+    traffic is NOT measured in this run, so a stale file must be visible in the line itself."""
+    import hashlib
+    try:
+        with open(PMC_FILE, "rb") as f:
+            data = f.read()
+        return {"file": os.path.relpath(PMC_FILE, ROOT), "git_blob": hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()}
+    except OSError:
+        return None
 
 
 def _pmc_traffic(kernel_key, grid=None):
@@ -154,11 +171,11 @@ def _pmc_traffic(kernel_key, grid=None):
         return None
 
 
-def _pmc_step_traffic():
+def _pmc_step_traffic(key="step"):
     """HBM bytes of one whole ADMM iteration (sum over its launches) from the same file, or None."""
     try:
         with open(PMC_FILE) as f:
-            return json.load(f)["step"]["traffic_bytes"]
+            return json.load(f)[key]["traffic_bytes"]
     except Exception:
         return None
 
@@ -400,19 +417,34 @@ def other_kernel_rooflines(tr, dev):
 
 
 def _lscpu():
-    """Host CPU as `lscpu` reports it (model, sockets, cores per socket, threads per core)."""
-    import subprocess
+    """Host CPU description (model, sockets, cores per socket, threads per core, logical CPUs) read from
+    /proc/cpuinfo in-process: a process that has initialised the GPU must not fork + exec (`lscpu`)."""
     try:
-        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
-    except Exception:
-        return "lscpu unavailable"
-    want = ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core", "CPU(s)")
-    got = {}
+        with open("/proc/cpuinfo") as f:
+            txt = f.read()
+    except OSError:
+        return f"CPU(s): {os.cpu_count()}"
+    model, phys, cores_per, siblings, ncpu = None, set(), None, None, 0
     for line in txt.splitlines():
         k, _, v = line.partition(":")
-        if k.strip() in want and k.strip() not in got:
-            got[k.strip()] = v.strip()
-    return "; ".join(f"{k}: {got[k]}" for k in want if k in got)
+        k, v = k.strip(), v.strip()
+        if k == "processor":
+            ncpu += 1
+        elif k == "model name" and model is None:
+            model = v
+        elif k == "physical id":
+            phys.add(v)
+        elif k == "cpu cores" and cores_per is None:
+            cores_per = int(v)
+        elif k == "siblings" and siblings is None:
+            siblings = int(v)
+    out = [f"Model name: {model}", f"Socket(s): {max(len(phys), 1)}"]
+    if cores_per:
+        out.append(f"Core(s) per socket: {cores_per}")
+        if siblings:
+            out.append(f"Thread(s) per core: {max(siblings // cores_per, 1)}")
+    out.append(f"CPU(s): {ncpu or os.cpu_count()}")
+    return "; ".join(out)
 
 
 # measured in the build container (8 vCPU Xeon @ 2.1 GHz, 8 threads, B=256, K=10; profiles/reference_cpu_timing.py):
@@ -468,6 +500,95 @@ def _cpu_baseline_once(args, threads, nsteps):
             "s_per_step": round(t, 3)}
 
 
+def _timed_steps(tr, steps, warmup, barrier, world, dev, log=False):
+    """`steps` ADMM iterations after `warmup` untimed ones, barrier + synchronize on both sides, MAX over ranks."""
+    for _ in range(warmup):
+        tr.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+        if log:
+            tr.read_terms()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    return dt
+
+
+def _variant(args, dev, pg, rank, world, barrier, x, uv, **cfg_kw):
+    """A second trainer with another configuration on the same synthetic minibatch: value / ms_per_step / step frac."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    B = args.batch
+    K = cfg_kw.pop("Kc", args.K)
+    tr = KHarmonicTrainer(TrainConfig(Kc=K, **cfg_kw), batch=B, batch_per_bline=args.bpb, default_batch=B // args.bpb,
+                          device=dev, process_group=pg)
+    tr.init_parameters(seed=0)
+    tr.new_minibatch(x.to(dev), uv.to(dev))
+    dt = _timed_steps(tr, args.steps, max(2, args.warmup), barrier, world, dev)
+    ms = dt / args.steps * 1e3
+    terms = tr.read_terms()
+    del tr
+    torch.cuda.empty_cache()
+    ach = STEP_BYTES_PER_PATCH * B / (ms * 1e-3) / 1e9
+    return {"value": round(world * B * args.steps / dt, 1), "unit": "patches/s", "ms_per_step": round(ms, 4),
+            "step_roofline": {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(ach / HBM_PEAK_GBS, 4)},
+            "loss_total": terms["total"], "nonfinite_terms": terms["nonfinite"]}
+
+
+def admm10_loop(args, dev, pg, rank, world, barrier, gen):
+    """The loop the reference runs (src/kharmonic_lofar.py:116-131,176-181): per minibatch ten ADMM iterations with the
+    eight terms read back on the host in every one; a NEW minibatch every ten iterations, handed over as host
+    tensors (pinned, 64 MiB at B=256) and uploaded on a copy stream while the previous ten iterate; inside the ten,
+    iteration k+1 starts from iteration k's no-grad forward (TrainConfig.reuse_forward: 9 of 10 closure forwards are
+    the same computation as the no-grad forward before them, bit for bit)."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    B, nadmm = args.batch, 10
+    tr = KHarmonicTrainer(TrainConfig(Kc=args.K, reuse_forward=True), batch=B, batch_per_bline=args.bpb,
+                          default_batch=B // args.bpb, device=dev, process_group=pg)
+    tr.init_parameters(seed=0)
+    host = []
+    for _ in range(3):  # three pinned host minibatches, cycled
+        xb = torch.randn(B, 4, 128, 128, generator=gen)
+        xb = ((xb - xb.mean()) / xb.std()).pin_memory()
+        host.append((xb, (1000.0 * torch.randn(B, 2, generator=gen)).pin_memory()))
+    nmb = max(2, (args.steps + nadmm - 1) // nadmm)
+
+    def run(n):
+        for mb in range(n):
+            tr.swap_in_minibatch()
+            tr.prefetch_minibatch(*host[(mb + 1) % 3])
+            for _ in range(nadmm):
+                tr.step()
+                tr.read_terms()
+    tr.prefetch_minibatch(*host[0])
+    run(1)
+    barrier()
+    t0 = time.perf_counter()
+    run(nmb)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    its = nmb * nadmm
+    del tr
+    torch.cuda.empty_cache()
+    return {"value": round(world * B * its / dt, 1), "unit": "patches/s", "ms_per_iteration": round(dt / its * 1e3, 4),
+            "minibatches": nmb, "iterations_per_minibatch": nadmm,
+            "host_to_device_bytes_per_minibatch": B * 4 * 128 * 128 * 4 + B * 2 * 4,
+            "note": "new pinned host minibatch every 10 iterations (H2D on a copy stream, overlapped), terms read back every "
+                    "iteration, reuse_forward inside the 10; trajectory bitwise that of the recomputing trainer "
+                    "(tests/test_gpu_step.py::test_admm_loop_with_staged_minibatches_is_the_recompute_trajectory)"}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -505,7 +626,8 @@ def main():
     from lshm_amd import KHarmonicTrainer, TrainConfig
     B = args.batch
     cfg = TrainConfig(Kc=args.K, matrix_precision="bf16" if args.bf16 else "fp32",
-                      activation_storage="bf16" if (args.bf16 and not args.bf16_operands_only) else "fp32")
+                      activation_storage="bf16" if (args.bf16 and not args.bf16_operands_only) else "fp32",
+                      overlap_forwards=not args.sequential_forwards)
     tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=args.bpb, default_batch=B // args.bpb, device=dev,
                           process_group=pg)
     tr.init_parameters(seed=0)  # identical replicas on every rank
@@ -535,19 +657,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        tr.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = tt.item()
+    dt = _timed_steps(tr, args.steps, args.warmup, barrier, world, dev)
     terms = tr.read_terms()
     ms = dt / args.steps * 1e3
     value = world * B * args.steps / dt
@@ -555,17 +665,7 @@ def main():
     # The reference prints its eight terms in every closure (src/kharmonic_lofar.py:176-181): the same loop with the
     # step log read back every iteration (one device->host copy of ten doubles, which also stops the host from
     # running ahead of the device).  `value` above is the free-running figure.
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.step()
-        tr.read_terms()
-    barrier()
-    dtl = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dtl], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dtl = tt.item()
+    dtl = _timed_steps(tr, args.steps, 0, barrier, world, dev, log=True)
 
     # Not the headline: the same iterations with TrainConfig.reuse_forward (iteration k+1 starts from the
     # activations of iteration k's no-grad forward; bit-for-bit the same trajectory, tests/test_gpu_step.py::
@@ -600,6 +700,9 @@ def main():
                                   f"fwd+bwd + Adam (all 4 groups) + no-grad fwd + multiplier update",
                       "global_batch": world * B, "per_gpu_batch": B, "K": args.K, "bpb": args.bpb,
                       "parallelism": f"dp{world}", "launch": "hipgraph" if use_graph else "eager",
+                      "schedule": "no-grad forward of iteration k and closure forward of iteration k+1 on two streams "
+                                  "(TrainConfig.overlap_forwards)" if cfg.overlap_forwards and not use_graph else
+                                  "forwards one after the other",
                       "feature_stage": "v2 path (row/column 1D AEs); FFT op benchmarked separately"},
            "loss_total": terms["total"], "nonfinite_terms": terms["nonfinite"],
            "value_with_log": {"value": round(world * B * args.steps / dtl, 1), "unit": "patches/s",
@@ -615,11 +718,25 @@ def main():
                         "ms": round(ms, 4), "bytes_per_launch": STEP_BYTES_PER_PATCH * B,
                         "flop_frac_of_f32_matrix_peak": round(STEP_FLOP_PER_PATCH * B / (ms * 1e-3) / 1e12 / 157.3, 4),
                         "traffic": _pmc_step_traffic() if B == 256 and args.K == 10 and not args.bf16 else None,
+                        "traffic_source": _pmc_file_id(),
                         "note": "algorithmic 15.04 MB/patch (SURVEY 8d: layer-wise read input + write output, glue passes "
                                 "counted as zero); traffic = PMC HBM bytes summed over the iteration's launches"}}
     out["step_roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
     if reuse is not None:
         out["reuse_forward_mode"] = reuse
+    if not use_graph and not args.no_extra_modes and not args.bf16 and args.K == 10:
+        # secondary objects, each on a trainer of its own over the same synthetic minibatch:
+        #  sequential_forwards_mode  the round-2 schedule (overlap_forwards=False), for round-to-round comparison
+        #  bf16_mode                 BASELINE.json configs[2]: bf16 matrix operands + bf16 activation storage
+        #  k64_mode                  configs[4]'s K = 64 centroids, Adam iteration
+        #  admm10_loop               the loop upstream runs: new host minibatch every 10 iterations, terms read back
+        out["sequential_forwards_mode"] = _variant(args, dev, pg, rank, world, barrier, x, uv, overlap_forwards=False)
+        out["bf16_mode"] = _variant(args, dev, pg, rank, world, barrier, x, uv, matrix_precision="bf16",
+                                    activation_storage="bf16")
+        out["bf16_mode"]["dtype"] = "bf16 operands (v_mfma_f32_16x16x16_bf16) + bf16 storage of the image-sized tensors, f32 accumulate"
+        out["bf16_mode"]["traffic"] = _pmc_step_traffic("step_bf16")
+        out["k64_mode"] = _variant(args, dev, pg, rank, world, barrier, x, uv, Kc=64)
+        out["admm10_loop"] = admm10_loop(args, dev, pg, rank, world, barrier, gen)
     if not args.no_lbfgs and not use_graph:
         # the LBFGS iteration (LBFGSNew(history 7, max_iter 4, line search, batch mode), the
         # commented-out optimiser of src/kharmonic_lofar.py:93) reported beside the Adam iteration

@@ -337,6 +337,21 @@ size_t lshm_engine_workspace_floats(const lshm_engine* e);
  * as their backward is complete, on a stream of their own beside the 2-D autoencoder's backward; the rest
  * follows the last weight gradient.  The communicator's world size must equal lshm_step_config.world. */
 int lshm_engine_set_comm(lshm_engine* e, lshm_comm* comm);
+/* The early bucket exists only where the engine has its side streams; the SEQUENCE of collectives must be the
+ * same on every rank, so the ranks agree on it once: each asks lshm_engine_comm_early_bucket (1: this engine
+ * would send the netT / netF gradients early), the answers are MIN-reduced over the job, and the result goes to
+ * lshm_engine_set_early_bucket on every rank (0: one closing group only).  A captured call (HIP graph) never uses
+ * the early bucket: it would be a fork nested in the forked weight-gradient stream, which hipStreamEndCapture of
+ * ROCm 7.2 does not survive. */
+int lshm_engine_comm_early_bucket(const lshm_engine* e);
+int lshm_engine_set_early_bucket(lshm_engine* e, int on);
+/* HIP device the engine was created on (-1: no device): every engine call makes it current, refuses a stream of
+ * another device and refuses arena / workspace / input pointers that are not device memory of that device. */
+int lshm_engine_device(const lshm_engine* e);
+/* what the LAST engine call on `e` actually did (diagnostics, tests) */
+#define LSHM_ENGINE_USED_EARLY_BUCKET 1u       /* the netT / netF gradients went as an early all-reduce bucket */
+#define LSHM_ENGINE_USED_CONCURRENT_FORWARD 2u /* two forwards ran side by side (LSHM_NEXT_CONCURRENT_FORWARD) */
+unsigned lshm_engine_last_flags(const lshm_engine* e);
 /* closure forward + backward: fills grads (same layout as params) and terms[16] (double, device):
  * [0..7] = loss0, loss1, loss2, loss3, kdist, aug, sim, rica (already weighted, as logged upstream),
  * [8] = total, [9] = how many of [0..7] are NaN or infinite (0 = healthy; sums over ranks like the rest).  With world > 1 the loss terms / gradients are this rank's share (sum over ranks = global). */
@@ -371,6 +386,16 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
 int lshm_engine_multiplier_update_next(lshm_engine* e, const float* params, const float* x, const float* uv,
                                        float* y1, float* y2, float* y3, float* workspace,
                                        size_t workspace_floats, lshm_stream_t stream);
+/* flags of lshm_engine_multiplier_update_next_ex */
+#define LSHM_NEXT_CONCURRENT_FORWARD 1u /* ALSO run the closure forward of the next iteration, concurrently: the no-grad
+                                         * forward that closes iteration k (src/kharmonic_lofar.py:187-196) and the closure
+                                         * forward that opens iteration k+1 (:135-150) depend on the updated parameters
+                                         * alone, so they are issued as two chains on two HIP streams with separate
+                                         * activation buffers (both are computed, as upstream computes both; neither
+                                         * waits for the other).  The next closure is then lshm_engine_backward_saved. */
+int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, const float* x, const float* uv,
+                                          float* y1, float* y2, float* y3, float* workspace,
+                                          size_t workspace_floats, unsigned flags, lshm_stream_t stream);
 /* closure forward only (line-search evaluations of LBFGS): terms as above */
 int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x, const float* uv,
                              const float* y1, const float* y2, const float* y3, double* terms,

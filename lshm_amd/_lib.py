@@ -38,6 +38,8 @@ class StepConfig(C.Structure):
 
 PRECISION_F32, PRECISION_BF16_OPERANDS, PRECISION_BF16_STORAGE = 0, 1, 2
 STEP_RECON_READY = 1
+NEXT_CONCURRENT_FORWARD = 1
+ENGINE_USED_EARLY_BUCKET, ENGINE_USED_CONCURRENT_FORWARD = 1, 2
 
 
 _SIGNATURES = {
@@ -130,6 +132,11 @@ _SIGNATURES = {
     "lshm_engine_backward_saved": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_multiplier_update": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_multiplier_update_next": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
+    "lshm_engine_multiplier_update_next_ex": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, C.c_uint, c_void_p]),
+    "lshm_engine_device": (c_int, [c_void_p]),
+    "lshm_engine_last_flags": (C.c_uint, [c_void_p]),
+    "lshm_engine_comm_early_bucket": (c_int, [c_void_p]),
+    "lshm_engine_set_early_bucket": (c_int, [c_void_p, c_int]),
     "lshm_engine_encode": (c_int, [c_void_p] * 8 + [c_void_p, c_size_t, c_void_p]),
 }
 # `_bf16` forms of the GEMM-shaped entry points: same prototypes (include/lshm.h)
@@ -201,15 +208,19 @@ _scratch = {}
 
 
 def scratch(device, nfloats: int):
-    """Split-K scratch reused by the autograd wrappers, one buffer per (device, stream): work on one
-    stream is ordered, work on two streams is not, so they never share.  Grows on demand."""
+    """Split-K scratch of the autograd wrappers.  The DEFAULT stream of a device keeps one persistent buffer
+    (grown on demand): work on one stream is ordered, so its launches may share it.  Any other stream gets a
+    fresh tensor from torch's caching allocator per call -- stream-safe by construction (the allocator ties the
+    block to the stream that is current now), effectively free after warm-up, and nothing is pinned for a
+    stream that has gone away (a raw stream handle can be re-used by a later stream)."""
     device = torch.device(device)
     index = device.index if device.index is not None else torch.cuda.current_device()
-    key = (index, torch.cuda.current_stream(index).cuda_stream)
-    t = _scratch.get(key)
+    if torch.cuda.current_stream(index) != torch.cuda.default_stream(index):
+        return torch.empty(max(int(nfloats), 1), device=torch.device("cuda", index), dtype=torch.float32)
+    t = _scratch.get(index)
     if t is None or t.numel() < nfloats:
         t = torch.empty(max(int(nfloats), 1 << 20), device=torch.device("cuda", index), dtype=torch.float32)
-        _scratch[key] = t
+        _scratch[index] = t
     return t
 
 

@@ -6,6 +6,10 @@
 
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace lshm {
 static thread_local char g_err[256] = "";
 void set_last_error(const char* msg) {
@@ -17,6 +21,41 @@ int check_launch(const char* what) {
   if (e == hipSuccess) return LSHM_OK;
   snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
   return (int)e;
+}
+int device_lds_bytes() {
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return v;
+}
+int kernel_budget_ok(const void* kernel, int threads, size_t dyn_lds, const char* what) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, std::pair<size_t, int>> known;  // (kernel, device) -> (static LDS, max threads)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return LSHM_OK; }  // no device: the launch itself reports it
+  std::pair<size_t, int> kv;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = known.find({kernel, dev});
+    if (it == known.end()) {
+      hipFuncAttributes fa;
+      if (hipFuncGetAttributes(&fa, kernel) != hipSuccess) { (void)hipGetLastError(); return LSHM_OK; }
+      it = known.emplace(std::make_pair(kernel, dev), std::make_pair((size_t)fa.sharedSizeBytes, fa.maxThreadsPerBlock)).first;
+    }
+    kv = it->second;
+  }
+  const int lds_max = device_lds_bytes();
+  if (lds_max > 0 && kv.first + dyn_lds > (size_t)lds_max) {
+    snprintf(g_err, sizeof(g_err), "%s: needs %zu bytes of LDS per workgroup, the device has %d", what, kv.first + dyn_lds, lds_max);
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  if (kv.second > 0 && threads > kv.second) {
+    snprintf(g_err, sizeof(g_err), "%s: register budget allows %d threads per workgroup, the launch needs %d", what, kv.second, threads);
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  return LSHM_OK;
 }
 }  // namespace lshm
 

@@ -12,6 +12,7 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace {
@@ -31,11 +32,18 @@ struct Rccl {
 Rccl& rccl() {
   static Rccl r = [] {
     Rccl q;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names)
-      if ((q.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;  // a copy the process already has
-    for (const char* n : names)
-      if (!q.handle) q.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    // LSHM_RCCL_LIB: bind the eight entry points from this library instead (the rehearsal tests point it at a
+    // stand-in that sums through host shared memory, so two ranks on ONE GPU can drive the engine-attached path)
+    const char* override_path = getenv("LSHM_RCCL_LIB");
+    if (override_path && *override_path) {
+      q.handle = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+      for (const char* n : names)
+        if ((q.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;  // a copy the process already has
+      for (const char* n : names)
+        if (!q.handle) q.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
     if (!q.handle) return q;
 #define LSHM_SYM(field, name) q.field = reinterpret_cast<decltype(q.field)>(dlsym(q.handle, name))
     LSHM_SYM(GetUniqueId, "ncclGetUniqueId");

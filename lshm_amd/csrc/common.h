@@ -12,6 +12,12 @@ namespace lshm {
 
 void set_last_error(const char* msg);
 int check_launch(const char* what);  // hipGetLastError -> code + message
+// LSHM_OK if `kernel` can be launched on the current device with `threads` per workgroup and `dyn_lds` bytes of
+// dynamic LDS on top of its static allocation; LSHM_ERR_UNSUPPORTED (with a message) if its LDS or register
+// budget does not fit the device -- asked once per (kernel, device) and remembered.  A tile configuration or
+// kernel variant that cannot launch is thus a return code at the call site, never a failed or aborted dispatch.
+int kernel_budget_ok(const void* kernel, int threads, size_t dyn_lds, const char* what);
+int device_lds_bytes();  // LDS a workgroup may use on the current device (0: unknown)
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

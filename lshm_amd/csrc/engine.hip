@@ -64,6 +64,12 @@ struct lshm_engine {
   // shared workspace offsets
   size_t o_scales, o_uvh, o_Mu, o_gMu, o_row, o_col, o_gx1p, o_gx2, o_gx3c, o_gT, o_gFc, o_gx1,
       o_scal, o_dMscratch;
+  // Everything a forward pass writes (activations, harmonics, latents, residuals, its split-K scratch) sits in
+  // the first fwd_floats of the layout, and a second copy of that prefix follows the layout at alt_base: two
+  // forwards that do not depend on each other -- the no-grad forward that closes iteration k and the closure
+  // forward that opens iteration k+1 -- run side by side on two streams, each with `ws` or `ws + alt_base` as base.
+  size_t o_fpart, fwd_floats, alt_base;
+  hipStream_t fstream = nullptr;  // the no-grad forward + shared reconstruction pass, beside the next closure forward
   // Two "lanes" of backward scratch: netT and netF (independent given AE1's output, identical
   // shapes) run as pairs inside the same launches, each with its own lane; o_part/o_wpart of a
   // lane are adjacent and together form the split-K scratch of a paired launch.
@@ -94,6 +100,12 @@ struct lshm_engine {
   lshm_comm* comm = nullptr;
   hipStream_t cstream = nullptr;  // the early bucket (netT / netF gradients) runs here, beside the 2-D backward
   long off1d = 0;                 // arena offset of the first netT tensor: [0, off1d) net, [off1d, Moff) netT+netF
+  bool early_ok = true;           // ranks agree on the early bucket (lshm_engine_set_early_bucket); else one group at the end
+  bool in_capture = false;        // the stream of the current call is being captured (set by ENGINE_ENTER)
+  unsigned last_flags = 0;        // LSHM_ENGINE_USED_*: what the last call actually did (tests)
+  const void* seen_ptr[12] = {};  // device pointers already checked to live on this engine's device
+  int nseen = 0;
+  unsigned seen_total = 0;
 };
 
 namespace lshm {
@@ -198,7 +210,7 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
   const lshm_step_config& c = e->cfg;
   const AEPlan& a0 = e->ae[idx[0]];
   const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
-  float* part = ws + e->lane[ln].o_part;  // a pair uses the lane's two adjacent scratch regions
+  float* part = ws + e->o_fpart + (size_t)ln * 2 * e->part_floats;  // a pair uses two adjacent scratch regions
   const size_t pf = e->part_floats * (G > 1 ? 2 : 1);
   int rc;
   const float* in[2];
@@ -629,7 +641,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     }
   }
   bool early_bucket = false;
-  if (e->comm && wgs && e->cstream) {
+  if (e->comm && wgs && e->cstream && e->early_ok && !e->in_capture) {
     // netT / netF are done once their closing sums have run on the weight-gradient stream: their 1.9 MB go
     // now, on a stream of their own, while the 2-D autoencoder's backward runs
     hipEvent_t ev = e->take_event();
@@ -641,6 +653,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     const size_t nseg[1] = {(size_t)(e->Moff - e->off1d)};
     if ((rc = comm_allreduce_segments(e->comm, seg, nseg, 1, nullptr, 0, e->cstream))) return rc;
     early_bucket = true;
+    e->last_flags |= LSHM_ENGINE_USED_EARLY_BUCKET;
   }
   if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st, e->bf))) return rc;
   {
@@ -688,29 +701,81 @@ struct EngineCall {
   MatrixPrecisionScope prec;
   int prev_dev = -1;
   bool switched = false;
+  bool ok = true;  // false: the engine's device could not be made current -- nothing may be launched
   explicit EngineCall(const lshm_engine* e) : prec(e->cfg.precision != LSHM_PRECISION_F32) {
-    if (e->device >= 0 && hipGetDevice(&prev_dev) == hipSuccess && prev_dev != e->device)
+    if (e->device < 0) return;
+    if (hipGetDevice(&prev_dev) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
+    if (prev_dev != e->device) {
       switched = hipSetDevice(e->device) == hipSuccess;
+      if (!switched) { (void)hipGetLastError(); ok = false; }
+    }
   }
   ~EngineCall() {
     if (switched) (void)hipSetDevice(prev_dev);
   }
 };
-// Fork mode (LSHM_FORK=1: netT and netF on two streams, each with its own weight-gradient fork) nests stream
-// forks; ending a capture of that topology crashes hipStreamEndCapture (ROCm 7.2).  Refuse it up front.
-static int capture_fence(const lshm_engine* e, hipStream_t st) {
-  if (e->pair_mode || !e->side_ok) return LSHM_OK;
+// The stream of an engine call must belong to the engine's device, and so must the arena / workspace / input
+// pointers: a launch on the wrong device faults, or crosses the fabric silently.  Pointers are looked up once
+// (hipPointerGetAttributes) and remembered; host memory -- pinned or not -- is refused.
+static int device_fence(lshm_engine* e, hipStream_t st, std::initializer_list<const void*> ptrs) {
+  if (e->device < 0) return LSHM_OK;
+  if (st) {
+    hipDevice_t sd = -1;
+    if (hipStreamGetDevice(st, &sd) != hipSuccess) { (void)hipGetLastError(); }
+    else if ((int)sd != e->device) {
+      set_last_error("engine: the stream belongs to another device than the engine (lshm_engine_device)");
+      return LSHM_ERR_ARG;
+    }
+  }
+  for (const void* q : ptrs) {
+    if (!q) continue;
+    bool seen = false;
+    for (int i = 0; i < e->nseen; ++i) seen = seen || e->seen_ptr[i] == q;
+    if (seen) continue;
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+      (void)hipGetLastError();
+      set_last_error("engine: an argument is not a device pointer (host memory?)");
+      return LSHM_ERR_ARG;
+    }
+    if (at.type != hipMemoryTypeDevice || at.device != e->device) {
+      set_last_error(at.type != hipMemoryTypeDevice ? "engine: an argument points to host / managed memory, not device memory"
+                                                    : "engine: an argument lives on another device than the engine");
+      return LSHM_ERR_ARG;
+    }
+    e->seen_ptr[e->seen_total++ % 12] = q;
+    if (e->nseen < 12) ++e->nseen;
+  }
+  return LSHM_OK;
+}
+// Nested stream forks crash hipStreamEndCapture (ROCm 7.2): fork mode (LSHM_FORK=1: netT and netF on two
+// streams, each with its own weight-gradient fork) is refused under capture; the early all-reduce bucket of an
+// attached communicator (a fork off the forked weight-gradient stream, the same topology) is switched off for
+// the captured call -- its gradients then travel in the closing group on the capturing stream.
+static int capture_fence(lshm_engine* e, hipStream_t st) {
+  e->in_capture = false;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); return LSHM_OK; }
   if (cap == hipStreamCaptureStatusNone) return LSHM_OK;
+  e->in_capture = true;
+  if (e->pair_mode || !e->side_ok) return LSHM_OK;
   set_last_error("engine: stream capture is not supported in fork mode (LSHM_FORK=1); use the default paired launches");
   return LSHM_ERR_UNSUPPORTED;
 }
-#define ENGINE_ENTER(e, st)                       \
-  EngineCall engine_call_scope(e);                \
-  do {                                            \
-    const int rc_fence = capture_fence(e, st);    \
-    if (rc_fence) return rc_fence;                \
+#define ENGINE_ENTER(e, st, ...)                                                          \
+  EngineCall engine_call_scope(e);                                                        \
+  do {                                                                                    \
+    if (!engine_call_scope.ok) {                                                          \
+      set_last_error("engine: cannot make the engine's device current");                  \
+      return LSHM_ERR_ARG;                                                                \
+    }                                                                                     \
+    const int rc_fence = capture_fence(e, st);                                            \
+    if (rc_fence) return rc_fence;                                                        \
+    if (!e->in_capture) {                                                                 \
+      const int rc_dev = device_fence(e, st, {__VA_ARGS__});                              \
+      if (rc_dev) return rc_dev;                                                          \
+    }                                                                                     \
+    e->last_flags = 0;                                                                    \
   } while (0)
 
 extern "C" {
@@ -753,12 +818,40 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     for (int a = 1; a < 3; ++a) e->ae[a].enc[0].in_bf16 = 1;
   }
   e->Moff = add_param(e, "mod.M", {cfg->K, e->D});
+  // split-K / reduction scratch: the largest consumer among wgrads, KHM and the recon partials
+  size_t pf = khm_workspace_floats(B, e->D, cfg->K);
+  {
+    const size_t rp = recon_partials_floats(B * cfg->C, cfg->P);
+    if (rp > pf) pf = rp;
+    for (int a = 0; a < 3; ++a)
+      for (int i = 0; i < 6; ++i) {
+        size_t w = conv_workspace_floats(e->ae[a].enc[i]);
+        if (w > pf) pf = w;
+        w = conv_workspace_floats(e->ae[a].dec[i]);
+        if (w > pf) pf = w;
+      }
+    // dense layers: largest of the fc1 / fc3 problems
+    const int Lm = cfg->L > cfg->Lt ? cfg->L : cfg->Lt;
+    size_t w = igemm_workspace_floats(B, 768, Lm + e->hdim, 1);
+    if (w > pf) pf = w;
+    w = igemm_workspace_floats(Lm, 768 + e->hdim, B, 1);
+    if (w > pf) pf = w;
+    w = igemm_workspace_floats(768, Lm + e->hdim, B, 1);
+    if (w > pf) pf = w;
+    w = igemm_workspace_floats(B, 768 + e->hdim, Lm, 1);
+    if (w > pf) pf = w;
+  }
+  e->part_floats = pf;
+  // ---- the forward prefix: the activations above, then ...
   e->o_scales = take(cur, 8);
   e->o_uvh = take(cur, (size_t)B * e->hdim);
   e->o_Mu = take(cur, (size_t)B * e->D);
-  e->o_gMu = take(cur, (size_t)B * e->D);
   e->o_row = take(cur, (size_t)B * img);
   e->o_col = take(cur, (size_t)B * img);
+  e->o_fpart = take(cur, 4 * pf);  // split-K scratch of the forward launches (two pair-sized slots)
+  e->fwd_floats = cur;
+  // ---- backward / loss side
+  e->o_gMu = take(cur, (size_t)B * e->D);
   e->o_gx1p = take(cur, (size_t)B * img);
   e->o_gx2 = take(cur, (size_t)B * img);
   e->o_gx3c = take(cur, (size_t)B * img);
@@ -797,29 +890,6 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->o_latent_ws = take(cur, e->latent_ws_floats);
   e->latent_event = nullptr;
   e->recon_ready = false;
-  // split-K / reduction scratch: the largest consumer among wgrads, KHM and the recon partials
-  size_t pf = khm_workspace_floats(B, e->D, cfg->K);
-  const size_t rp = recon_partials_floats(B * cfg->C, cfg->P);
-  if (rp > pf) pf = rp;
-  for (int a = 0; a < 3; ++a)
-    for (int i = 0; i < 6; ++i) {
-      size_t w = conv_workspace_floats(e->ae[a].enc[i]);
-      if (w > pf) pf = w;
-      w = conv_workspace_floats(e->ae[a].dec[i]);
-      if (w > pf) pf = w;
-    }
-  {  // dense layers: largest of the fc1 / fc3 problems
-    const int Lm = cfg->L > cfg->Lt ? cfg->L : cfg->Lt;
-    size_t w = igemm_workspace_floats(B, 768, Lm + e->hdim, 1);
-    if (w > pf) pf = w;
-    w = igemm_workspace_floats(Lm, 768 + e->hdim, B, 1);
-    if (w > pf) pf = w;
-    w = igemm_workspace_floats(768, Lm + e->hdim, B, 1);
-    if (w > pf) pf = w;
-    w = igemm_workspace_floats(B, 768 + e->hdim, Lm, 1);
-    if (w > pf) pf = w;
-  }
-  e->part_floats = pf;
   for (int ln = 0; ln < 3; ++ln) {
     e->lane[ln].o_part = take(cur, pf);
     e->lane[ln].o_wpart = take(cur, pf);
@@ -836,6 +906,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     if (e->device >= 0 && (!e->pair_mode || e->side_wgrad)) {
       bool ok = hipStreamCreateWithFlags(&e->wstream, hipStreamNonBlocking) == hipSuccess;
       ok = ok && hipStreamCreateWithFlags(&e->lstream, hipStreamNonBlocking) == hipSuccess;
+      ok = ok && hipStreamCreateWithFlags(&e->fstream, hipStreamNonBlocking) == hipSuccess;
       {
         const char* v = getenv("LSHM_EVENT_POOL");
         const int n = v ? atoi(v) : 128;
@@ -849,7 +920,8 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   }
   const size_t ngroups = (size_t)(B + cfg->bpb - 1) / cfg->bpb;
   e->o_scal = take(cur, 2 * (16 + ngroups + 3 * LOGCOSH3_BLOCKS));
-  e->ws_floats = cur;
+  e->alt_base = cur;  // second forward prefix (see lshm_engine: fwd_floats)
+  e->ws_floats = cur + e->fwd_floats;
   *out = e;
   return LSHM_OK;
 }
@@ -861,6 +933,7 @@ void lshm_engine_destroy(lshm_engine* e) {
     if (e->cstream) (void)hipStreamDestroy(e->cstream);
     (void)hipStreamDestroy(e->wstream);
     if (e->lstream) (void)hipStreamDestroy(e->lstream);
+    if (e->fstream) (void)hipStreamDestroy(e->fstream);
     for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   }
   delete e;
@@ -913,6 +986,17 @@ int lshm_engine_set_comm(lshm_engine* e, lshm_comm* comm) {
   return LSHM_OK;
 }
 
+int lshm_engine_device(const lshm_engine* e) { return e ? e->device : -1; }
+unsigned lshm_engine_last_flags(const lshm_engine* e) { return e ? e->last_flags : 0u; }
+int lshm_engine_comm_early_bucket(const lshm_engine* e) {
+  return (e && e->comm && e->cstream && e->side_ok && e->side_wgrad && e->pair_mode && e->early_ok) ? 1 : 0;
+}
+int lshm_engine_set_early_bucket(lshm_engine* e, int on) {
+  if (!e) { set_last_error("engine_set_early_bucket: null engine"); return LSHM_ERR_ARG; }
+  e->early_ok = on != 0;
+  return LSHM_OK;
+}
+
 #define ENGINE_CHECK(cond, msg)     \
   do {                              \
     if (!(cond)) {                  \
@@ -927,7 +1011,7 @@ int lshm_engine_forward_backward_ex(lshm_engine* e, const float* params, float* 
   ENGINE_CHECK(e && params && grads && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_backward: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st);
+  ENGINE_ENTER(e, st, params, grads, x, uv, y1, ws, terms);
   e->next_event = 0;
   // the forward below is recomputed either way; only the reconstruction pass can be the one the preceding
   // lshm_engine_multiplier_update_next already made with the same inputs
@@ -951,7 +1035,7 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
   ENGINE_CHECK(e && params && grads && x && y1 && y2 && y3 && terms && ws, "engine_backward_saved: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st);
+  ENGINE_ENTER(e, st, params, grads, x, y1, ws, terms);
   e->next_event = 0;
   const bool recon_done = e->recon_ready;
   e->recon_ready = false;
@@ -960,24 +1044,57 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
   return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st, recon_done);
 }
 
-int lshm_engine_multiplier_update_next(lshm_engine* e, const float* params, const float* x, const float* uv,
-                                       float* y1, float* y2, float* y3, float* ws, size_t wsf, lshm_stream_t s) {
+int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, const float* x, const float* uv,
+                                          float* y1, float* y2, float* y3, float* ws, size_t wsf, unsigned flags,
+                                          lshm_stream_t s) {
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update_next: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st);
+  ENGINE_ENTER(e, st, params, x, uv, y1, ws);
   e->next_event = 0;
   e->recon_ready = false;
-  int rc = three_forward(e, params, x, uv, ws, st);
-  if (rc) return rc;
   const lshm_step_config& c = e->cfg;
   const double world = c.world > 0 ? c.world : 1;
-  rc = multiplier_update_recon(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3, c.rho,
-                               c.B * c.C, c.P, reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
-                               ws + e->o_gx2, ws + e->o_gx3c, ws + e->lane[0].o_part, st, (float)(1.0 / world), e->bf);
+  // The no-grad forward that closes this iteration (src/kharmonic_lofar.py:187-196) and the closure forward that
+  // opens the next one (:135-150) both depend on the updated parameters and on nothing else: with
+  // LSHM_NEXT_CONCURRENT_FORWARD they are two chains on two streams, each with its own copy of the forward
+  // buffers.  The reconstruction pass (multiplier update + the next closure's terms) follows the no-grad forward
+  // on its stream; the caller's stream resumes when both are done.
+  const bool concurrent = (flags & LSHM_NEXT_CONCURRENT_FORWARD) && e->side_ok && e->fstream && !e->in_capture &&
+                          e->pair_mode;
+  hipStream_t fst = concurrent ? e->fstream : st;
+  float* fws = concurrent ? ws + e->alt_base : ws;
+  if (concurrent) {
+    hipEvent_t ev = e->take_event();
+    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(fst, ev, 0) != hipSuccess) {
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
+  }
+  int rc = three_forward(e, params, x, uv, fws, fst);
   if (rc) return rc;
+  rc = multiplier_update_recon(x, fws + e->ae[0].out, fws + e->ae[1].out, fws + e->ae[2].out, y1, y2, y3, c.rho,
+                               c.B * c.C, c.P, reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
+                               ws + e->o_gx2, ws + e->o_gx3c, ws + e->lane[0].o_part, fst, (float)(1.0 / world), e->bf);
+  if (rc) return rc;
+  if (concurrent) {
+    // the next closure's forward: activations saved in the primary buffers; nothing reads the reconstructions of
+    // netT / netF (the pass above took them from the no-grad forward), so their last decoder layer is not run
+    if ((rc = three_forward(e, params, x, uv, ws, st, nullptr, true))) return rc;
+    hipEvent_t evj = e->take_event();
+    if (hipEventRecord(evj, fst) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
+      set_last_error("engine: stream join failed");
+      return LSHM_ERR_ARG;
+    }
+    e->last_flags |= LSHM_ENGINE_USED_CONCURRENT_FORWARD;
+  }
   e->recon_ready = true;
   return LSHM_OK;
+}
+
+int lshm_engine_multiplier_update_next(lshm_engine* e, const float* params, const float* x, const float* uv,
+                                       float* y1, float* y2, float* y3, float* ws, size_t wsf, lshm_stream_t s) {
+  return lshm_engine_multiplier_update_next_ex(e, params, x, uv, y1, y2, y3, ws, wsf, 0u, s);
 }
 
 int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x, const float* uv,
@@ -986,7 +1103,7 @@ int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_loss: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st);
+  ENGINE_ENTER(e, st, params, x, uv, y1, ws, terms);
   e->next_event = 0;
   int rc = forward_with_latent_losses(e, params, nullptr, x, uv, ws, st);
   if (rc) return rc;
@@ -999,7 +1116,7 @@ int lshm_engine_multiplier_update(lshm_engine* e, const float* params, const flo
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st);
+  ENGINE_ENTER(e, st, params, x, uv, y1, ws);
   e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;
@@ -1013,7 +1130,7 @@ int lshm_engine_encode(lshm_engine* e, const float* params, const float* x, cons
   ENGINE_CHECK(e && params && x && uv && ws, "engine_encode: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st);
+  ENGINE_ENTER(e, st, params, x, uv, ws);
   e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;

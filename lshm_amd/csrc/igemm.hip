@@ -852,11 +852,16 @@ static int launch_cfg(const typename P::Params& p0, const typename P::Params* p1
   }
   pp.zper = Z * sp.splits;
   dim3 grid(cdiv(M, BM), cdiv(N, BN), Z * sp.splits * G);
+  // a tile configuration whose LDS image (up to 74 KB for 128-row tiles with 64-deep K chunks) or register
+  // budget does not fit this device is an error code here, not a failed dispatch
+  int rc = t_matrix_bf16 ? kernel_budget_ok(reinterpret_cast<const void*>(&igemm_kernel<P, BM, BN, BK, KW, true>), 256, 0, "igemm tile configuration")
+                         : kernel_budget_ok(reinterpret_cast<const void*>(&igemm_kernel<P, BM, BN, BK, KW, false>), 256, 0, "igemm tile configuration");
+  if (rc) return rc;
   if (t_matrix_bf16)
     hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, KW, true>), grid, dim3(256), 0, st, pp);
   else
     hipLaunchKernelGGL((igemm_kernel<P, BM, BN, BK, KW, false>), grid, dim3(256), 0, st, pp);
-  int rc = check_launch("igemm");
+  rc = check_launch("igemm");
   if (rc || sp.splits == 1) return rc;
   if (defer && Z == 1) {  // leave the slabs where they are; the combine joins the backward's job list
     SumJob J[2];

@@ -687,6 +687,9 @@ __global__ __launch_bounds__(256) void khm_mfma_kernel(
 static size_t khm_mfma_lds_bytes() { return (size_t)(4 * 16 * 64 * 4 + 64 * KHM_MM_XP + 64 * KHM_MM_WP + 64 + 256) * sizeof(float); }
 static bool khm_mfma_ok(int D, int K, long ldx, long lddx, const float* X, const float* dX, const float* M) {
   static const bool off = getenv("LSHM_KHM_MFMA_OFF") != nullptr;
+  // 152 KB of LDS per workgroup: only where the device has it (gfx950: 160 KB); elsewhere the row-split kernel runs
+  const int lds = device_lds_bytes();
+  if (lds > 0 && khm_mfma_lds_bytes() > (size_t)lds) return false;
   return !off && D == 256 && K > 16 && K <= 64 && (ldx % 4) == 0 && (lddx % 4) == 0 &&
          ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(dX) | reinterpret_cast<uintptr_t>(M)) & 15) == 0;
 }
@@ -783,7 +786,7 @@ static int khm_launch(dim3 grid, size_t shmem, hipStream_t st, const float* X, l
   if (shmem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) { set_last_error("khm: cannot raise dynamic LDS limit"); return (int)e; }
+    if (e != hipSuccess) { (void)hipGetLastError(); set_last_error("khm: cannot raise dynamic LDS limit"); return LSHM_ERR_UNSUPPORTED; }
   }
   hipLaunchKernelGGL(kern, grid, dim3(NW * 64), shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale,
                      dX, lddx, acc_dx, partial, lpart);
@@ -799,7 +802,7 @@ static int khm_launch_rowsplit(dim3 grid, hipStream_t st, const float* X, long l
   if (shmem > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    if (e != hipSuccess) { set_last_error("khm: cannot raise dynamic LDS limit"); return (int)e; }
+    if (e != hipSuccess) { (void)hipGetLastError(); set_last_error("khm: cannot raise dynamic LDS limit"); return LSHM_ERR_UNSUPPORTED; }
   }
   hipLaunchKernelGGL(kern, grid, dim3(RS * 64), shmem, st, X, ldx, M, N, D, K, p, pint, eps, wscale, dX, lddx,
                      acc_dx, partial, lpart);
@@ -875,7 +878,7 @@ static int khm_run(const float* X, long ldx, const float* M, int N, int D, int K
     const size_t lds_bytes = khm_mfma_lds_bytes();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds_bytes);
-    if (e != hipSuccess) { set_last_error("khm: cannot raise dynamic LDS limit"); return (int)e; }
+    if (e != hipSuccess) { (void)hipGetLastError(); set_last_error("khm: cannot raise dynamic LDS limit"); return LSHM_ERR_UNSUPPORTED; }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds_bytes, st, X, ldx, M, N, K, p, pint, eps, wscale, dX, lddx, acc_dx,
                        partial, lpart);
     rc = check_launch("khm_mfma");

@@ -49,21 +49,32 @@ class Communicator:
         import ctypes as C
         from . import _lib as L
         self.lib = L.load()
-        if not self.lib.lshm_comm_available():
-            raise RuntimeError("RCCL is not available in this process")
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # Collective-consistent construction: rank 0's status travels WITH the id (a failure in
+        # lshm_comm_unique_id raises on every rank instead of leaving the others inside the broadcast), and the
+        # outcome of lshm_comm_init is MIN-reduced, so either every rank holds a communicator or none does.
         buf = C.create_string_buffer(128)
+        rc0, msg0 = 0, ""
         if self.rank == 0:
-            L.check(self.lib.lshm_comm_unique_id(buf), "comm_unique_id")
-        box = [buf.raw]
+            rc0 = self.lib.lshm_comm_unique_id(buf)
+            if rc0:
+                msg0 = self.lib.lshm_last_error_string().decode("utf-8", "replace")
+        box = [(rc0, msg0, buf.raw)]
         if self.world > 1:
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        rc0, msg0, raw = box[0]
+        if rc0:
+            raise RuntimeError(f"lshm_amd: comm_unique_id failed on rank 0 (code {rc0}): {msg0}")
         self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
         h = C.c_void_p()
         with L.on_device(self.device):
-            L.check(self.lib.lshm_comm_init(box[0], self.rank, self.world, C.byref(h)), "comm_init")
-        self.handle = h
+            rc = self.lib.lshm_comm_init(raw, self.rank, self.world, C.byref(h))
+        msg = self.lib.lshm_last_error_string().decode("utf-8", "replace") if rc else ""
+        self.handle = h if rc == 0 else None
+        if not agree(rc == 0, group if self.world > 1 else None, self.world):
+            self.close()
+            raise RuntimeError("lshm_amd: comm_init failed" + (f" (code {rc}): {msg}" if rc else " on another rank"))
 
     def allreduce_flat(self, buf: Optional[torch.Tensor], tail: Optional[torch.Tensor] = None):
         """In place SUM over ranks of a float32 buffer and / or a float64 tail, one fused launch."""
@@ -83,6 +94,20 @@ class Communicator:
             self.close()
         except Exception:
             pass
+
+
+def agree(ok: bool, group=None, world: Optional[int] = None) -> bool:
+    """True iff `ok` on EVERY rank of the group (MIN all-reduce of a flag; CPU tensor for gloo, the current
+    device's for nccl).  Used wherever ranks must take the same branch: which collective path a trainer uses,
+    whether a communicator exists, whether the early gradient bucket is sent."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world <= 1 or not dist.is_initialized():
+        return bool(ok)
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item())
 
 
 def allreduce_closure(grads: torch.Tensor, terms: torch.Tensor, group=None) -> None:

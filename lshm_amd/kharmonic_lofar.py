@@ -78,6 +78,12 @@ class TrainConfig:
     # the same seven image-sized arrays; True (default): they share one pass (the closure forward itself is
     # still recomputed, as upstream does) -- identical results, one 0.67 GB pass less per iteration.
     share_recon_pass: bool = True
+    # After the optimiser step the no-grad forward that closes iteration k (:187-196) and the closure forward
+    # that opens iteration k+1 (:135-150) depend on the updated parameters alone.  True (default): they are
+    # issued together, as two chains on two HIP streams with separate activation buffers
+    # (lshm_engine_multiplier_update_next_ex, LSHM_NEXT_CONCURRENT_FORWARD); both are computed, as upstream
+    # computes both -- neither waits for the other.  Same trajectory bit for bit.  False: one after the other.
+    overlap_forwards: bool = True
 
 
 class KHarmonicTrainer:
@@ -153,29 +159,50 @@ class KHarmonicTrainer:
         self.x = torch.zeros(img, device=dev)
         self.uv = torch.zeros((self.B, 2), device=dev)
         self.y = [torch.zeros(self.x.numel(), device=dev) for _ in range(3)]
-        # data parallelism: with an nccl (= RCCL) group the collectives run inside the engine's closure, on its
-        # own streams (lshm_engine_set_comm); other backends (gloo in the CPU-rehearsal tests) and
-        # LSHM_DP_TORCH=1 go through torch.distributed after the closure
+        # Data parallelism.  Default: torch.distributed all-reduces after the closure (backend nccl == RCCL;
+        # gloo in the CPU-rehearsal tests).  LSHM_DP_ENGINE=1: the collectives run inside the engine's closure on
+        # its own streams (lshm_engine_set_comm: early bucket for netT / netF beside the 2-D backward) -- opt-in
+        # until that path has run on a real multi-GPU node (it is rehearsed with two ranks on one GPU through a
+        # host-shared-memory stand-in for RCCL, tests/test_gpu_dp.py).
         self._comm = None
-        if self.world > 1 and os.environ.get("LSHM_DP_TORCH") != "1":
-            import torch.distributed as dist
-            if dist.get_backend(process_group) == "nccl" and self.lib.lshm_comm_available():
-                from .dist import Communicator
-                try:
-                    self._comm = Communicator(process_group, self.device)
-                    with L.on_device(self.device):
-                        L.check(self.lib.lshm_engine_set_comm(self._h, self._comm.handle), "engine_set_comm")
-                except Exception as e:  # still RCCL, through torch.distributed after the closure (same sums)
-                    import sys
-                    print(f"lshm_amd: engine-side RCCL communicator unavailable ({e}); using torch.distributed "
-                          "all-reduces after the closure", file=sys.stderr)
-                    if self._comm is not None:
-                        self._comm.close()
-                    self._comm = None
+        if self.world > 1 and os.environ.get("LSHM_DP_ENGINE") == "1" and os.environ.get("LSHM_DP_TORCH") != "1":
+            self._attach_engine_comm(process_group)
         self._graph = None
+        self._prefetched = False     # the saved forward is the next closure's own (overlap_forwards), not a re-used one
         self._saved_forward = False  # the workspace holds the forward of the current params / x / uv
         self._recon_ready = False    # ... and the reconstruction terms of the next closure (share_recon_pass)
         self._opt_generation = 0     # bumped by set_train_groups: optimisers built before it are stale
+
+    def _attach_engine_comm(self, process_group):
+        """Engine-side communicator, all ranks or none: a rank whose lshm_comm_init / lshm_engine_set_comm failed
+        while the others succeeded would issue different collectives from them (torch.distributed after the closure
+        against RCCL inside it) and the job would hang.  Every rank therefore reports success, the flags are
+        MIN-reduced over the group, and one failure detaches the communicator everywhere.  The early bucket is
+        agreed the same way (lshm_engine_comm_early_bucket / lshm_engine_set_early_bucket)."""
+        import sys
+        from .dist import Communicator, agree
+
+        def fallback(why):
+            print(f"lshm_amd: engine-side communicator unavailable ({why}); every rank uses torch.distributed "
+                  "all-reduces after the closure", file=sys.stderr)
+
+        # every step below ends in the same decision on every rank before the next collective is issued
+        if not agree(bool(self.lib.lshm_comm_available()), process_group):
+            return fallback("RCCL is not available on at least one rank")
+        try:
+            comm = Communicator(process_group, self.device)  # raises on every rank or on none (see dist.Communicator)
+        except RuntimeError as e:
+            return fallback(e)
+        with L.on_device(self.device):
+            rc = self.lib.lshm_engine_set_comm(self._h, comm.handle)
+        if not agree(rc == 0, process_group):
+            with L.on_device(self.device):
+                self.lib.lshm_engine_set_comm(self._h, None)
+            comm.close()
+            return fallback("lshm_engine_set_comm failed on at least one rank")
+        self._comm = comm
+        early = agree(bool(self.lib.lshm_engine_comm_early_bucket(self._h)), process_group)
+        L.check(self.lib.lshm_engine_set_early_bucket(self._h, int(early)), "engine_set_early_bucket")
 
     def _stream(self):
         return L.stream(self.device)
@@ -238,8 +265,7 @@ class KHarmonicTrainer:
 
     def load_state_dicts(self, net=None, netT=None, netF=None, mod=None):
         """Accepts the reference's four state_dicts (keys 'conv0.weight' ... / 'M')."""
-        self._saved_forward = False
-        self._recon_ready = False
+        self.invalidate_forward()
         with torch.no_grad():
             for prefix, sd in (("net", net), ("netT", netT), ("netF", netF), ("mod", mod)):
                 if sd is None:
@@ -290,20 +316,52 @@ class KHarmonicTrainer:
         self.uv.copy_(uv)
         for t in self.y:
             t.zero_()
-        self._saved_forward = False
-        self._recon_ready = False
+        self.invalidate_forward()
+
+    def prefetch_minibatch(self, x_host: torch.Tensor, uv_host: torch.Tensor):
+        """Upload the NEXT minibatch (src/kharmonic_lofar.py:118 hands over host tensors) while the ADMM iterations
+        of the current one run: an asynchronous copy from pinned host memory into a staging pair, on a copy
+        stream of its own.  swap_in_minibatch() makes it current."""
+        if tuple(x_host.shape) != tuple(self.x.shape) or tuple(uv_host.shape) != tuple(self.uv.shape):
+            raise RuntimeError(f"expected x {tuple(self.x.shape)} and uv {tuple(self.uv.shape)}")
+        with L.on_device(self.device):
+            if getattr(self, "_copy_stream", None) is None:
+                self._copy_stream = torch.cuda.Stream(self.device)
+                self._stage = (torch.empty_like(self.x), torch.empty_like(self.uv))
+                self._staged = None
+            # the staging pair may still be read by iterations enqueued before the last swap
+            self._copy_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._copy_stream):
+                self._stage[0].copy_(x_host, non_blocking=True)
+                self._stage[1].copy_(uv_host, non_blocking=True)
+                self._staged = torch.cuda.Event()
+                self._staged.record(self._copy_stream)
+
+    def swap_in_minibatch(self):
+        """Start the minibatch uploaded by prefetch_minibatch: the compute stream waits for the copy (no host
+        synchronisation), the staging pair and the current pair trade places, multipliers reset to zero (:128-130)."""
+        if getattr(self, "_staged", None) is None:
+            raise RuntimeError("swap_in_minibatch: nothing was prefetched")
+        with L.on_device(self.device):
+            torch.cuda.current_stream(self.device).wait_event(self._staged)
+            self._staged = None
+            (self.x, self.uv), self._stage = self._stage, (self.x, self.uv)
+            for t in self.y:
+                t.zero_()
+        self.invalidate_forward()
 
     def invalidate_forward(self):
         """Call after changing parameters, inputs or multipliers behind the trainer's back (e.g. through
         ``view``): the next iteration recomputes its closure forward and its reconstruction terms."""
         self._saved_forward = False
         self._recon_ready = False
+        self._prefetched = False
 
     # ------------------------------------------------------------------ one iteration
     def _closure_fwd_bwd(self):
         P = L.ptr
         with L.on_device(self.device):
-            if self.cfg.reuse_forward and self._saved_forward and self._graph is None:
+            if (self.cfg.reuse_forward or self._prefetched) and self._saved_forward and self._graph is None:
                 L.check(self.lib.lshm_engine_backward_saved(
                     self._h, P(self.params), P(self.grads), P(self.x), P(self.y[0]), P(self.y[1]), P(self.y[2]),
                     P(self.terms), P(self.ws), self.ws_floats, self._stream()), "engine_backward_saved")
@@ -315,6 +373,7 @@ class KHarmonicTrainer:
                     "engine_forward_backward")
             self._saved_forward = False  # whatever follows (optimiser, line search) moves the parameters
             self._recon_ready = False
+            self._prefetched = False
             if self.world > 1 and self._comm is None:
                 from .dist import allreduce_closure
                 allreduce_closure(self.grads, self.terms, self.pg)
@@ -345,12 +404,23 @@ class KHarmonicTrainer:
         if prepare_next is None:
             prepare_next = (self.cfg.share_recon_pass or self.cfg.reuse_forward)
         prepare_next = bool(prepare_next) and self._graph is None
-        fn = self.lib.lshm_engine_multiplier_update_next if prepare_next else self.lib.lshm_engine_multiplier_update
+        # two forwards side by side (cfg.overlap_forwards): only together with the shared reconstruction pass, and
+        # pointless when the next closure re-uses this call's forward anyway (cfg.reuse_forward)
+        concurrent = prepare_next and self.cfg.overlap_forwards and not self.cfg.reuse_forward
         with L.on_device(self.device):
-            L.check(fn(self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
-                       P(self.ws), self.ws_floats, self._stream()), "engine_multiplier_update")
+            if prepare_next:
+                L.check(self.lib.lshm_engine_multiplier_update_next_ex(
+                    self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+                    P(self.ws), self.ws_floats, L.NEXT_CONCURRENT_FORWARD if concurrent else 0, self._stream()),
+                    "engine_multiplier_update_next")
+                concurrent = concurrent and bool(self.lib.lshm_engine_last_flags(self._h) & L.ENGINE_USED_CONCURRENT_FORWARD)
+            else:
+                L.check(self.lib.lshm_engine_multiplier_update(
+                    self._h, P(self.params), P(self.x), P(self.uv), P(self.y[0]), P(self.y[1]), P(self.y[2]),
+                    P(self.ws), self.ws_floats, self._stream()), "engine_multiplier_update")
         self._saved_forward = True  # forward of the parameters the next closure will see
         self._recon_ready = prepare_next
+        self._prefetched = concurrent  # ... computed for it on purpose, beside the no-grad forward
 
     def _step_impl(self):
         self._closure_fwd_bwd()
@@ -418,8 +488,7 @@ class KHarmonicTrainer:
         if torch.is_grad_enabled():
             self._closure_fwd_bwd()
         else:
-            self._saved_forward = False  # trial point of the line search
-            self._recon_ready = False
+            self.invalidate_forward()  # trial point of the line search
             P = L.ptr
             with L.on_device(self.device):
                 L.check(self.lib.lshm_engine_forward_loss(
@@ -459,7 +528,7 @@ class KHarmonicTrainer:
     # ------------------------------------------------------------------ inference helper
     def encode(self, want_recon: bool = False):
         """Latents Mu = [mu | muT | muF] (B, L+2Lt) for the current x, uv (no grad)."""
-        self._saved_forward = False  # conservative: the encode pass re-uses the activation workspace
+        self.invalidate_forward()  # conservative: the encode pass re-uses the activation workspace
         c = self.cfg
         Mu = torch.empty((self.B, c.L + 2 * c.Lt), device=self.device)
         outs = [torch.empty_like(self.x) for _ in range(3)] if want_recon else [None] * 3

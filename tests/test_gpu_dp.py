@@ -33,9 +33,18 @@ def _inputs():
     return params, M, x, uv
 
 
-def _rank_main(rank, world, port, q, lbfgs):
+FAKE_RCCL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "fake_rccl", "libfake_rccl.so")
+
+
+def _rank_main(rank, world, port, q, lbfgs, engine_comm=False, fail_rank=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if engine_comm:
+        # the engine-attached collective path (lshm_engine_set_comm), RCCL's entry points bound from the
+        # host-shared-memory stand-in: RCCL itself refuses two ranks on one device
+        os.environ.update(LSHM_DP_ENGINE="1", LSHM_RCCL_LIB=FAKE_RCCL)
+        if fail_rank == rank:
+            os.environ["LSHM_RCCL_LIB"] = "/nonexistent/librccl.so"  # this rank cannot build a communicator
     import torch.distributed as dist
     from lshm_amd import KHarmonicTrainer, TrainConfig
     from lshm_amd import dist as D
@@ -46,7 +55,10 @@ def _rank_main(rank, world, port, q, lbfgs):
     sl = slice(b0 * BPB, b1 * BPB)
     tr = KHarmonicTrainer(TrainConfig(Kc=K), batch=(b1 - b0) * BPB, batch_per_bline=BPB, default_batch=b1 - b0,
                           device="cuda:0", process_group=dist.group.WORLD)
-    assert tr.world == world and tr._comm is None  # gloo: the collectives go through torch.distributed
+    if engine_comm and fail_rank is None:
+        assert tr._comm is not None and tr.lib.lshm_engine_comm_early_bucket(tr._h) == 1
+    else:  # the default (and the all-ranks fallback when one rank has no communicator): torch.distributed after the closure
+        assert tr.world == world and tr._comm is None
     tr.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
     tr.new_minibatch(x[sl].cuda(), uv[sl].cuda())
     if lbfgs:
@@ -57,6 +69,11 @@ def _rank_main(rank, world, port, q, lbfgs):
             tr.step()
     torch.cuda.synchronize()
     terms = tr.read_terms()
+    if engine_comm and fail_rank is None and not lbfgs:
+        # the last closure sent the netT / netF gradients as the early bucket
+        tr.closure_only()
+        assert tr.lib.lshm_engine_last_flags(tr._h) & 1
+        torch.cuda.synchronize()
     q.put((rank, tr.params.cpu().numpy(), [terms[k] for k in ("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica",
                                                               "total", "nonfinite")],
            [t.cpu().numpy() for t in tr.y]))
@@ -64,11 +81,11 @@ def _rank_main(rank, world, port, q, lbfgs):
     dist.destroy_process_group()
 
 
-def _run_two_ranks(lbfgs):
+def _run_two_ranks(lbfgs, engine_comm=False, fail_rank=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, lbfgs)) for r in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q, lbfgs, engine_comm, fail_rank)) for r in range(2)]
     for p in procs:
         p.start()
     got = sorted((q.get(timeout=540) for _ in range(2)), key=lambda t: t[0])
@@ -94,12 +111,22 @@ def _single_process(lbfgs):
 
 
 @pytest.mark.timeout(900)
+@pytest.mark.parametrize("path", ["torch", "engine", "engine-one-rank-fails"])
 @pytest.mark.parametrize("lbfgs", [False, True], ids=["adam", "lbfgs"])
-def test_two_ranks_on_one_gpu_equal_the_global_batch(lbfgs):
+def test_two_ranks_on_one_gpu_equal_the_global_batch(lbfgs, path):
     """engine -> all-reduce -> optimiser on two ranks == one process on the global batch: replicated parameters
     identical across ranks (bitwise) and equal to the global-batch parameters to 2e-5; the logged terms are the
-    global ones on every rank; each rank's multipliers are its slice of the global ones."""
-    got = _run_two_ranks(lbfgs)
+    global ones on every rank; each rank's multipliers are its slice of the global ones.
+    path "torch": the collectives go through torch.distributed after the closure (gloo here, RCCL on a node).
+    path "engine": through lshm_engine_set_comm -- the early netT / netF bucket on its own stream beside the 2-D
+    backward, the closing group, the loss terms of the gradient-free closures -- with the RCCL entry points
+    bound from tests/fake_rccl (host shared memory).  path "engine-one-rank-fails": rank 1 cannot build its
+    communicator; the ranks must agree to fall back together instead of issuing mismatched collectives."""
+    if path != "torch" and not os.path.exists(FAKE_RCCL):
+        pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (make testlibs)")
+    if path == "engine-one-rank-fails" and lbfgs:
+        pytest.skip("the fallback decision is made at construction: one optimiser suffices")
+    got = _run_two_ranks(lbfgs, engine_comm=path != "torch", fail_rank=1 if path == "engine-one-rank-fails" else None)
     ref = _single_process(lbfgs)
     p0, p1 = torch.from_numpy(got[0][1]), torch.from_numpy(got[1][1])
     assert torch.equal(p0, p1)
@@ -180,4 +207,46 @@ def test_engine_with_attached_communicator_world_one():
     comm = Communicator(None, torch.device("cuda:0"))
     assert lib.lshm_engine_set_comm(h, comm.handle) != 0
     lib.lshm_engine_destroy(h)
+    comm.close()
+
+
+def test_captured_closure_with_communicator_sends_no_early_bucket():
+    """The early bucket forks a stream off the forked weight-gradient stream; ending a capture of that topology
+    crashes hipStreamEndCapture (ROCm 7.2, seen in round 2 with the same nesting).  A captured call therefore
+    keeps every collective on the capturing stream: eager closures report the early bucket, a captured one does
+    not, and its replay gives the eager gradients."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig, _lib
+    from lshm_amd.dist import Communicator
+    lib = _lib.load()
+    if not lib.lshm_comm_available():
+        pytest.skip("no RCCL in this process")
+    params, M, x, uv = _inputs()
+    tr = KHarmonicTrainer(TrainConfig(Kc=K), batch=B, batch_per_bline=BPB, default_batch=B // BPB, device=DEV)
+    comm = Communicator(None, torch.device("cuda:0"))
+    _lib.check(lib.lshm_engine_set_comm(tr._h, comm.handle))
+    assert lib.lshm_engine_comm_early_bucket(tr._h) == 1
+    tr.load_state_dicts(params["net"], params["netT"], params["netF"], {"M": M})
+    tr.new_minibatch(x.to(DEV), uv.to(DEV))
+    tr.closure_only()
+    assert lib.lshm_engine_last_flags(tr._h) & _lib.ENGINE_USED_EARLY_BUCKET
+    torch.cuda.synchronize()
+    eager = tr.grads.clone()
+    # the agreed switch turns it off for eager calls too
+    _lib.check(lib.lshm_engine_set_early_bucket(tr._h, 0))
+    tr.closure_only()
+    assert not (lib.lshm_engine_last_flags(tr._h) & _lib.ENGINE_USED_EARLY_BUCKET)
+    torch.cuda.synchronize()
+    assert torch.equal(tr.grads, eager)
+    _lib.check(lib.lshm_engine_set_early_bucket(tr._h, 1))
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        tr.closure_only()
+    assert not (lib.lshm_engine_last_flags(tr._h) & _lib.ENGINE_USED_EARLY_BUCKET)
+    tr.grads.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.grads, eager)
+    _lib.check(lib.lshm_engine_set_comm(tr._h, None))
     comm.close()

@@ -1,0 +1,146 @@
+"""The implicit-GEMM policies at the layer shapes of BASELINE.json's configuration (B = 256), not the B = 2 shapes of
+the golden fixtures.  Operands are fetched with raw buffer loads whose out-of-range offsets read as ZERO, so a wrong
+edge predicate at full size would produce a plausible number instead of a fault: every policy is therefore compared
+here against an fp64 evaluation of the same layer (torch CPU conv; the layer math of src/lofar_models.py:31-57,
+115-142) on whole samples that include the first and the last batch entry -- first / last rows of the GEMM, first /
+last k-block, the padded border -- with the tile table shipped for these shapes in effect."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+B = 256
+CH = (4, 8, 12, 24, 48, 96, 192)
+SAMPLES = (0, 1, 127, 254, 255)
+
+
+def _shapes(kind, i):
+    nd2 = kind < 2
+    tr = kind in (1, 3)
+    cin, cout = (CH[6 - i], CH[5 - i]) if tr else (CH[i], CH[i + 1])
+    if nd2:
+        hw = (2 << i) if tr else (128 >> i)
+        ishape = (B, cin, hw, hw)
+    else:
+        L = (4 << (2 * i)) if tr else (16384 >> (2 * i))
+        ishape = (B, cin, L)
+    wshape = ((cin, cout) if tr else (cout, cin)) + ((4, 4) if nd2 else (4,))
+    return ishape, wshape, cin, cout
+
+
+def _ref_layer(kind, x, w, b):
+    if kind == 0:
+        return TF.conv2d(x, w, b, stride=2, padding=1)
+    if kind == 1:
+        return TF.conv_transpose2d(x, w, b, stride=2, padding=1)
+    if kind == 2:
+        return TF.conv1d(x, w, b, stride=4, padding=1)
+    return TF.conv_transpose1d(x, w, b, stride=4, padding=0)
+
+
+@pytest.mark.parametrize("i", [2, 3, 4, 5])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3], ids=["conv2d", "tconv2d", "conv1d", "tconv1d"])
+def test_gemm_shaped_layers_at_full_batch(kind, i):
+    """Forward (bias + ELU), data gradient with the ELU' multiply of a saved activation, weight and bias gradient of
+    conv2-5 / tconv0-3 (decoder index i <-> 5 - i counted from the output) at B = 256."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    if kind in (1, 3):
+        i = 5 - i  # tconv0..3 are the GEMM-shaped transposed layers
+    ishape, wshape, cin, cout = _shapes(kind, i)
+    g = torch.Generator().manual_seed(100 * kind + i)
+    x = torch.randn(ishape, generator=g)
+    fan = (cout if kind in (1, 3) else cin) * (16 if kind < 2 else 4)
+    w = torch.randn(wshape, generator=g) * (3.0 / fan) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    Hin, Win = (ishape[2], ishape[3]) if kind < 2 else (1, ishape[2])
+    nws = lib.lshm_conv_workspace_floats(kind, B, cin, cout, Hin, Win)
+    ws = torch.empty(max(nws, 1), device=DEV)
+    st = L.stream()
+    yref = TF.elu(_ref_layer(kind, x[list(SAMPLES)].double(), w.double(), b.double()))
+    y = torch.empty((B,) + tuple(yref.shape[1:]), device=DEV)
+    L.check(lib.lshm_conv_fwd(kind, L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(y), B, cin, cout, Hin, Win, 0, 0, 1, L.ptr(ws),
+                              nws, st), "conv_fwd")
+    assert rel_err(y[list(SAMPLES)], yref) < 2e-5
+    # data gradient, multiplied by ELU'(saved input) as inside the backward pass (the saved input is an ELU output)
+    dz = torch.randn(y.shape, generator=g)
+    saved = TF.elu(torch.randn(ishape, generator=g))
+    dzd, savedd = dz.to(DEV), saved.to(DEV)
+    dx = torch.empty(ishape, device=DEV)
+    L.check(lib.lshm_conv_dgrad(kind, L.ptr(dzd), L.ptr(wd), L.ptr(dx), L.ptr(savedd), B, cin, cout, Hin, Win, 0, 0,
+                                L.ptr(ws), nws, st), "conv_dgrad")
+    xs = x[list(SAMPLES)].double().requires_grad_(True)
+    _ref_layer(kind, xs, w.double(), None).backward(dz[list(SAMPLES)].double())
+    sv = saved[list(SAMPLES)].double()
+    dxref = xs.grad * torch.where(sv > 0, torch.ones_like(sv), sv + 1.0)
+    assert rel_err(dx[list(SAMPLES)], dxref) < 5e-5
+    # weight / bias gradient: a sum over the WHOLE batch -- fp64 on the CPU over all 256 samples
+    dw, db = torch.empty(wshape, device=DEV), torch.empty(cout, device=DEV)
+    L.check(lib.lshm_conv_wgrad(kind, L.ptr(xd), L.ptr(dzd), L.ptr(dw), L.ptr(db), B, cin, cout, Hin, Win, 0, 0, L.ptr(ws),
+                                nws, 0, st), "conv_wgrad")
+    wref = w.double().requires_grad_(True)
+    bref = b.double().requires_grad_(True)
+    _ref_layer(kind, x.double(), wref, bref).backward(dz.double())
+    assert rel_err(dw, wref.grad) < 1e-4
+    assert rel_err(db, bref.grad) < 1e-4
+
+
+@pytest.mark.parametrize("i", [2, 3, 4, 5])
+@pytest.mark.parametrize("kind", [2, 3], ids=["conv1d", "tconv1d"])
+def test_paired_1d_launches_at_full_batch(kind, i):
+    """netT and netF share every launch of their GEMM-shaped layers (grid.z carries the problem): both halves of a
+    paired forward at B = 256 against fp64."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    if kind == 3:
+        i = 5 - i
+    ishape, wshape, cin, cout = _shapes(kind, i)
+    g = torch.Generator().manual_seed(7 + 10 * kind + i)
+    xs = [torch.randn(ishape, generator=g) for _ in range(2)]
+    fan = (cout if kind == 3 else cin) * 4
+    wsx = [torch.randn(wshape, generator=g) * (3.0 / fan) ** 0.5 for _ in range(2)]
+    bs = [torch.randn(cout, generator=g) * 0.1 for _ in range(2)]
+    nws = lib.lshm_conv_workspace_floats(kind, B, cin, cout, 1, ishape[2])
+    ws = torch.empty(max(2 * nws, 1), device=DEV)
+    refs = [TF.elu(_ref_layer(kind, xs[q][list(SAMPLES)].double(), wsx[q].double(), bs[q].double())) for q in range(2)]
+    d = [t.to(DEV) for t in xs + wsx + bs]
+    ys = [torch.empty((B,) + tuple(refs[0].shape[1:]), device=DEV) for _ in range(2)]
+    L.check(lib.lshm_conv_fwd_pair(kind, L.ptr(d[0]), L.ptr(d[2]), L.ptr(d[4]), L.ptr(ys[0]), L.ptr(d[1]), L.ptr(d[3]),
+                                   L.ptr(d[5]), L.ptr(ys[1]), B, cin, cout, 1, ishape[2], 0, 0, 1, L.ptr(ws), 2 * nws,
+                                   L.stream()), "conv_fwd_pair")
+    for q in range(2):
+        assert rel_err(ys[q][list(SAMPLES)], refs[q]) < 2e-5
+
+
+@pytest.mark.parametrize("K,N,act", [(784, 224, 1), (224, 224, 1), (240, 768, 0), (784, 16, 1), (32, 768, 0)])
+def test_dense_layers_at_full_batch(K, N, act):
+    """The four strided-GEMM policies (forward, data gradient with addend + ELU', weight gradient) at B = 256 and the
+    dense-layer shapes of the three autoencoders (fc1, fc2in / fc2out, fc3), every row compared."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(K + N)
+    x = torch.randn(B, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g) * 0.1
+    dz = torch.randn(B, N, generator=g)
+    saved = TF.elu(torch.randn(B, K, generator=g))
+    xd, wd, bd, dzd, sd = (t.to(DEV) for t in (x, w, b, dz, saved))
+    nws = lib.lshm_linear_workspace_floats(B, K, N)
+    ws = torch.empty(nws, device=DEV)
+    st = L.stream()
+    y = torch.empty(B, N, device=DEV)
+    L.check(lib.lshm_linear_fwd(L.ptr(xd), K, L.ptr(wd), L.ptr(bd), L.ptr(y), N, B, K, N, act, L.ptr(ws), nws, st))
+    yref = x.double() @ w.double().t() + b.double()
+    assert rel_err(y, TF.elu(yref) if act else yref) < 2e-5
+    dx = torch.empty(B, K, device=DEV)
+    L.check(lib.lshm_linear_dgrad(L.ptr(dzd), N, L.ptr(wd), L.ptr(dx), K, L.ptr(sd), K, B, K, N, L.ptr(ws), nws, st))
+    sv = saved.double()
+    assert rel_err(dx, (dz.double() @ w.double()) * torch.where(sv > 0, torch.ones_like(sv), sv + 1.0)) < 5e-5
+    dw, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    L.check(lib.lshm_linear_wgrad(L.ptr(xd), K, L.ptr(dzd), N, L.ptr(dw), L.ptr(db), B, K, N, L.ptr(ws), nws, st))
+    assert rel_err(dw, dz.double().t() @ x.double()) < 5e-5
+    assert rel_err(db, dz.double().sum(0)) < 5e-5

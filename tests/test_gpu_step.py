@@ -774,3 +774,112 @@ def test_bf16_storage_step_vs_fp32_oracle():
     for n, rf in zip(("loss0", "loss1", "loss2", "loss3", "kdist", "aug", "sim", "rica"), ref_terms):
         assert abs(t[n] - rf) <= 2e-2 * abs(rf) + 1e-7, n
     assert t["nonfinite"] == 0.0
+
+
+@pytest.mark.parametrize("batch", [4, 256])
+def test_overlapped_forwards_are_bitwise_the_same_trajectory(batch):
+    """TrainConfig.overlap_forwards (default): the no-grad forward that closes iteration k and the closure forward
+    that opens iteration k+1 run side by side on two streams with separate activation buffers
+    (LSHM_NEXT_CONCURRENT_FORWARD).  Parameters, multipliers, Adam moments and logged terms must be bit for bit
+    those of the one-after-the-other schedule -- across a new minibatch, a parameter reload and an LBFGS step."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig, _lib
+    out = []
+    for overlap in (False, True):
+        tr = KHarmonicTrainer(TrainConfig(Kc=5, overlap_forwards=overlap), batch=batch, batch_per_bline=2,
+                              default_batch=batch // 2, device=DEV)
+        tr.init_parameters(seed=3)
+        x, uv = O.closed_form_inputs(4, 4)
+        x, uv = x.repeat(batch // 4, 1, 1, 1) * torch.linspace(0.5, 1.5, batch).view(-1, 1, 1, 1), uv.repeat(batch // 4, 1)
+        tr.new_minibatch(x.to(DEV), uv.to(DEV))
+        terms = []
+        for it in range(4):
+            tr.step()
+            used = bool(tr.lib.lshm_engine_last_flags(tr._h) & _lib.ENGINE_USED_CONCURRENT_FORWARD)
+            assert used == overlap and tr._prefetched == overlap
+            terms.append(tr.terms[:10].clone())
+        tr.new_minibatch((0.5 * x).to(DEV), uv.to(DEV))
+        for it in range(2):
+            tr.step()
+            terms.append(tr.terms[:10].clone())
+        sd = tr.state_dicts()
+        tr.load_state_dicts(sd["net"], sd["netT"], sd["netF"], sd["mod"])  # the forward made ahead is stale now
+        tr.y[0].mul_(0.5)
+        tr.invalidate_forward()
+        tr.step()
+        terms.append(tr.terms[:10].clone())
+        if batch == 4:
+            tr.step_lbfgs(tr.make_lbfgs())
+            terms.append(tr.terms[:10].clone())
+            tr.step()
+            terms.append(tr.terms[:10].clone())
+        torch.cuda.synchronize()
+        out.append((tr.params.clone(), [t.clone() for t in tr.y], tr.exp_avg.clone(), torch.stack(terms)))
+        del tr
+    a, b = out
+    assert torch.equal(a[0], b[0])
+    assert all(torch.equal(p, q) for p, q in zip(a[1], b[1]))
+    assert torch.equal(a[2], b[2])
+    assert torch.equal(a[3], b[3])
+
+
+def test_engine_reports_its_device_and_refuses_what_is_not_on_it():
+    """One-device form of the device guard: the engine remembers the device it was created on, makes it current for
+    every call, and refuses -- with an error code, nothing launched -- arena / workspace / input pointers that are
+    not device memory of that device (here: pinned host memory, which a kernel could read across PCIe without
+    any fault) and streams of another device."""
+    import ctypes as C
+    from lshm_amd import _lib as L
+    tr, *_ = _trainer(4, 4, 2, 2)
+    lib = tr.lib
+    assert lib.lshm_engine_device(tr._h) == torch.cuda.current_device()
+    P = L.ptr
+    host_x = torch.zeros(tr.x.shape).pin_memory()
+    rc = lib.lshm_engine_forward_backward(tr._h, P(tr.params), P(tr.grads), P(host_x), P(tr.uv), P(tr.y[0]), P(tr.y[1]),
+                                          P(tr.y[2]), P(tr.terms), P(tr.ws), tr.ws_floats, L.stream())
+    assert rc == -1 and b"host" in lib.lshm_last_error_string()
+    host_ws = torch.zeros(1024).pin_memory()  # too small as well, but the size is honest: the pointer check comes first
+    rc = lib.lshm_engine_multiplier_update(tr._h, P(tr.params), P(tr.x), P(tr.uv), P(tr.y[0]), P(tr.y[1]), P(tr.y[2]),
+                                           P(host_ws), tr.ws_floats, L.stream())
+    assert rc == -1
+    unregistered = (C.c_float * 16)()
+    rc = lib.lshm_engine_forward_loss(tr._h, C.addressof(unregistered), P(tr.x), P(tr.uv), P(tr.y[0]), P(tr.y[1]),
+                                      P(tr.y[2]), P(tr.terms), P(tr.ws), tr.ws_floats, L.stream())
+    assert rc == -1
+    torch.cuda.synchronize()
+    before = tr.params.clone()
+    tr.step()  # the engine is unharmed and nothing was launched by the refused calls
+    torch.cuda.synchronize()
+    assert torch.isfinite(tr.params).all() and not torch.equal(before, tr.params)
+
+
+def test_admm_loop_with_staged_minibatches_is_the_recompute_trajectory():
+    """The loop upstream runs (src/kharmonic_lofar.py:116-131): ten ADMM iterations per minibatch, the terms read
+    back every iteration, the next minibatch uploaded from pinned host memory on a copy stream meanwhile
+    (KHarmonicTrainer.prefetch_minibatch / swap_in_minibatch), reuse_forward inside the ten.  Bit for bit the
+    trajectory of the plain recomputing trainer fed with blocking copies."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    x0, uv0 = O.closed_form_inputs(4, 4)
+    batches = [(x0, uv0), (0.5 * x0.flip(0), uv0.flip(0)), (x0 * 1.25, 0.5 * uv0)]
+    out = []
+    for staged in (False, True):
+        cfg = TrainConfig(Kc=5, reuse_forward=staged, overlap_forwards=not staged)
+        tr = KHarmonicTrainer(cfg, batch=4, batch_per_bline=2, default_batch=2, device=DEV)
+        tr.init_parameters(seed=9)
+        logs = []
+        if staged:
+            tr.prefetch_minibatch(batches[0][0].pin_memory(), batches[0][1].pin_memory())
+        for mb in range(len(batches)):
+            if staged:
+                tr.swap_in_minibatch()
+                if mb + 1 < len(batches):
+                    tr.prefetch_minibatch(batches[mb + 1][0].pin_memory(), batches[mb + 1][1].pin_memory())
+            else:
+                tr.new_minibatch(batches[mb][0].to(DEV), batches[mb][1].to(DEV))
+            for admm in range(4):
+                tr.step()
+                logs.append(tr.format_log(0, mb, admm))
+        torch.cuda.synchronize()
+        out.append((tr.params.clone(), [t.clone() for t in tr.y], logs))
+    assert torch.equal(out[0][0], out[1][0])
+    assert all(torch.equal(p, q) for p, q in zip(out[0][1], out[1][1]))
+    assert out[0][2] == out[1][2]
