@@ -143,6 +143,21 @@ int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float*
   if (rc) return rc;
   return conv_layer_wgrad(L, ConvWgradIO{x, dz, dw, db}, ws, wsf, accumulate, ST(s));
 }
+int lshm_conv_bwd_fused(int kind, const float* x, const float* dz, const float* w, float* dw, float* db, float* dx,
+                        int elu_grad, int B, int Cin, int Cout, int Hin, int Win, float* ws, size_t wsf,
+                        lshm_stream_t s) {
+  REQUIRE(x && dz && w && dw && dx && ws, "conv_bwd_fused: null pointer");
+  ConvLayer L;
+  int rc = make_layer(kind, B, Cin, Cout, Hin, Win, 0, 0, &L);
+  if (rc) return rc;
+  const ConvWgradIO io{x, dz, dw, db};
+  const ConvDgradIO dio{dz, w, dx, elu_grad ? x : nullptr};
+  if (!conv_layer_bwd_fusable(L, io, dio)) {
+    set_last_error("conv_bwd_fused: no one-pass backward kernel for this layer");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  return conv_layer_wgrad(L, io, ws, wsf, 0, ST(s), nullptr, nullptr, &dio);
+}
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t s) {
   REQUIRE(gy && y && dz && n >= 0, "elu_bwd: bad argument");
   if (n == 0) return LSHM_OK;

@@ -1,0 +1,321 @@
+// One-pass backward of the outer 1-D layers (k4 s4; src/lofar_models.py:115-117 conv0 / conv1 and :140-142
+// tconv4 / tconv5 of AutoEncoder1DCNN): weight, bias AND data gradient from ONE read of the layer's output
+// gradient and of its saved input.  The two-kernel form reads both tensors twice (once for the weight gradient,
+// once for the data gradient); these layers carry 76 % of the 1-D bytes and are HBM-bound.
+//
+// Geometry shared with conv1d_wgrad_stream_kernel (conv1d_stream.hip): `small` is the short tensor (B, CS, Ls),
+// `big` the long one (B, CB, 4 Ls); lane (slot, q) of a wavefront owns 4 consecutive positions of a 64-position
+// tile, the small channels {4a + q} and the big channels {4g + q}; the weight gradient runs on
+// v_mfma_f32_4x4x1_16b_f32 straight from those registers.  The data gradient re-uses the same registers:
+//   transposed layer (pad 0; small = saved input, big = dz):
+//       dsmall[cs, j] = ELU'(small[cs, j]) * sum_{cb,t} w[cs, cb, t] big[cb, 4j + t]
+//     a lane sums over ITS big channels for every cs, the four lanes of a quad reduce-scatter the partial sums
+//     (two DPP quad permutations) and each ends with exactly the channels it loaded;
+//   conv layer (pad 1; small = dz, big = saved input):
+//       dbig[cb, 4j - 1 + t] = ELU'(big[..]) * sum_cs small[cs, j] w[cs, cb, t]
+//     the quad all-gathers the small channels (DPP broadcasts), a lane then forms ITS big channels; the aligned
+//     output quad 4j .. 4j+3 takes taps 1..3 of position j and tap 0 of position j + 1, so a lane also loads the
+//     small values of the position after its four.
+// `big` is read as aligned quads plus, for pad 1, the one element before them; the pad-1 windows of the weight
+// gradient are register selections (no shifted loads).  Weights of the data gradient: 8 x float4 per lane for the
+// 8 / 4 layers (registers), 24 for 12 / 8 (LDS, one broadcast ds_read_b128 per use).
+#include <stdlib.h>
+
+#include "kernels.h"
+
+namespace lshm {
+
+struct FusedBwd1dArgs {
+  const float* small[2];
+  const void* big[2];
+  const float* w[2];       // [CS][CB][4] (Conv1d: (Cout, Cin, 4); ConvTranspose1d: (Cin, Cout, 4))
+  float* partial[2];       // one slab of CS*CB*4 + 16 floats per workgroup
+  void* dout[2];           // conv layer: gradient w.r.t. big (element type of big); transposed: w.r.t. small (float)
+  long s_bs, big_bs, d_bs;
+  int Ls, Lb, ntiles;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
+// CONV: conv layer (pad 1, bias gradient = sum of small) / transposed layer (pad 0, bias gradient = sum of big)
+// DACT: multiply the data gradient by ELU'(saved input) (the saved input is the layer's input: small for the
+//       transposed layer, big for the conv layer)
+// two wavefronts per SIMD (at most 256 registers, accumulators included): with one, nothing hides the latency of a
+// tile's loads but the next tile's prefetch; the 12 / 8 kernels keep 96 accumulator registers and therefore do
+// NOT hold a second tile in registers (PF == false) -- the other wavefront of the SIMD covers the wait instead
+template <int CS, int CB, bool CONV, bool DACT, bool WLDS, class TB>
+__global__ __launch_bounds__(256, 2) void conv1d_bwd_fused2_kernel(const FusedBwd1dArgs a) {
+  constexpr bool PF = CS <= 8;
+  constexpr int GA = CS / 4, GB = CB / 4;
+  constexpr int NW = CS * CB * 4, SLAB = NW + 16;
+  constexpr int WSTR = CS * GB + 1;  // float4 units; (4 WSTR) mod 64 banks spreads the four q rows
+  static_assert(CS % 4 == 0 && CB % 4 == 0, "channel groups of four");
+  __shared__ float comb[4][SLAB];
+  __shared__ f32x4 wl[WLDS ? 4 * WSTR : 1];
+  const int pr = blockIdx.y;
+  const float* __restrict__ small = a.small[pr];
+  const TB* __restrict__ big = reinterpret_cast<const TB*>(a.big[pr]);
+  const float* __restrict__ w = a.w[pr];
+  float* __restrict__ partial = a.partial[pr];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int slot = lane >> 2, q = lane & 3;
+  const int Ls = a.Ls, Lb = a.Lb;
+
+  // w[cs][cb = 4g + q][0..3] of this lane
+  f32x4 wr[WLDS ? 1 : CS * GB];
+  if constexpr (WLDS) {
+    for (int i = t; i < CS * CB; i += 256) {
+      const int cs = i / CB, cb = i - cs * CB;
+      wl[(cb & 3) * WSTR + cs * GB + (cb >> 2)] = *reinterpret_cast<const f32x4*>(w + 4 * i);
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int cs = 0; cs < CS; ++cs)
+#pragma unroll
+      for (int g = 0; g < GB; ++g) wr[cs * GB + g] = *reinterpret_cast<const f32x4*>(w + ((long)cs * CB + 4 * g + q) * 4);
+  }
+  auto W = [&](int cs, int g) -> f32x4 {
+    if constexpr (WLDS) return wl[q * WSTR + cs * GB + g];
+    else return wr[cs * GB + g];
+  };
+
+  f32x4 acc[GA][GB][4];
+#pragma unroll
+  for (int x = 0; x < GA; ++x)
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp) acc[x][g][tp] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NBS = CONV ? GA : GB;
+  float bsum[NBS];
+#pragma unroll
+  for (int i = 0; i < NBS; ++i) bsum[i] = 0.f;
+
+  const int tiles_per = Ls / 64;
+  const int nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
+  f32x4 ra[GA], rq[GB][4];
+  float rx[GA], rm[GB];
+  auto load_tile = [&](int tile) {
+    const int b = tile / tiles_per, p0 = (tile - b * tiles_per) * 64 + 4 * slot;
+    const float* sb = small + (long)b * a.s_bs + p0;
+    const TB* bb = big + (long)b * a.big_bs + 4L * p0;
+#pragma unroll
+    for (int x = 0; x < GA; ++x) {
+      ra[x] = *reinterpret_cast<const f32x4*>(sb + (long)(4 * x + q) * Ls);
+      if constexpr (CONV) rx[x] = p0 + 4 < Ls ? sb[(long)(4 * x + q) * Ls + 4] : 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) rq[g][i] = Elem<TB>::ld4(bb + (long)(4 * g + q) * Lb + 4 * i);
+      if constexpr (CONV) rm[g] = p0 > 0 ? Elem<TB>::ld(bb + (long)(4 * g + q) * Lb - 1) : 0.f;
+    }
+  };
+  if (PF && w0 < a.ntiles) load_tile(w0);
+  for (int tile = w0; tile < a.ntiles; tile += nwaves) {
+    if (!PF) load_tile(tile);
+    f32x4 ca[GA], cq[GB][4];
+    float cx[GA], cm[GB];
+#pragma unroll
+    for (int x = 0; x < GA; ++x) { ca[x] = ra[x]; if constexpr (CONV) cx[x] = rx[x]; }
+#pragma unroll
+    for (int g = 0; g < GB; ++g) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) cq[g][i] = rq[g][i];
+      if constexpr (CONV) cm[g] = rm[g];
+    }
+    if (PF && tile + nwaves < a.ntiles) load_tile(tile + nwaves);
+    if constexpr (CONV) {
+#pragma unroll
+      for (int x = 0; x < GA; ++x) bsum[x] += (ca[x][0] + ca[x][1]) + (ca[x][2] + ca[x][3]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < GB; ++g)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bsum[g] += (cq[g][i][0] + cq[g][i][1]) + (cq[g][i][2] + cq[g][i][3]);
+    }
+    // ---- weight gradient: 16 slots x (4 small channels x 4 big channels) per instruction
+#pragma unroll
+    for (int st = 0; st < 4; ++st)      // position p0 + st
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp)    // tap: big[4 (p0 + st) - pad + tp]
+#pragma unroll
+        for (int x = 0; x < GA; ++x)
+#pragma unroll
+          for (int g = 0; g < GB; ++g) {
+            float bv;
+            if constexpr (CONV) bv = tp == 0 ? (st == 0 ? cm[g] : cq[g][st - 1][3]) : cq[g][st][tp - 1];
+            else bv = cq[g][st][tp];
+            acc[x][g][tp] = __builtin_amdgcn_mfma_f32_4x4x1f32(ca[x][st], bv, acc[x][g][tp], 0, 0, 0);
+          }
+    const int b = tile / tiles_per, p0 = (tile - b * tiles_per) * 64 + 4 * slot;
+    // (position-outer loops below: short live ranges keep the 12 / 8 kernels inside 256 registers)
+    if constexpr (!CONV) {
+      // ---- data gradient of the transposed layer: partial sums over this lane's big channels, reduce-scatter
+      const bool odd = q & 1, hi = q & 2;
+      f32x4 r2[GA];  // channel 4m + q, this lane's 4 positions
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        // (LDS weights: re-read per position -- 24 broadcast ds_read_b128 -- instead of 96 registers held across the loop)
+        if constexpr (WLDS) asm volatile("" ::: "memory");
+        float pc[CS];
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) {
+          float s = 0.f;
+#pragma unroll
+          for (int g = 0; g < GB; ++g) {
+            const f32x4 wv = W(cs, g);
+            s = fmaf(wv[3], cq[g][st][3], fmaf(wv[2], cq[g][st][2], fmaf(wv[1], cq[g][st][1], fmaf(wv[0], cq[g][st][0], s))));
+          }
+          pc[cs] = s;
+        }
+        float r1[CS / 2];  // after the pair exchange: channel 2k + (q & 1), summed over two lanes
+#pragma unroll
+        for (int k = 0; k < CS / 2; ++k) {
+          const float send = odd ? pc[2 * k] : pc[2 * k + 1], keep = odd ? pc[2 * k + 1] : pc[2 * k];
+          r1[k] = keep + quad_dpp<0xB1>(send);  // quad_perm [1,0,3,2]
+        }
+#pragma unroll
+        for (int m = 0; m < GA; ++m) {
+          const float send = hi ? r1[2 * m] : r1[2 * m + 1], keep = hi ? r1[2 * m + 1] : r1[2 * m];
+          r2[m][st] = keep + quad_dpp<0x4E>(send);  // quad_perm [2,3,0,1]
+        }
+      }
+      float* dsm = reinterpret_cast<float*>(a.dout[pr]) + (long)b * a.d_bs + p0;
+#pragma unroll
+      for (int m = 0; m < GA; ++m) {
+        f32x4 o = r2[m];
+        if constexpr (DACT) {
+#pragma unroll
+          for (int st = 0; st < 4; ++st) o[st] *= elu_grad_from_out(ca[m][st]);
+        }
+        *reinterpret_cast<f32x4*>(dsm + (long)(4 * m + q) * Ls) = o;
+      }
+    } else {
+      // ---- data gradient of the conv layer: all-gather the small channels of one position over the quad, then this
+      // lane's big channels; the values of the next position (tap 0 of the aligned quad's last element) carry over
+      auto gather = [&](int i, float (&dst)[CS]) {
+#pragma unroll
+        for (int x = 0; x < GA; ++x) {
+          const float v = i < 4 ? ca[x][i < 4 ? i : 0] : cx[x];
+          dst[4 * x + 0] = quad_dpp<0x00>(v);
+          dst[4 * x + 1] = quad_dpp<0x55>(v);
+          dst[4 * x + 2] = quad_dpp<0xAA>(v);
+          dst[4 * x + 3] = quad_dpp<0xFF>(v);
+        }
+      };
+      TB* dbg = reinterpret_cast<TB*>(a.dout[pr]) + (long)b * a.d_bs + 4L * p0;
+      float cur[CS], nxt[CS];
+      gather(0, cur);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (WLDS) asm volatile("" ::: "memory");  // as above: the weights come from LDS again for every position
+        gather(i + 1, nxt);
+#pragma unroll
+        for (int g = 0; g < GB; ++g) {
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int cs = 0; cs < CS; ++cs) {
+            const f32x4 wv = W(cs, g);
+            // big[4p + r] (r < 3) is tap r + 1 of position p; big[4p + 3] is tap 0 of position p + 1
+            o[0] = fmaf(cur[cs], wv[1], o[0]);
+            o[1] = fmaf(cur[cs], wv[2], o[1]);
+            o[2] = fmaf(cur[cs], wv[3], o[2]);
+            o[3] = fmaf(nxt[cs], wv[0], o[3]);
+          }
+          if constexpr (DACT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= elu_grad_from_out(cq[g][i][r]);
+          }
+          Elem<TB>::st4(dbg + (long)(4 * g + q) * Lb + 4 * i, o);
+        }
+#pragma unroll
+        for (int cs = 0; cs < CS; ++cs) cur[cs] = nxt[cs];
+      }
+    }
+  }
+  // ---- 16 slots -> lane q of slot 0 (butterflies over lane bits 2..5), then the 4 waves through LDS
+#pragma unroll
+  for (int x = 0; x < GA; ++x)
+#pragma unroll
+    for (int g = 0; g < GB; ++g)
+#pragma unroll
+      for (int tp = 0; tp < 4; ++tp)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[x][g][tp][r];
+          v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+          // lane (slot 0, q): dW[cs = 4x + r][cb = 4g + q][tap tp]
+          if (slot == 0) comb[wave][((4 * x + r) * CB + 4 * g + q) * 4 + tp] = v;
+        }
+#pragma unroll
+  for (int i = 0; i < NBS; ++i) {
+    float v = bsum[i];
+    v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (slot == 0) comb[wave][NW + 4 * i + q] = v;  // channel 4i + q of small (conv) or big (transposed)
+  }
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * SLAB;
+  for (int i = t; i < SLAB; i += 256) {
+    const bool live = i < NW || i - NW < 4 * NBS;
+    out[i] = live ? (comb[0][i] + comb[1][i]) + (comb[2][i] + comb[3][i]) : 0.f;
+  }
+}
+
+bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
+  // 12 / 8 channels: 96 accumulator registers + the data-gradient working set do not fit two wavefronts per SIMD
+  // (the compiler spills 80-330 registers; 67-129 us against 50 us for the two separate kernels, profiles/r03):
+  // opt-in only (LSHM_FUSED2_12_8=1) until those layers get an LDS-staged form
+  static const bool wide = getenv("LSHM_FUSED2_12_8") != nullptr;
+  return (wide && Cs == 12 && Cb == 8 && (pad == 0 || pad == 1)) || (Cs == 8 && Cb == 4 && (pad == 0 || pad == 1));
+}
+
+// one slab of Cs*Cb*4 + 16 floats per workgroup at ws (and ws2 for the second problem); returns the grid size
+int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs,
+                      float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks,
+                      hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd) {
+  const bool two = small2 != nullptr;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!conv1d_bwd_fused2_supported(Cs, Cb, pad) || Ls % 64 || Lb != 4 * Ls || s_bs % 4 || big_bs % 4 || fd.dx_bs % 4 ||
+      !fd.w || !fd.dx || !al16(small) || !al16(big) || !al16(fd.w) || !al16(fd.dx) ||
+      (two && (!big2 || !fd.w2 || !fd.dx2 || !al16(small2) || !al16(big2) || !al16(fd.w2) || !al16(fd.dx2))) ||
+      (big_bf16 && !(Cs == 8 && Cb == 4))) {
+    set_last_error("conv1d_bwd_fused: unsupported layer shape, stride or alignment");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  FusedBwd1dArgs a;
+  a.small[0] = small; a.small[1] = two ? small2 : small;
+  a.big[0] = big; a.big[1] = two ? big2 : big;
+  a.w[0] = fd.w; a.w[1] = two ? fd.w2 : fd.w;
+  a.partial[0] = ws; a.partial[1] = two ? ws2 : ws;
+  a.dout[0] = fd.dx; a.dout[1] = two ? fd.dx2 : fd.dx;
+  a.s_bs = s_bs; a.big_bs = big_bs; a.d_bs = fd.dx_bs;
+  a.Ls = Ls; a.Lb = Lb; a.ntiles = (Ls / 64) * B;
+  static const int tpw = [] { const char* v = getenv("LSHM_FUSED2_TPW"); return v && atoi(v) > 0 ? atoi(v) : 4; }();
+  int grid = a.ntiles / (4 * tpw);  // tiles per wavefront
+  if (grid > 512) grid = 512;
+  if (grid < 1) grid = 1;
+  if (grid > max_blocks) grid = max_blocks;
+  *grid_out = grid;
+  const dim3 g(grid, two ? 2 : 1);
+  const bool dact = fd.dact != 0;
+#define LSHM_FUSED2(CS, CB, CONV, WL, T)                                                                            \
+  do {                                                                                                              \
+    if (dact) hipLaunchKernelGGL((conv1d_bwd_fused2_kernel<CS, CB, CONV, true, WL, T>), g, dim3(256), 0, st, a);    \
+    else hipLaunchKernelGGL((conv1d_bwd_fused2_kernel<CS, CB, CONV, false, WL, T>), g, dim3(256), 0, st, a);        \
+  } while (0)
+  if (Cs == 12 && pad == 0) LSHM_FUSED2(12, 8, false, true, float);
+  else if (Cs == 12) LSHM_FUSED2(12, 8, true, true, float);
+  else if (pad == 0 && big_bf16) LSHM_FUSED2(8, 4, false, false, bf16);
+  else if (pad == 0) LSHM_FUSED2(8, 4, false, false, float);
+  else if (big_bf16) LSHM_FUSED2(8, 4, true, false, bf16);
+  else LSHM_FUSED2(8, 4, true, false, float);
+#undef LSHM_FUSED2
+  return check_launch("conv1d_bwd_fused");
+}
+
+}  // namespace lshm

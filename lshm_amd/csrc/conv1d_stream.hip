@@ -5,6 +5,8 @@
 // one position of the short tensor for all channels: loads are one float (coalesced across lanes) or
 // one float4 per channel, stores one float4 or one float per channel, weights are uniform and come
 // through the scalar cache.  fp32 FMA chains in a fixed order: bitwise reproducible.
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace lshm {
@@ -335,12 +337,19 @@ bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int 
          s_bs % 4 == 0 && big_bs % 4 == 0 && (reinterpret_cast<uintptr_t>(small) & 15) == 0 &&
          (reinterpret_cast<uintptr_t>(big) & 15) == 0;
 }
-bool conv1d_bwd_fused_supported(int Cs, int Cb, int pad) { return Cs == 8 && Cb == 4 && pad == 0; }
+bool conv1d_bwd_fused_supported(int Cs, int Cb, int pad) {
+  return (Cs == 8 && Cb == 4 && pad == 0) || conv1d_bwd_fused2_supported(Cs, Cb, pad);
+}
 // one slab of Cs*Cb*4 + 16 floats per workgroup at ws (and ws2 for the second problem); returns the grid size
 int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
                         int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16,
                         const FusedDgrad* fd) {
+  // every fused layer but the original 8 -> 4 transposed one (which keeps its own kernel unless LSHM_FUSED2_ALL=1)
+  static const bool fused2_all = getenv("LSHM_FUSED2_ALL") != nullptr;
+  if (fd && fd->dx && (fused2_all || !(Cs == 8 && Cb == 4 && pad == 0) || !fd->dact))
+    return conv1d_bwd_fused2(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, max_blocks, st,
+                             grid_out, big_bf16, *fd);
   const float* w = fd ? fd->w : nullptr;
   const float* w2 = fd ? fd->w2 : nullptr;
   float* dsmall = fd ? fd->dx : nullptr;

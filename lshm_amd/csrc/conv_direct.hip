@@ -897,6 +897,250 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// One-pass backward of the outermost 2-D decoder layer, tconv5 (8 -> 4 channels, src/lofar_models.py:57):
+// data gradient (conv2d_q4_kernel above, with the ELU' multiply), weight gradient and bias gradient
+// (conv2d_wgrad_direct_kernel<8, 4, 4, 64>) from ONE staging of the gradient image's patch in LDS and one read of
+// the saved input: the two kernels read the same 67 MB gradient image and the same 33 MB saved input, and stage
+// the same 4 x 10 x 130 patch.  Per tile: patch -> LDS; data gradient on v_mfma_f32_4x4x1 (wavefront = input
+// channel, partial rows combined through LDS in channel order, exactly as conv2d_q4_kernel does: bitwise the same
+// data gradient); the epilogue's float4s of the saved input go to the LDS small tile on their way through the ELU'
+// multiply; weight gradient on v_mfma_f32_16x16x4 from the small tile and the patch, accumulators kept in
+// registers across the tiles of the persistent workgroup (the same MFMA sequence as the stand-alone kernel).
+// ----------------------------------------------------------------------------------------------
+template <class TB>  // TB: element type of `big` (the gradient image; bf16 storage, common.h)
+__global__ __launch_bounds__(256, 2) void tconv2d_bwd_fused_kernel(const float* __restrict__ big_, long big_bs,
+                                                                   const float* __restrict__ small, long s_bs,
+                                                                   const float* __restrict__ w,
+                                                                   float* __restrict__ dsmall, float* __restrict__ partial,
+                                                                   int Hs, int Ws, int ntiles, int dact) {
+  const TB* __restrict__ big = reinterpret_cast<const TB*>(big_);
+  constexpr int CS = 8, CB = 4, TH = 4, TW = 64, NH = CS / 4;
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
+  constexpr int TP = TH * TW, LDS_S = TP + 2;
+  constexpr int SLAB = CS * CB * 16 + 16;
+  __shared__ __attribute__((aligned(16))) float patch[CB * PH * PW];
+  __shared__ f32x4 red[CB][TH - 1][NH][64];
+  __shared__ float stile[16 * LDS_S];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int q = lane & 3, lm = lane & 15, lk = lane >> 4;
+  for (int i = t; i < 16 * LDS_S; i += 256) stile[i] = 0.f;  // rows >= CS stay zero
+  // data-gradient B fragments: bw[ky][h] = taps kx 0..3 of w[4h + q][wave][ky][:]  (conv view: out = small ch, in = big ch)
+  f32x4 bw[4][NH];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      bw[ky][h] = *reinterpret_cast<const f32x4*>(w + (((long)(4 * h + q) * CB + wave) * 4 + ky) * 4);
+  f32x4 wacc[CB];
+#pragma unroll
+  for (int j = 0; j < CB; ++j) wacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NV4 = (CB * PH * (2 * TW / 4) + 255) / 256, NHL = (CB * PH * 2 + 255) / 256;
+  float bs_big[NV4];
+#pragma unroll
+  for (int k = 0; k < NV4; ++k) bs_big[k] = 0.f;
+
+  const int tiles_x = Ws / TW, tiles_y = Hs / TH;
+  const int Hb = 2 * Hs, Wb = 2 * Ws;
+  f32x4 rv[NV4], rs[NH];
+  float rh[NHL];
+  auto load_tile = [&](int tile) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    const TB* xb = big + (long)b * big_bs;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int i = k * 256 + t;
+      const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+      const int prow = rr % PH, ci = rr / PH;
+      const int iy = 2 * m0 - 1 + prow;
+      rv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CB * PH * (2 * TW / 4) && (unsigned)iy < (unsigned)Hb)
+        rv[k] = Elem<TB>::ld4(xb + ((long)ci * Hb + iy) * Wb + 2 * n0 + 4 * c4);
+    }
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int i = k * 256 + t;
+      const int side = i & 1, rr = i >> 1;
+      const int prow = rr % PH, ci = rr / PH;
+      const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
+      rh[k] = 0.f;
+      if (i < CB * PH * 2 && (unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb) rh[k] = Elem<TB>::ld(xb + ((long)ci * Hb + iy) * Wb + ix);
+    }
+    // the saved input this thread finishes in the epilogue: row m0 + wave, columns n0 + 4 (lane / 4) .., channel 4h + q
+#pragma unroll
+    for (int h = 0; h < NH; ++h)
+      rs[h] = *reinterpret_cast<const f32x4*>(small + (long)b * s_bs + ((long)(4 * h + q) * Hs + m0 + wave) * Ws + n0 + 4 * (lane >> 2));
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    __syncthreads();  // the previous tile's weight-gradient loop has finished reading the patch and the small tile
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int i = k * 256 + t;
+      if (i < CB * PH * (2 * TW / 4)) {
+        const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+        const int prow = rr % PH;
+        float* d = &patch[rr * PW + 1 + 4 * c4];  // odd offset: b32 + b64 + b32
+        d[0] = rv[k][0];
+        *reinterpret_cast<float2*>(d + 1) = make_float2(rv[k][1], rv[k][2]);
+        d[3] = rv[k][3];
+        // halo rows belong to the neighbouring tiles: only the 2*TH interior rows count towards the bias gradient
+        if (prow >= 1 && prow <= 2 * TH) bs_big[k] += (rv[k][0] + rv[k][1]) + (rv[k][2] + rv[k][3]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < NHL; ++k) {
+      const int i = k * 256 + t;
+      if (i < CB * PH * 2) patch[(i >> 1) * PW + ((i & 1) ? PW - 1 : 0)] = rh[k];
+    }
+    f32x4 sv[NH];
+#pragma unroll
+    for (int h = 0; h < NH; ++h) sv[h] = rs[h];
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
+
+    // ---- data gradient: this wavefront's big channel, all rows (conv2d_q4_kernel)
+    f32x4 acc[TH][NH];
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+      for (int h = 0; h < NH; ++h) acc[r][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      float2 a01[TH], a23[TH];
+#pragma unroll
+      for (int r = 0; r < TH; ++r) {
+        const float* pr = &patch[(wave * PH + 2 * r + ky) * PW + 2 * lane];
+        a01[r] = *reinterpret_cast<const float2*>(pr);
+        a23[r] = *reinterpret_cast<const float2*>(pr + 2);
+      }
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a01[r].x, bw[ky][h][0], acc[r][h], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a01[r].y, bw[ky][h][1], acc[r][h], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a23[r].x, bw[ky][h][2], acc[r][h], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a23[r].y, bw[ky][h][3], acc[r][h], 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+      if (r != wave) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) red[wave][r < wave ? r : r - 1][h][lane] = acc[r][h];
+      }
+    __syncthreads();
+    // ---- row `wave`: add the four channel partials in order, ELU' multiply, float4 stores; the saved input goes to the small tile
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
+      const f32x4 own = wave == 0 ? acc[0][h] : wave == 1 ? acc[1][h] : wave == 2 ? acc[2][h] : acc[3][h];
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CB; ++c) s4 += (c == wave) ? own : red[c][wave < c ? wave : wave - 1][h][lane];
+      const long g = (long)b * s_bs + ((long)(4 * h + q) * Hs + m0 + wave) * Ws + n0 + 4 * (lane >> 2);
+      f32x4 o = s4;
+      if (dact) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] *= elu_grad_from_out(sv[h][r]);
+      }
+      *reinterpret_cast<f32x4*>(dsmall + g) = o;
+      float* d = &stile[(4 * h + q) * LDS_S + wave * TW + 4 * (lane >> 2)];
+      d[0] = sv[h][0]; d[1] = sv[h][1]; d[2] = sv[h][2]; d[3] = sv[h][3];
+    }
+    __syncthreads();
+    // ---- weight gradient: groups of 4 consecutive positions, every 4th group per wave (conv2d_wgrad_direct_kernel)
+    const int ky = lm >> 2, kx = lm & 3;
+#pragma unroll 4
+    for (int s = wave; s < TP / 4; s += 4) {
+      const int p = 4 * s + lk;
+      const int oy = p / TW, ox = p - oy * TW;
+      const float av = stile[lm * LDS_S + p];
+      const int boff = (2 * oy + ky) * PW + 2 * ox + kx;
+#pragma unroll
+      for (int j = 0; j < CB; ++j) wacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, patch[j * PH * PW + boff], wacc[j], 0, 0, 0);
+    }
+  }
+  // ---- combine the 4 waves (fixed order) and write this workgroup's slab [CS][CB*16] + bias sums
+  __syncthreads();
+  float* out = partial + (size_t)blockIdx.x * SLAB;
+  {
+    static_assert(CB * PH * PW >= 4 * 16 * (CB * 16 + 1), "combine buffer must fit in the patch");
+    float (*comb)[16][CB * 16 + 1] = reinterpret_cast<float (*)[16][CB * 16 + 1]>(patch);
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) comb[wave][4 * lk + r][16 * j + lm] = wacc[j][r];
+    __syncthreads();
+    for (int i = t; i < CS * CB * 16; i += 256) {
+      const int m = i / (CB * 16), n = i - m * (CB * 16);
+      out[i] = (comb[0][m][n] + comb[1][m][n]) + (comb[2][m][n] + comb[3][m][n]);
+    }
+  }
+  __syncthreads();
+  float* bred = patch;  // [16 channels][4 waves]
+  for (int c = 0; c < CB; ++c) {
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV4; ++k) {
+      const int i = k * 256 + t;
+      if (i < CB * PH * (2 * TW / 4) && (i / (2 * TW / 4)) / PH == c) v += bs_big[k];
+    }
+    v = wave_sum(v);
+    if (lane == 0) bred[c * 4 + wave] = v;
+  }
+  __syncthreads();
+  if (t < 16) out[CS * CB * 16 + t] = t < CB ? (bred[t * 4] + bred[t * 4 + 1]) + (bred[t * 4 + 2] + bred[t * 4 + 3]) : 0.f;
+}
+
+bool tconv2d_bwd_fused_supported(int Cs, int Cb, int Hs, int Ws) { return Cs == 8 && Cb == 4 && Hs % 4 == 0 && Ws % 64 == 0; }
+// weight + bias + data gradient of the 8 -> 4 transposed layer; one slab per workgroup in ws (conv2d_wgrad_direct_workspace_floats)
+int tconv2d_bwd_fused(const float* small, long s_bs, const float* big, long big_bs, const float* w, float* dsmall, int dact,
+                      float* dw, float* db, int B, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
+                      GradJobs* defer, int big_bf16) {
+  constexpr int Cs = 8, Cb = 4;
+  if (wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("tconv2d_bwd_fused: workspace too small"); return LSHM_ERR_WORKSPACE; }
+  if (!tconv2d_bwd_fused_supported(Cs, Cb, Hs, Ws) || s_bs % 4 || big_bs % 4 || (reinterpret_cast<uintptr_t>(small) & 15) ||
+      (reinterpret_cast<uintptr_t>(big) & 15) || (reinterpret_cast<uintptr_t>(dsmall) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) {
+    set_last_error("tconv2d_bwd_fused: unsupported shape or alignment");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  const int ntiles = (Ws / 64) * (Hs / 4) * B;
+  const int grid = ntiles < 512 ? ntiles : 512;  // 62 KB of LDS: two workgroups per CU
+  int rc;
+  if (big_bf16) {
+    if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(&tconv2d_bwd_fused_kernel<bf16>), 256, 0, "tconv2d_bwd_fused"))) return rc;
+    hipLaunchKernelGGL((tconv2d_bwd_fused_kernel<bf16>), dim3(grid), dim3(256), 0, st, big, big_bs, small, s_bs, w, dsmall, ws, Hs,
+                       Ws, ntiles, dact);
+  } else {
+    if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(&tconv2d_bwd_fused_kernel<float>), 256, 0, "tconv2d_bwd_fused"))) return rc;
+    hipLaunchKernelGGL((tconv2d_bwd_fused_kernel<float>), dim3(grid), dim3(256), 0, st, big, big_bs, small, s_bs, w, dsmall, ws, Hs,
+                       Ws, ntiles, dact);
+  }
+  if ((rc = check_launch("tconv2d_bwd_fused"))) return rc;
+  const int nw = Cs * Cb * 16, slab = nw + 16;
+  if (defer) {
+    defer->sums.push_back(SumJob{ws, dw, slab, nw, grid, 0, 0, 0, 0, accumulate, 0});
+    if (db) defer->sums.push_back(SumJob{ws + nw, db, slab, Cb, grid, 0, 0, 0, 0, accumulate, 0});
+    return LSHM_OK;
+  }
+  rc = reduce_partials_strided(ws, slab, dw, nw, grid, accumulate, st);
+  if (rc || !db) return rc;
+  return reduce_partials_strided(ws + nw, slab, db, Cb, grid, accumulate, st);
+}
+
 bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo) {
   if (Cin == 4 && Cout == 8) return Ho % 4 == 0 && Wo % 64 == 0;
   if (Cin == 8 && Cout == 12) return Ho % 8 == 0 && Wo % 32 == 0;

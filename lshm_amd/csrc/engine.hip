@@ -53,8 +53,19 @@ struct AEPlan {
 
 using namespace lshm;
 
+namespace lshm {
+using FwdStep = std::function<int(float* ws, hipStream_t st)>;
+}
+
 struct lshm_engine {
   lshm_step_config cfg;
+  struct FwdPlan {  // step list of the forward for one (params, x, uv) triple, see forward_plan
+    const float* prm = nullptr;
+    const float* x = nullptr;
+    const float* uv = nullptr;
+    std::vector<lshm::FwdStep> steps;
+    size_t latent_mark = 0, output1d_mark = 0;
+  } plan;
   int D;        // L + 2 Lt
   int hdim;     // 4 H
   std::vector<ParamInfo> params;
@@ -201,63 +212,134 @@ static void plan_ae(lshm_engine* e, int idx, const char* prefix, int ndim, int L
   a.out = take(cur, (size_t)B * c.C * PP);
 }
 
+// A forward pass is built as a list of steps, one launch each, every step a function of (workspace base, stream):
+// the same list can then be enqueued once (the usual forward) or twice in lock step on two streams with two
+// workspace bases (lshm_engine_multiplier_update_next_ex: two independent forwards side by side -- enqueueing one
+// whole chain before the other would leave the second stream empty for the ~0.2 ms the host needs per chain).
+struct Src {  // an input tensor: absolute (the caller's x) or relative to the workspace base
+  const float* abs;
+  size_t off;
+  const float* at(const float* ws) const { return abs ? abs : ws + off; }
+};
+
 // Forward of one autoencoder (G == 1) or of two autoencoders of identical shape that share every
 // launch (G == 2: netT and netF).  idx[] = AE indices, input[] = their input tensors.
+// latent_mark: index of the first step after the latents are complete; output_mark: index of the step that writes
+// the reconstruction itself (the last decoder layer)
+static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const float* prm, const Src* input,
+                             int ln,  // ln: scratch slot of problem 0
+                             std::vector<FwdStep>& steps, size_t* latent_mark, size_t* output_mark) {
+  const lshm_step_config& c = e->cfg;
+  const int i0 = idx[0], i1 = G > 1 ? idx[1] : idx[0];
+  const Src s0 = input[0], s1 = G > 1 ? input[1] : input[0];
+  const int B = c.B, hd = e->hdim, L = e->ae[i0].L, D = e->D;
+  const size_t pf = e->part_floats * (G > 1 ? 2 : 1);
+  const size_t o_part = e->o_fpart + (size_t)ln * 2 * e->part_floats;  // a pair uses two adjacent scratch regions
+  auto A = [e, i0, i1](int g) -> const AEPlan& { return e->ae[g ? i1 : i0]; };
+  for (int i = 0; i < 6; ++i)
+    steps.push_back([=](float* ws, hipStream_t st) -> int {
+      ConvFwdIO io[2];
+      for (int g = 0; g < G; ++g) {
+        const float* in = i == 0 ? (g ? s1 : s0).at(ws) : ws + A(g).act[i - 1];
+        float* out = (i < 5) ? ws + A(g).act[i] : ws + A(g).cat1;
+        io[g] = ConvFwdIO{in, prm + A(g).cw[i], prm + A(g).cb[i], out};
+      }
+      return conv_layer_fwd(A(0).enc[i], io[0], 1, ws + o_part, pf, st, G > 1 ? &io[1] : nullptr);
+    });
+  // dense layers: (input offset, weight, bias, output offset) per problem; offsets relative to the workspace
+  struct Lin { size_t x[2], y[2]; long w[2], b[2]; long ldx, ldy; int K, N, act; };
+  auto lin = [&](const Lin& q) {
+    steps.push_back([=](float* ws, hipStream_t st) -> int {
+      LinFwdIO l[2];
+      for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + q.x[g], prm + q.w[g], prm + q.b[g], ws + q.y[g]};
+      return linear_fwd(l[0], q.ldx, q.ldy, B, q.K, q.N, q.act, ws + o_part, pf, st, G > 1 ? &l[1] : nullptr);
+    });
+  };
+  auto both = [&](auto f) { Lin q{}; for (int g = 0; g < 2; ++g) f(q, g, A(g)); return q; };
+  // (elu(fcuv1(uvh)) and elu(fcuv3(uvh)) are already in cat1 / cat3: the uv_features step)
+  if (c.rica) {
+    Lin q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = a.cat1; q.w[g] = a.fc1w; q.b[g] = a.fc1b; q.y[g] = a.z1; });
+    q.ldx = 768 + hd; q.ldy = L; q.K = 768 + hd; q.N = L; q.act = 1;
+    lin(q);
+    q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = a.z1; q.w[g] = a.fc2inw; q.b[g] = a.fc2inb; q.y[g] = e->o_Mu + a.mu_col; });
+    q.ldx = L; q.ldy = D; q.K = L; q.N = L; q.act = 1;
+    lin(q);
+    q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = e->o_Mu + a.mu_col; q.w[g] = a.fc2outw; q.b[g] = a.fc2outb; q.y[g] = a.cat3; });
+    q.ldx = D; q.ldy = L + hd; q.K = L; q.N = L; q.act = 1;
+    lin(q);
+  } else {
+    Lin q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = a.cat1; q.w[g] = a.fc1w; q.b[g] = a.fc1b; q.y[g] = e->o_Mu + a.mu_col; });
+    q.ldx = 768 + hd; q.ldy = D; q.K = 768 + hd; q.N = L; q.act = 1;
+    lin(q);
+    for (int g = 0; g < G; ++g) {
+      const size_t src = e->o_Mu + A(g).mu_col, dst = A(g).cat3;
+      steps.push_back([=](float* ws, hipStream_t st) -> int { return copy2d(ws + src, D, ws + dst, L + hd, B, L, st); });
+    }
+  }
+  if (latent_mark) *latent_mark = steps.size();
+  {
+    Lin q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = a.cat3; q.w[g] = a.fc3w; q.b[g] = a.fc3b; q.y[g] = a.d0; });
+    q.ldx = L + hd; q.ldy = 768; q.K = L + hd; q.N = 768; q.act = 0;
+    lin(q);
+  }
+  for (int i = 0; i < 6; ++i) {
+    if (i == 5 && output_mark) *output_mark = steps.size();
+    steps.push_back([=](float* ws, hipStream_t st) -> int {
+      ConvFwdIO io[2];
+      for (int g = 0; g < G; ++g) {
+        const float* in = i == 0 ? ws + A(g).d0 : ws + A(g).dact[i - 1];
+        float* out = (i < 5) ? ws + A(g).dact[i] : ws + A(g).out;
+        io[g] = ConvFwdIO{in, prm + A(g).tw[i], prm + A(g).tb[i], out};
+      }
+      return conv_layer_fwd(A(0).dec[i], io[0], i < 5, ws + o_part, pf, st, G > 1 ? &io[1] : nullptr);
+    });
+  }
+}
+
 static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* prm, const float* const* input,
-                      float* ws, int ln, hipStream_t st,  // ln: scratch lane of problem 0
+                      float* ws, int ln, hipStream_t st,  // ln: scratch slot of problem 0
                       const std::function<int()>* after_latent = nullptr,  // called once the latents are enqueued
                       bool skip_output = false) {  // the reconstruction itself is not needed (only the saved activations)
-  const lshm_step_config& c = e->cfg;
-  const AEPlan& a0 = e->ae[idx[0]];
-  const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
-  float* part = ws + e->o_fpart + (size_t)ln * 2 * e->part_floats;  // a pair uses two adjacent scratch regions
-  const size_t pf = e->part_floats * (G > 1 ? 2 : 1);
-  int rc;
-  const float* in[2];
-  float* out[2];
-  for (int g = 0; g < G; ++g) in[g] = input[g];
-  auto A = [&](int g) -> const AEPlan& { return e->ae[idx[g]]; };
-  for (int i = 0; i < 6; ++i) {
-    ConvFwdIO io[2];
-    for (int g = 0; g < G; ++g) {
-      out[g] = (i < 5) ? ws + A(g).act[i] : ws + A(g).cat1;
-      io[g] = ConvFwdIO{in[g], prm + A(g).cw[i], prm + A(g).cb[i], out[g]};
-    }
-    if ((rc = conv_layer_fwd(a0.enc[i], io[0], 1, part, pf, st, G > 1 ? &io[1] : nullptr))) return rc;
-    for (int g = 0; g < G; ++g) in[g] = out[g];
-  }
-  LinFwdIO l[2];
-  auto lin = [&](long ldx, long ldy, int K, int N, int act) {
-    return linear_fwd(l[0], ldx, ldy, B, K, N, act, part, pf, st, G > 1 ? &l[1] : nullptr);
-  };
-  // (elu(fcuv1(uvh)) and elu(fcuv3(uvh)) are already in cat1 / cat3: three_forward's uv_features)
-  if (c.rica) {
-    for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat1, prm + A(g).fc1w, prm + A(g).fc1b, ws + A(g).z1};
-    if ((rc = lin(768 + hd, L, 768 + hd, L, 1))) return rc;
-    for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).z1, prm + A(g).fc2inw, prm + A(g).fc2inb, ws + e->o_Mu + A(g).mu_col};
-    if ((rc = lin(L, D, L, L, 1))) return rc;
-    for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + e->o_Mu + A(g).mu_col, prm + A(g).fc2outw, prm + A(g).fc2outb, ws + A(g).cat3};
-    if ((rc = lin(D, L + hd, L, L, 1))) return rc;
-  } else {
-    for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat1, prm + A(g).fc1w, prm + A(g).fc1b, ws + e->o_Mu + A(g).mu_col};
-    if ((rc = lin(768 + hd, D, 768 + hd, L, 1))) return rc;
-    for (int g = 0; g < G; ++g)
-      if ((rc = copy2d(ws + e->o_Mu + A(g).mu_col, D, ws + A(g).cat3, L + hd, B, L, st))) return rc;
-  }
-  if (after_latent && (rc = (*after_latent)())) return rc;
-  for (int g = 0; g < G; ++g) l[g] = LinFwdIO{ws + A(g).cat3, prm + A(g).fc3w, prm + A(g).fc3b, ws + A(g).d0};
-  if ((rc = lin(L + hd, 768, L + hd, 768, 0))) return rc;
-  for (int g = 0; g < G; ++g) in[g] = ws + A(g).d0;
-  for (int i = 0; i < (skip_output ? 5 : 6); ++i) {
-    ConvFwdIO io[2];
-    for (int g = 0; g < G; ++g) {
-      out[g] = (i < 5) ? ws + A(g).dact[i] : ws + A(g).out;
-      io[g] = ConvFwdIO{in[g], prm + A(g).tw[i], prm + A(g).tb[i], out[g]};
-    }
-    if ((rc = conv_layer_fwd(a0.dec[i], io[0], i < 5, part, pf, st, G > 1 ? &io[1] : nullptr))) return rc;
-    for (int g = 0; g < G; ++g) in[g] = out[g];
+  std::vector<FwdStep> steps;
+  size_t lm = 0, om = 0;
+  Src in[2];
+  for (int g = 0; g < G; ++g) in[g] = Src{input[g], 0};
+  ae_forward_steps(e, G, idx, prm, in, ln, steps, &lm, &om);
+  for (size_t i = 0; i < steps.size(); ++i) {
+    int rc;
+    if (i == lm && after_latent && (rc = (*after_latent)())) return rc;
+    if (i == om && skip_output) continue;
+    if ((rc = steps[i](ws, st))) return rc;
   }
   return LSHM_OK;
+}
+
+// The three forwards of the default (paired) schedule as one step list: harmonic features + the six layers fed by
+// them alone, the 2-D autoencoder, the residual split, netT and netF as paired launches.
+static void three_forward_steps(const lshm_engine* e, const float* prm, const float* x, const float* uv,
+                                std::vector<FwdStep>& steps, size_t* latent_mark, size_t* output1d_mark) {
+  const lshm_step_config& c = e->cfg;
+  steps.push_back([=](float* ws, hipStream_t st) -> int {
+    UvLayers ul;
+    ul.n = 0;
+    for (int a = 0; a < 3; ++a) {
+      const AEPlan& A = e->ae[a];
+      ul.w[ul.n] = prm + A.fcuv1w; ul.bias[ul.n] = prm + A.fcuv1b;
+      ul.out[ul.n] = ws + A.cat1 + 768; ul.ld[ul.n] = 768 + e->hdim; ++ul.n;
+      ul.w[ul.n] = prm + A.fcuv3w; ul.bias[ul.n] = prm + A.fcuv3b;
+      ul.out[ul.n] = ws + A.cat3 + A.L; ul.ld[ul.n] = A.L + e->hdim; ++ul.n;
+    }
+    return uv_features(uv, c.scales, c.H, c.B, ws + e->o_uvh, ul, st);
+  });
+  const int i0[1] = {0};
+  const Src in0[1] = {Src{x, 0}};
+  ae_forward_steps(e, 1, i0, prm, in0, 0, steps, nullptr, nullptr);
+  steps.push_back([=](float* ws, hipStream_t st) -> int {
+    return residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st, e->bf);
+  });
+  const int i12[2] = {1, 2};
+  const Src in12[2] = {Src{nullptr, e->o_row}, Src{nullptr, e->o_col}};
+  ae_forward_steps(e, 2, i12, prm, in12, 0, steps, latent_mark, output1d_mark);
 }
 
 // Backward of one (G == 1) or two same-shape (G == 2) autoencoders.  dz_out[g]: gradient w.r.t. the
@@ -396,6 +478,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   if ((rc = release(true))) return rc;
   if (side && (rc = grad_jobs_finish(jobs, wst))) return rc;
   // ---- encoder
+  bool fused_tail = false;  // a fused kernel on `st` wrote partials that the closing sums on `wst` have not been ordered behind yet
   for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_dcat1;
   for (int i = 5; i >= 0; --i) {
     ConvWgradIO wg[2];
@@ -407,14 +490,25 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       wg[g] = ConvWgradIO{xin, dz[g], grd + A(g).cw[i], grd + A(g).cb[i]};
       dg[g] = ConvDgradIO{dz[g], prm + A(g).cw[i], dx[g], i == 0 ? nullptr : xin};
     }
+    if (dx[0] && conv_layer_bwd_fusable(a0.enc[i], wg[0], dg[0]) && (G < 2 || conv_layer_bwd_fusable(a0.enc[i], wg[1], dg[1]))) {
+      // outer 1-D encoder layers: weight, bias and data gradient from one pass over dz and the saved input, on the
+      // data-gradient stream; their closing sums run on the other one, behind the "dz ready" event below
+      if ((rc = conv_layer_wgrad(a0.enc[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs, &dg[0],
+                                 G > 1 ? &dg[1] : nullptr))) return rc;
+      fused_tail = true;
+      for (int g = 0; g < G; ++g) dz[g] = dx[g];
+      continue;
+    }
     pending.push_back([&, i, w0 = wg[0], w1 = wg[1]]() {
       return conv_layer_wgrad(a0.enc[i], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
     });
     if ((rc = release(i <= 2))) return rc;
+    fused_tail = false;
     if (i == 0 && !dinput[0]) break;
     if ((rc = conv_layer_dgrad(a0.enc[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
+  if (fused_tail && (rc = dz_ready())) return rc;
   return grad_jobs_finish(jobs, wst);
 }
 
@@ -443,6 +537,18 @@ __global__ void finalize_terms_kernel(const double* __restrict__ scal, double* _
   terms[9] = (double)bad;
 }
 
+// the step list of the paired schedule for these (params, x, uv), built once and kept: the pointers of a trainer do
+// not change from call to call, and ~60 closures need not be re-made for every forward
+static const lshm_engine::FwdPlan& forward_plan(lshm_engine* e, const float* prm, const float* x, const float* uv) {
+  lshm_engine::FwdPlan& P = e->plan;
+  if (P.prm != prm || P.x != x || P.uv != uv || P.steps.empty()) {
+    P.steps.clear();
+    P.prm = prm; P.x = x; P.uv = uv;
+    three_forward_steps(e, prm, x, uv, P.steps, &P.latent_mark, &P.output1d_mark);
+  }
+  return P;
+}
+
 // skip_1d_output: the outputs of netT / netF are only consumed by the reconstruction pass; when that pass has
 // already been made for this forward (LSHM_STEP_RECON_READY) their last decoder layer is not run
 static int three_forward(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws,
@@ -451,6 +557,16 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   const lshm_step_config& c = e->cfg;
   int rc;
   e->recon_ready = false;  // a new forward: whatever reconstruction terms the workspace held are stale
+  if (e->pair_mode || !e->side_ok) {  // every launch of netT / netF carries both problems
+    const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
+    for (size_t i = 0; i < P.steps.size(); ++i) {
+      if (i == P.latent_mark && after_latents && (rc = (*after_latents)())) return rc;
+      if (i == P.output1d_mark && skip_1d_output) continue;
+      if ((rc = P.steps[i](ws, st))) return rc;
+    }
+    return LSHM_OK;
+  }
+  // LSHM_FORK=1: netT and netF on two streams side by side (no faster than paired launches since the reductions are deferred)
   {  // harmonic features + the six layers that depend on them alone (fcuv1 / fcuv3 of net, netT, netF)
     UvLayers ul;
     ul.n = 0;
@@ -469,12 +585,8 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
     if ((rc = ae_forward(e, 1, i0, prm, in0, ws, 0, st))) return rc;
   }
   if ((rc = residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st, e->bf))) return rc;
-  // the two 1-D autoencoders have identical shapes and are independent
   const int i12[2] = {1, 2};
   const float* in12[2] = {ws + e->o_row, ws + e->o_col};
-  if (e->pair_mode || !e->side_ok)  // every launch carries both problems
-    return ae_forward(e, 2, i12, prm, in12, ws, 0, st, after_latents, skip_1d_output);
-  // or: two streams side by side (LSHM_FORK=1; no faster than paired launches since the reductions are deferred)
   hipEvent_t evf = e->take_event();
   if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(e->wstream, evf, 0) != hipSuccess) {
     set_last_error("engine: stream fork failed");
@@ -488,6 +600,41 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
     return LSHM_ERR_ARG;
   }
   return after_latents ? (*after_latents)() : LSHM_OK;
+}
+
+// Two forwards of the same (params, x, uv) side by side: the host enqueues step k of the first on (ws_a, st_a), then
+// step k of the second on (ws_b, st_b), so neither stream runs dry while the other chain is being enqueued.
+// A forward alternates bandwidth-bound stretches (the outer layers, the residual split) with latency-bound ones
+// (mid / deep / dense layers: a few microseconds per launch on a fraction of the machine); in lock step like meets
+// like: the latency-bound stretches overlap almost for free, the bandwidth-bound ones share the HBM pipe.
+// LSHM_FORWARD_STAGGER=n holds the second chain n steps behind the first (its first launch waits for an event
+// after step n - 1 of the first), which pairs one chain's outer layers with the other's deep layers instead --
+// measured slower (see below).  The second forward does not need the reconstructions of netT / netF
+// (skip_b_1d_output).
+static int two_forwards(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws_a, hipStream_t st_a,
+                        float* ws_b, hipStream_t st_b, bool skip_b_1d_output) {
+  e->recon_ready = false;
+  const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
+  // default 0 (lock step, no gate).  Measured (profiles/r03/README.md): 0: 2.28 ms, 6: 2.32, 12: 2.39, 24: 2.49 -- a
+  // latency-bound launch beside a bandwidth-bound one is starved (up to 10x longer), so like phases belong together
+  static const int stagger_env = [] { const char* v = getenv("LSHM_FORWARD_STAGGER"); return v ? atoi(v) : 0; }();
+  const int n = (int)P.steps.size();
+  const int lead = stagger_env < 0 ? 0 : stagger_env > n ? n : stagger_env;
+  int rc;
+  for (int i = 0; i < n + lead; ++i) {
+    if (i < n && (rc = P.steps[i](ws_a, st_a))) return rc;
+    if (lead > 0 && i == lead - 1) {
+      hipEvent_t gate = e->take_event();
+      if (hipEventRecord(gate, st_a) != hipSuccess || hipStreamWaitEvent(st_b, gate, 0) != hipSuccess) {
+        set_last_error("engine: stream fork failed");
+        return LSHM_ERR_ARG;
+      }
+    }
+    const int j = i - lead;
+    if (j < 0 || ((size_t)j == P.output1d_mark && skip_b_1d_output)) continue;
+    if ((rc = P.steps[j](ws_b, st_b))) return rc;
+  }
+  return LSHM_OK;
 }
 
 // Latent-space terms (src/kharmonic_lofar.py:160-172): they need only the three latent codes, so
@@ -1071,16 +1218,16 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
       return LSHM_ERR_ARG;
     }
   }
-  int rc = three_forward(e, params, x, uv, fws, fst);
+  // concurrent: the no-grad forward on (fws, fst) and the next closure's forward (activations saved in the primary
+  // buffers; nothing reads its reconstructions of netT / netF -- the pass below takes them from the no-grad
+  // forward -- so their last decoder layer is not run), enqueued in lock step
+  int rc = concurrent ? two_forwards(e, params, x, uv, fws, fst, ws, st, true) : three_forward(e, params, x, uv, fws, fst);
   if (rc) return rc;
   rc = multiplier_update_recon(x, fws + e->ae[0].out, fws + e->ae[1].out, fws + e->ae[2].out, y1, y2, y3, c.rho,
                                c.B * c.C, c.P, reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
                                ws + e->o_gx2, ws + e->o_gx3c, ws + e->lane[0].o_part, fst, (float)(1.0 / world), e->bf);
   if (rc) return rc;
   if (concurrent) {
-    // the next closure's forward: activations saved in the primary buffers; nothing reads the reconstructions of
-    // netT / netF (the pass above took them from the no-grad forward), so their last decoder layer is not run
-    if ((rc = three_forward(e, params, x, uv, ws, st, nullptr, true))) return rc;
     hipEvent_t evj = e->take_event();
     if (hipEventRecord(evj, fst) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
       set_last_error("engine: stream join failed");

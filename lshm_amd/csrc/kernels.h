@@ -138,8 +138,14 @@ bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int 
                                    const float* small, const float* big);
 // fd (optional; the 8 -> 4 channel transposed layer only): the layer's data gradient in the same pass over `big`
 // and `small`: dx = ELU'(small) * conv(big, w), written to dx / dx2 (batch stride dx_bs)
-struct FusedDgrad { const float* w; const float* w2; float* dx; float* dx2; long dx_bs; };
+// dact: multiply by ELU'(saved input of the layer)
+struct FusedDgrad { const float* w; const float* w2; float* dx; float* dx2; long dx_bs; int dact = 1; };
 bool conv1d_bwd_fused_supported(int Cs, int Cb, int pad);
+// the general one-pass backward (conv1d_fused.hip): 12 / 8 and 8 / 4 channels, conv (pad 1) and transposed (pad 0)
+bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad);
+int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs,
+                      float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks,
+                      hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd);
 int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
                         int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16 = 0,
@@ -177,6 +183,12 @@ size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb);
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
                         hipStream_t st, GradJobs* defer = nullptr, int big_bf16 = 0);
+
+// one-pass backward (data + weight + bias gradient) of the outermost 2-D decoder layer (8 -> 4 channels)
+bool tconv2d_bwd_fused_supported(int Cs, int Cb, int Hs, int Ws);
+int tconv2d_bwd_fused(const float* small, long s_bs, const float* big, long big_bs, const float* w, float* dsmall, int dact,
+                      float* dw, float* db, int B, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
+                      GradJobs* defer = nullptr, int big_bf16 = 0);
 
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,

@@ -227,10 +227,17 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
 }
 
 bool conv_layer_bwd_fusable(const ConvLayer& L, const ConvWgradIO& io, const ConvDgradIO& dio) {
-  if (getenv("LSHM_BWD_FUSED_OFF") || L.kind != 3 || !transposed(L)) return false;
-  // the ELU' reference of the data gradient must be the layer's own input (it is, for every layer behind an ELU)
-  return conv1d_bwd_fused_supported(L.Cin, L.Cout, 0) && dio.dact_in == io.x && dio.dz == io.dz && L.in_bs % 4 == 0 &&
-         conv1d_wgrad_direct_supported(L.Cin, L.Cout, L.Win);
+  if (getenv("LSHM_BWD_FUSED_OFF") || L.kind == 0 || !dio.dx || dio.dz != io.dz || L.in_bs % 4 != 0) return false;
+  // the ELU' reference of the data gradient, if any, must be the layer's own input (it is, for every layer behind an ELU)
+  if (dio.dact_in && dio.dact_in != io.x) return false;
+  if (L.kind == 1)  // 2-D transposed: the outermost decoder layer (8 -> 4 channels)
+    return !getenv("LSHM_BWD_FUSED2D_OFF") && !L.in_bf16 && tconv2d_bwd_fused_supported(L.Cin, L.Cout, L.Hin, L.Win);
+  if (L.kind == 3)  // transposed: small = the layer's input, big = dz
+    return conv1d_bwd_fused_supported(L.Cin, L.Cout, 0) && (dio.dact_in || conv1d_bwd_fused2_supported(L.Cin, L.Cout, 0)) &&
+           conv1d_wgrad_direct_supported(L.Cin, L.Cout, L.Win);
+  int Ho, Wo;
+  conv_out_dims(L, Ho, Wo);  // conv: small = dz, big = the layer's input
+  return conv1d_bwd_fused2_supported(L.Cout, L.Cin, 1) && conv1d_wgrad_direct_supported(L.Cout, L.Cin, Wo);
 }
 
 int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_t ws_floats, int accumulate,
@@ -263,8 +270,15 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
   const int big_bf16 = tr ? L.out_bf16 : L.in_bf16;
   if ((tr ? L.in_bf16 : L.out_bf16)) return bf16_unsupported();  // `small` side: never stored as bf16
   if (L.kind < 2) {
-    if (fuse) { set_last_error("conv wgrad: fused data gradient not available for this layer"); return LSHM_ERR_UNSUPPORTED; }
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
+    if (fuse) {
+      if (!tr || io2 || !tconv2d_bwd_fused_supported(Cs, Cb, Hs, Ws) || gemm_wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
+        set_last_error("conv wgrad: fused data gradient not available for this layer");
+        return LSHM_ERR_UNSUPPORTED;
+      }
+      return tconv2d_bwd_fused(io.x, s_bs, io.dz, big_bs, fuse->w, fuse->dx, fuse->dact_in ? 1 : 0, io.dw, io.db, L.B, Hs, Ws,
+                               gemm_ws, gemm_wsf, accumulate, st, defer, big_bf16);
+    }
     if (!io2 && conv2d_wgrad_direct_supported(Cs, Cb, Hs, Ws) &&
         gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
       // weight and bias gradient in one pass (dz is `big` for the transposed conv, `small` otherwise)
@@ -293,7 +307,8 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
     if (stream_ok) {
       // weight and bias gradient in one pass (dz is `big` for the transposed conv, `small` otherwise)
       FusedDgrad fd{};
-      if (fuse) fd = FusedDgrad{fuse->w, fuse2 ? fuse2->w : nullptr, fuse->dx, fuse2 ? fuse2->dx : nullptr, L.in_bs};
+      if (fuse) fd = FusedDgrad{fuse->w, fuse2 ? fuse2->w : nullptr, fuse->dx, fuse2 ? fuse2->dx : nullptr, L.in_bs,
+                                fuse->dact_in ? 1 : 0};
       return conv1d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.Cout, L.B, Cs,
                                  Cb, Ls, Lb, tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st,
                                  io2 ? small_of(*io2) : nullptr, io2 ? big_of(*io2) : nullptr,

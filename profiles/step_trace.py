@@ -12,12 +12,10 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 for r in rows:
     r['Kernel_Name'] = short(r['Kernel_Name']) if r['Kernel_Name'].strip('"').startswith('_ZN4lshm') else r['Kernel_Name']
 idx = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
-mu = [i for i, r in enumerate(rows) if 'multiplier_update_kernel' in r['Kernel_Name'] or 'recon_kernel<true' in r['Kernel_Name']]
-if 'recon_kernel<true' in rows[mu[-1]]['Kernel_Name']:  # the shared pass is followed by its 7-way sum
-    mu = [i + 1 for i in mu]
-# a step = everything after the previous multiplier_update up to and including this one
-end = mu[-1] + 1
-start = mu[-2] + 1
+# a step = one Adam update and everything up to the next one (round 3: the closure forward of iteration k+1 starts
+# beside the no-grad forward of iteration k, so the listing runs Adam -> [two forwards] -> reconstruction pass ->
+# backward; the wall time between two Adam launches is the iteration time)
+start, end = idx[-3], idx[-2]
 last = rows[start:end]
 t0 = int(last[0]['Start_Timestamp'])
 qkey = 'Queue_Id' if 'Queue_Id' in last[0] else 'Stream_Id'
@@ -32,7 +30,7 @@ for r in last:
     else:
         cur_e = max(cur_e, e)
 busy_union += cur_e - cur_s
-wall = int(last[-1]['End_Timestamp']) - t0
+wall = int(rows[end]['Start_Timestamp']) - t0
 print(f"# step wall {wall/1e3:.1f} us, {len(last)} kernels, device busy (union) {busy_union/1e3:.1f} us, "
       f"sum {sum(int(r['End_Timestamp'])-int(r['Start_Timestamp']) for r in last)/1e3:.1f} us")
 for r in last:

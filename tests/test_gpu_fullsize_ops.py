@@ -144,3 +144,60 @@ def test_dense_layers_at_full_batch(K, N, act):
     L.check(lib.lshm_linear_wgrad(L.ptr(xd), K, L.ptr(dzd), N, L.ptr(dw), L.ptr(db), B, K, N, L.ptr(ws), nws, st))
     assert rel_err(dw, dz.double().t() @ x.double()) < 5e-5
     assert rel_err(db, dz.double().sum(0)) < 5e-5
+
+
+@pytest.mark.parametrize("kind,i,elu_grad", [(3, 5, 1), (3, 4, 1), (2, 1, 1), (2, 0, 0), (2, 0, 1), (3, 5, 0), (1, 5, 1), (1, 5, 0)],
+                         ids=["tconv5", "tconv4", "conv1", "conv0", "conv0-elu", "tconv5-noelu", "2d-tconv5", "2d-tconv5-noelu"])
+def test_one_pass_backward_of_outer_layers(kind, i, elu_grad):
+    """lshm_conv_bwd_fused (weight + bias + data gradient from one read of dz and the saved input; backward of
+    src/lofar_models.py:115-117,140-142) against the pair of kernels it replaces (lshm_conv_wgrad + lshm_conv_dgrad)
+    and against fp64, at B = 256: the weight / bias gradients come from the same MFMA sequence as the stand-alone
+    weight-gradient kernel (fp32 rounding apart: the pad-1 windows are assembled from other loads), the data
+    gradient agrees to fp32 rounding."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    ishape, wshape, cin, cout = _shapes(kind, i)
+    g = torch.Generator().manual_seed(31 * kind + i)
+    x = TF.elu(torch.randn(ishape, generator=g))  # the saved input of a layer behind an ELU
+    fan = (cout if kind in (1, 3) else cin) * (16 if kind < 2 else 4)
+    w = torch.randn(wshape, generator=g) * (3.0 / fan) ** 0.5
+    if kind < 2:
+        Hin, Win = ishape[2], ishape[3]
+        dz = torch.randn(B, cout, 2 * Hin, 2 * Win, generator=g)
+    else:
+        Hin, Win = 1, ishape[2]
+        dz = torch.randn(B, cout, Win * 4 if kind == 3 else Win // 4, generator=g)
+    xd, wd, dzd = x.to(DEV), w.to(DEV), dz.to(DEV)
+    nws = lib.lshm_conv_workspace_floats(kind, B, cin, cout, Hin, Win)
+    ws = torch.empty(nws, device=DEV)
+    st = L.stream()
+    dw, db, dx = torch.empty(wshape, device=DEV), torch.empty(cout, device=DEV), torch.full(ishape, float("nan"), device=DEV)
+    L.check(lib.lshm_conv_bwd_fused(kind, L.ptr(xd), L.ptr(dzd), L.ptr(wd), L.ptr(dw), L.ptr(db), L.ptr(dx), elu_grad, B, cin,
+                                    cout, Hin, Win, L.ptr(ws), nws, st), "conv_bwd_fused")
+    dw2, db2, dx2 = torch.empty_like(dw), torch.empty_like(db), torch.empty_like(dx)
+    L.check(lib.lshm_conv_wgrad(kind, L.ptr(xd), L.ptr(dzd), L.ptr(dw2), L.ptr(db2), B, cin, cout, Hin, Win, 0, 0, L.ptr(ws),
+                                nws, 0, st), "conv_wgrad")
+    L.check(lib.lshm_conv_dgrad(kind, L.ptr(dzd), L.ptr(wd), L.ptr(dx2), L.ptr(xd) if elu_grad else None, B, cin, cout, Hin,
+                                Win, 0, 0, L.ptr(ws), nws, st), "conv_dgrad")
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx).all()
+    assert rel_err(dw, dw2) < 2e-6 and rel_err(db, db2) < 2e-6
+    assert rel_err(dx, dx2) < 2e-6
+    # fp64: whole batch for the parameter gradients, five samples for the data gradient
+    wref = w.double().requires_grad_(True)
+    bref = torch.zeros(cout, dtype=torch.float64, requires_grad=True)
+    xs = x.double().requires_grad_(True)
+    _ref_layer(kind, xs, wref, bref).backward(dz.double())
+    assert rel_err(dw, wref.grad) < 1e-4 and rel_err(db, bref.grad) < 1e-4
+    sv = x[list(SAMPLES)].double()
+    dxref = xs.grad[list(SAMPLES)] * (torch.where(sv > 0, torch.ones_like(sv), sv + 1.0) if elu_grad else 1.0)
+    assert rel_err(dx[list(SAMPLES)], dxref) < 5e-5
+
+
+def test_one_pass_backward_refuses_other_layers():
+    from lshm_amd import _lib as L
+    lib = L.load()
+    t = torch.zeros(16, device=DEV)
+    rc = lib.lshm_conv_bwd_fused(2, L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), 1, 2, 24, 48, 1, 256, L.ptr(t), 16,
+                                 L.stream())
+    assert rc == -3 and b"one-pass" in lib.lshm_last_error_string()
