@@ -130,6 +130,16 @@ int lshm_conv_wgrad_bf16(int kind, const float* x, const float* dz, float* dw, f
 int lshm_conv_bwd_fused(int kind, const float* x, const float* dz, const float* w, float* dw, float* db, float* dx,
                         int elu_grad, int B, int Cin, int Cout, int Hin, int Win, float* workspace,
                         size_t workspace_floats, lshm_stream_t stream);
+/* Three consecutive k4 s4 1-D layers of AutoEncoder1DCNN's middle as ONE launch, the patch's activations resident in
+ * LDS from layer to layer (every layer's output is still written to out[k], once, coalesced):
+ *   up == 0: stride-4 conv direction, 12 -> 24 -> 48 -> 96 channels from 1024 positions: conv2 -> conv3 -> conv4
+ *            forward (pad = 1, act = 1; src/lofar_models.py:119-123) or the data gradients of tconv3 <- tconv2 <- tconv1
+ *            (pad = 0, act = 0, dact[k] = the saved input of that layer; :138-140 backward);
+ *   up != 0: transposed direction, 96 -> 48 -> 24 -> 12 channels from 16 positions: tconv1 -> tconv2 -> tconv3 forward
+ *            (pad = 0, act = 1) or the data gradients of conv4 <- conv3 <- conv2 (pad = 1, act = 0, dact[k]).
+ * w[k] / bias[k] (bias may be NULL) in the layers' own torch layouts; dact (NULL or 3 pointers): out[k] *= ELU'(dact[k]). */
+int lshm_conv1d_chain3(int up, const float* x, const float* const* w, const float* const* bias, float* const* out,
+                       const float* const* dact, int act, int pad, int B, lshm_stream_t stream);
 /* dz = gy * ELU'(y) from the saved output y                      (autograd of F.elu) */
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t stream);
 

@@ -158,6 +158,29 @@ int lshm_conv_bwd_fused(int kind, const float* x, const float* dz, const float* 
   }
   return conv_layer_wgrad(L, io, ws, wsf, 0, ST(s), nullptr, nullptr, &dio);
 }
+int lshm_conv1d_chain3(int up, const float* x, const float* const* w, const float* const* bias, float* const* out,
+                       const float* const* dact, int act, int pad, int B, lshm_stream_t s) {
+  REQUIRE(x && w && out && B > 0 && (pad == 0 || pad == 1), "conv1d_chain3: bad argument");
+  const int chd[4] = {12, 24, 48, 96}, chu[4] = {96, 48, 24, 12};
+  if (!conv1d_chain_supported(up != 0, up ? chu : chd, up ? 16 : 1024)) {
+    set_last_error("conv1d_chain3: chains are switched off (LSHM_CHAIN_OFF)");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  Chain1dStage st[3];
+  long L = up ? 16 : 1024;
+  for (int k = 0; k < 3; ++k) {
+    REQUIRE(w[k] && out[k], "conv1d_chain3: null stage pointer");
+    L = up ? 4 * L : L / 4;
+    const int c = up ? chu[k + 1] : chd[k + 1];
+    st[k].w[0] = st[k].w[1] = w[k];
+    st[k].bias[0] = st[k].bias[1] = bias ? bias[k] : nullptr;
+    st[k].out[0] = st[k].out[1] = out[k];
+    st[k].dact[0] = st[k].dact[1] = dact ? dact[k] : nullptr;
+    st[k].out_bs = (long)c * L;
+    st[k].act = act;
+  }
+  return conv1d_chain(up != 0, st, x, nullptr, up ? 96L * 16 : 12L * 1024, pad, B, ST(s));
+}
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t s) {
   REQUIRE(gy && y && dz && n >= 0, "elu_bwd: bad argument");
   if (n == 0) return LSHM_OK;

@@ -270,7 +270,7 @@ bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
   // 12 / 8 channels: 96 accumulator registers + the data-gradient working set do not fit two wavefronts per SIMD
   // (the compiler spills 80-330 registers; 67-129 us against 50 us for the two separate kernels, profiles/r03):
   // opt-in only (LSHM_FUSED2_12_8=1) until those layers get an LDS-staged form
-  static const bool wide = getenv("LSHM_FUSED2_12_8") != nullptr;
+  const bool wide = getenv("LSHM_FUSED2_12_8") != nullptr;  // read per call: the parity tests switch it on for two cases
   return (wide && Cs == 12 && Cb == 8 && (pad == 0 || pad == 1)) || (Cs == 8 && Cb == 4 && (pad == 0 || pad == 1));
 }
 

@@ -236,7 +236,31 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   const size_t pf = e->part_floats * (G > 1 ? 2 : 1);
   const size_t o_part = e->o_fpart + (size_t)ln * 2 * e->part_floats;  // a pair uses two adjacent scratch regions
   auto A = [e, i0, i1](int g) -> const AEPlan& { return e->ae[g ? i1 : i0]; };
-  for (int i = 0; i < 6; ++i)
+  // mid layers of the 1-D autoencoders as LDS-resident chains (chain1d.hip): conv2 -> conv3 -> conv4 and
+  // tconv1 -> tconv2 -> tconv3, one launch each instead of three
+  const AEPlan& a0 = e->ae[i0];
+  const int chd[4] = {a0.enc[2].Cin, a0.enc[2].Cout, a0.enc[3].Cout, a0.enc[4].Cout};
+  const int chu[4] = {a0.dec[1].Cin, a0.dec[1].Cout, a0.dec[2].Cout, a0.dec[3].Cout};
+  const bool chain_dn = a0.ndim == 1 && conv1d_chain_supported(false, chd, a0.enc[2].Win);
+  const bool chain_up = a0.ndim == 1 && conv1d_chain_supported(true, chu, a0.dec[1].Win);
+  for (int i = 0; i < 6; ++i) {
+    if (chain_dn && i == 2) {
+      steps.push_back([=](float* ws, hipStream_t st) -> int {
+        Chain1dStage cs[3];
+        for (int k = 0; k < 3; ++k) {
+          for (int g = 0; g < 2; ++g) {
+            const AEPlan& a = A(g < G ? g : 0);
+            cs[k].w[g] = prm + a.cw[2 + k]; cs[k].bias[g] = prm + a.cb[2 + k];
+            cs[k].out[g] = ws + a.act[2 + k]; cs[k].dact[g] = nullptr;
+          }
+          cs[k].out_bs = A(0).enc[2 + k].out_bs;
+          cs[k].act = 1;
+        }
+        return conv1d_chain(false, cs, ws + A(0).act[1], G > 1 ? ws + A(1).act[1] : nullptr, A(0).enc[2].in_bs, 1, B, st);
+      });
+      i = 4;
+      continue;
+    }
     steps.push_back([=](float* ws, hipStream_t st) -> int {
       ConvFwdIO io[2];
       for (int g = 0; g < G; ++g) {
@@ -246,6 +270,7 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
       }
       return conv_layer_fwd(A(0).enc[i], io[0], 1, ws + o_part, pf, st, G > 1 ? &io[1] : nullptr);
     });
+  }
   // dense layers: (input offset, weight, bias, output offset) per problem; offsets relative to the workspace
   struct Lin { size_t x[2], y[2]; long w[2], b[2]; long ldx, ldy; int K, N, act; };
   auto lin = [&](const Lin& q) {
@@ -284,6 +309,23 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   }
   for (int i = 0; i < 6; ++i) {
     if (i == 5 && output_mark) *output_mark = steps.size();
+    if (chain_up && i == 1) {
+      steps.push_back([=](float* ws, hipStream_t st) -> int {
+        Chain1dStage cs[3];
+        for (int k = 0; k < 3; ++k) {
+          for (int g = 0; g < 2; ++g) {
+            const AEPlan& a = A(g < G ? g : 0);
+            cs[k].w[g] = prm + a.tw[1 + k]; cs[k].bias[g] = prm + a.tb[1 + k];
+            cs[k].out[g] = ws + a.dact[1 + k]; cs[k].dact[g] = nullptr;
+          }
+          cs[k].out_bs = A(0).dec[1 + k].out_bs;
+          cs[k].act = 1;
+        }
+        return conv1d_chain(true, cs, ws + A(0).dact[0], G > 1 ? ws + A(1).dact[0] : nullptr, A(0).dec[1].in_bs, 0, B, st);
+      });
+      i = 3;
+      continue;
+    }
     steps.push_back([=](float* ws, hipStream_t st) -> int {
       ConvFwdIO io[2];
       for (int g = 0; g < G; ++g) {
@@ -395,8 +437,43 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   };
   const float* dz[2];
   for (int g = 0; g < G; ++g) dz[g] = dz_out[g];
+  // the mid layers of the 1-D autoencoders: data gradients of three layers as one LDS-resident chain (chain1d.hip)
+  const int chd[4] = {a0.dec[3].Cout, a0.dec[3].Cin, a0.dec[2].Cin, a0.dec[1].Cin};  // tconv3 <- tconv2 <- tconv1: stride-4 conv direction
+  const int chu[4] = {a0.enc[4].Cout, a0.enc[4].Cin, a0.enc[3].Cin, a0.enc[2].Cin};  // conv4 -> conv3 -> conv2: transposed direction
+  static const bool chain_bwd = getenv("LSHM_CHAIN_BWD_OFF") == nullptr;
+  const bool chain_dec = chain_bwd && a0.ndim == 1 && conv1d_chain_supported(false, chd, a0.dec[3].Win * 4);
+  const bool chain_enc = chain_bwd && a0.ndim == 1 && conv1d_chain_supported(true, chu, a0.enc[4].Win / 4);
   // ---- decoder, last layer first
   for (int i = 5; i >= 0; --i) {
+    if (chain_dec && i == 3) {
+      // dz of tconv3 (12 channels) -> gradients w.r.t. the inputs of tconv3, tconv2, tconv1, each multiplied by ELU' of
+      // that (saved) input; the three weight gradients follow on the other stream once the chain has written their dz
+      Chain1dStage cs[3];
+      for (int k = 0; k < 3; ++k) {  // stage k: layer 3 - k
+        for (int g = 0; g < 2; ++g) {
+          const int gg = g < G ? g : 0;
+          cs[k].w[g] = prm + A(gg).tw[3 - k]; cs[k].bias[g] = nullptr;
+          cs[k].out[g] = ws + LA(gg).o_gdec[3 - k]; cs[k].dact[g] = ws + A(gg).dact[2 - k];
+        }
+        cs[k].out_bs = a0.dec[3 - k].in_bs;
+        cs[k].act = 0;
+      }
+      const float* dzin[2] = {dz[0], G > 1 ? dz[1] : nullptr};
+      for (int k = 0; k < 3; ++k) {
+        const int li = 3 - k;
+        ConvWgradIO w0{ws + A(0).dact[li - 1], k == 0 ? dzin[0] : ws + LA(0).o_gdec[li + 1], grd + A(0).tw[li], grd + A(0).tb[li]};
+        ConvWgradIO w1 = w0;
+        if (G > 1) w1 = ConvWgradIO{ws + A(1).dact[li - 1], k == 0 ? dzin[1] : ws + LA(1).o_gdec[li + 1], grd + A(1).tw[li], grd + A(1).tb[li]};
+        pending.push_back([&, li, w0, w1]() {
+          return conv_layer_wgrad(a0.dec[li], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
+        });
+      }
+      if ((rc = conv1d_chain(false, cs, dzin[0], dzin[1], a0.dec[3].out_bs, 0, B, st))) return rc;
+      if ((rc = release(true))) return rc;
+      for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_gdec[1];
+      i = 1;
+      continue;
+    }
     ConvWgradIO wg[2];
     ConvDgradIO dg[2];
     float* dx[2];
@@ -481,6 +558,35 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   bool fused_tail = false;  // a fused kernel on `st` wrote partials that the closing sums on `wst` have not been ordered behind yet
   for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_dcat1;
   for (int i = 5; i >= 0; --i) {
+    if (chain_enc && i == 4) {
+      // dz of conv4 (96 channels) -> gradients w.r.t. the inputs of conv4, conv3, conv2 (x ELU' of the saved inputs)
+      Chain1dStage cs[3];
+      for (int k = 0; k < 3; ++k) {  // stage k: layer 4 - k
+        for (int g = 0; g < 2; ++g) {
+          const int gg = g < G ? g : 0;
+          cs[k].w[g] = prm + A(gg).cw[4 - k]; cs[k].bias[g] = nullptr;
+          cs[k].out[g] = ws + LA(gg).o_genc[4 - k]; cs[k].dact[g] = ws + A(gg).act[3 - k];
+        }
+        cs[k].out_bs = a0.enc[4 - k].in_bs;
+        cs[k].act = 0;
+      }
+      const float* dzin[2] = {dz[0], G > 1 ? dz[1] : nullptr};
+      for (int k = 0; k < 3; ++k) {
+        const int li = 4 - k;
+        ConvWgradIO w0{ws + A(0).act[li - 1], k == 0 ? dzin[0] : ws + LA(0).o_genc[li + 1], grd + A(0).cw[li], grd + A(0).cb[li]};
+        ConvWgradIO w1 = w0;
+        if (G > 1) w1 = ConvWgradIO{ws + A(1).act[li - 1], k == 0 ? dzin[1] : ws + LA(1).o_genc[li + 1], grd + A(1).cw[li], grd + A(1).cb[li]};
+        pending.push_back([&, li, w0, w1]() {
+          return conv_layer_wgrad(a0.enc[li], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
+        });
+      }
+      if ((rc = conv1d_chain(true, cs, dzin[0], dzin[1], a0.enc[4].out_bs, 1, B, st))) return rc;
+      if ((rc = release(true))) return rc;
+      fused_tail = false;
+      for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_genc[2];
+      i = 2;
+      continue;
+    }
     ConvWgradIO wg[2];
     ConvDgradIO dg[2];
     float* dx[2];

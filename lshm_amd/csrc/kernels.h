@@ -206,6 +206,22 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
                         const float* big2 = nullptr, float* dw2 = nullptr, float* db2 = nullptr,
                         GradJobs* defer = nullptr, int big_bf16 = 0, const FusedDgrad* fd = nullptr);
 
+// ---- LDS-resident chains of three k4 s4 1-D layers (chain1d.hip) -------------------------------
+// one stage: weights, optional bias, global output (B, Cout, Lout) and either ELU (act) or the ELU' multiply by the
+// saved activation of the output's shape (dact); [2]: the two problems of a paired launch
+struct Chain1dStage {
+  const float* w[2];
+  const float* bias[2];
+  float* out[2];
+  const float* dact[2];
+  long out_bs;
+  int act;
+};
+// up == false: stride-4 conv direction, channels ch[0..3] from L0 positions (forward of conv2..4: pad 1; data gradient
+// of tconv3..1: pad 0); up == true: transposed direction (forward of tconv1..3: pad 0; data gradient of conv4..2: pad 1)
+bool conv1d_chain_supported(bool up, const int* ch, int L0);
+int conv1d_chain(bool up, const Chain1dStage* st, const float* in0, const float* in1, long in_bs, int pad, int B, hipStream_t s);
+
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
 struct ConvLayer {

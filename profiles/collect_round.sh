@@ -5,12 +5,12 @@
 # gpurun_out/<round>/out; copy the latter to profiles/<round>/ afterwards.  PMC passes are separate runs with
 # --kernel-trace only (FETCH_SIZE and WRITE_SIZE cannot share a pass).
 set -o pipefail
-R=${1:-r02}
+R=${1:-r03}
 OUT=gpurun_out/$R/out
 RAW=gpurun_out/$R/raw
 mkdir -p $OUT $RAW
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-STEP="--steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-reuse-mode --no-lbfgs --no-rica"
+STEP="--steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-reuse-mode --no-lbfgs --no-rica --no-extra-modes"
 # PART=a: items 1-4, PART=b: items 5-7 (a gpurun call is limited to 20 minutes); default both
 PART=${PART:-ab}
 if [[ $PART == *a* ]]; then
@@ -31,14 +31,18 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $RAW/pmc_bf16_$C --output-format csv -- python3 bench.py $STEP --bf16 > /dev/null 2> $RAW/pmc_bf16_$C.err
 done
 python3 profiles/pmc_traffic.py $OUT/hbm_traffic.json step:$RAW/pmc_step_FETCH_SIZE:$RAW/pmc_step_WRITE_SIZE \
-  khm_N1048576_K10:$RAW/pmc_khm10_FETCH_SIZE:$RAW/pmc_khm10_WRITE_SIZE khm_N1048576_K64:$RAW/pmc_khm64_FETCH_SIZE:$RAW/pmc_khm64_WRITE_SIZE
-python3 profiles/pmc_traffic.py $OUT/bf16_hbm_traffic.json step:$RAW/pmc_bf16_FETCH_SIZE:$RAW/pmc_bf16_WRITE_SIZE
+  khm_N1048576_K10:$RAW/pmc_khm10_FETCH_SIZE:$RAW/pmc_khm10_WRITE_SIZE khm_N1048576_K64:$RAW/pmc_khm64_FETCH_SIZE:$RAW/pmc_khm64_WRITE_SIZE \
+  step_bf16:$RAW/pmc_bf16_FETCH_SIZE:$RAW/pmc_bf16_WRITE_SIZE
 fi
 if [[ $PART == *b* ]]; then
 # 5. matrix-pipe utilisation per kernel of the step
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_BUSY_CYCLES --kernel-trace -d $RAW/pmc_mfma --output-format csv -- python3 bench.py $STEP > /dev/null 2> $RAW/pmc_mfma.err
 rocprofv3 --kernel-trace --stats -d $RAW/stepstats --output-format csv -- python3 bench.py $STEP > /dev/null 2> $RAW/stepstats.err
 python3 profiles/mfma_util.py $RAW/pmc_mfma $(ls $RAW/stepstats/*/*kernel_stats.csv | head -1) > $OUT/mfma_utilisation.txt
+# 5b. the same for BASELINE configs[2] (bf16 operands + storage)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_MFMA SQ_BUSY_CYCLES --kernel-trace -d $RAW/pmc_mfma_bf16 --output-format csv -- python3 bench.py $STEP --bf16 > /dev/null 2> $RAW/pmc_mfma_bf16.err
+rocprofv3 --kernel-trace --stats -d $RAW/stepstats_bf16 --output-format csv -- python3 bench.py $STEP --bf16 > /dev/null 2> $RAW/stepstats_bf16.err
+python3 profiles/mfma_util.py $RAW/pmc_mfma_bf16 $(ls $RAW/stepstats_bf16/*/*kernel_stats.csv | head -1) > $OUT/bf16_mfma_utilisation.txt
 # 6. BASELINE configs[2]: bf16 bench line + kernel statistics + timeline
 rocprofv3 --kernel-trace --stats -d $RAW/bf16 --output-format csv -- python3 bench.py --bf16 --no-cpu-baseline > $OUT/bf16_bench_output.json 2> $RAW/bf16.err
 cp $(ls $RAW/bf16/*/*kernel_stats.csv | head -1) $OUT/bf16_kernel_stats.csv

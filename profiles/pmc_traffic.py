@@ -40,9 +40,9 @@ for spec in sys.argv[2:]:
             out["kernels"][f"{k} @{label}"] = {"launches": len(fetch[k]), "FETCH_SIZE_KB": round(f), "WRITE_SIZE_KB": round(w),
                                                "traffic_bytes_per_launch": int((2 * f + w) * 1024)}
         tot += (2 * sum(fetch[k]) * len(write[k]) / len(fetch[k]) + sum(write[k])) * 1024 if k in write else 0.0
-    if label == "step":
+    if label.startswith("step"):  # "step", "step_bf16", ...: one whole ADMM iteration of that configuration
         nsteps = len(fetch.get("adam_kernel", [])) or 1
-        out["step"] = {"iterations": nsteps, "traffic_bytes": int(tot / nsteps),
+        out[label] = {"iterations": nsteps, "traffic_bytes": int(tot / nsteps),
                        "note": "every launch of the run (warm-up included) / adam_kernel launches"}
 json.dump(out, open(sys.argv[1], "w"), indent=1)
 print(f"{len(out['kernels'])} kernel entries -> {sys.argv[1]}")

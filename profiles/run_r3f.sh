@@ -1,0 +1,25 @@
+#!/bin/bash
+O=gpurun_out/r3f
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+timeout -k 10 300 python -m pytest tests/test_gpu_fullsize_ops.py -x -q -k "chain" > $O/pytest_chain.txt 2>&1
+rc=$?; echo "chain pytest rc=$rc"; tail -12 $O/pytest_chain.txt
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 900 python -m pytest tests/test_gpu_step.py tests/test_gpu_ops.py -x -q > $O/pytest.txt 2>&1
+rc=$?; echo "pytest rc=$rc"; tail -6 $O/pytest.txt
+if [ $rc -ge 124 ]; then exit $rc; fi
+Q="--no-extra-modes --no-roofline --no-cpu-baseline --no-lbfgs --no-rica --no-reuse-mode --steps 40 --warmup 5"
+run() { n=$1; shift
+  env "$@" timeout -k 10 200 python bench.py $Q > $O/b_$n.json 2>$O/b_$n.err || { tail -3 $O/b_$n.err; exit 1; }
+  python -c "
+import json
+d=json.load(open('$O/b_$n.json')); print('$n', d['ms_per_step'], d['value_with_log']['ms_per_step'])"
+}
+run chains X=1
+run nochain LSHM_CHAIN_OFF=1
+run chain_fwd_only LSHM_CHAIN_BWD_OFF=1
+STEP="--steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-reuse-mode --no-lbfgs --no-rica --no-extra-modes"
+timeout -k 10 300 rocprofv3 --kernel-trace -d $O/raw_step --output-format csv -- python3 bench.py $STEP > $O/step.json 2> $O/step.err || exit 1
+python3 profiles/step_trace.py $O/raw_step > $O/step_timeline.txt
+head -2 $O/step_timeline.txt; grep chain $O/step_timeline.txt | head
+rm -rf $O/raw_step

@@ -148,7 +148,7 @@ def test_dense_layers_at_full_batch(K, N, act):
 
 @pytest.mark.parametrize("kind,i,elu_grad", [(3, 5, 1), (3, 4, 1), (2, 1, 1), (2, 0, 0), (2, 0, 1), (3, 5, 0), (1, 5, 1), (1, 5, 0)],
                          ids=["tconv5", "tconv4", "conv1", "conv0", "conv0-elu", "tconv5-noelu", "2d-tconv5", "2d-tconv5-noelu"])
-def test_one_pass_backward_of_outer_layers(kind, i, elu_grad):
+def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, monkeypatch):
     """lshm_conv_bwd_fused (weight + bias + data gradient from one read of dz and the saved input; backward of
     src/lofar_models.py:115-117,140-142) against the pair of kernels it replaces (lshm_conv_wgrad + lshm_conv_dgrad)
     and against fp64, at B = 256: the weight / bias gradients come from the same MFMA sequence as the stand-alone
@@ -157,6 +157,8 @@ def test_one_pass_backward_of_outer_layers(kind, i, elu_grad):
     from lshm_amd import _lib as L
     lib = L.load()
     ishape, wshape, cin, cout = _shapes(kind, i)
+    if kind >= 2 and 12 in (cin, cout):
+        monkeypatch.setenv("LSHM_FUSED2_12_8", "1")  # the 12 / 8 channel form is opt-in (slower than the pair it replaces)
     g = torch.Generator().manual_seed(31 * kind + i)
     x = TF.elu(torch.randn(ishape, generator=g))  # the saved input of a layer behind an ELU
     fan = (cout if kind in (1, 3) else cin) * (16 if kind < 2 else 4)
@@ -201,3 +203,71 @@ def test_one_pass_backward_refuses_other_layers():
     rc = lib.lshm_conv_bwd_fused(2, L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), L.ptr(t), 1, 2, 24, 48, 1, 256, L.ptr(t), 16,
                                  L.stream())
     assert rc == -3 and b"one-pass" in lib.lshm_last_error_string()
+
+
+@pytest.mark.parametrize("mode", ["down-forward", "down-dgrad", "up-forward", "up-dgrad"])
+def test_three_layer_chain_matches_the_three_launches(mode):
+    """lshm_conv1d_chain3 (conv2 -> conv3 -> conv4 / tconv1 -> tconv2 -> tconv3 of AutoEncoder1DCNN and the data-gradient
+    chains through the same layers, activations resident in LDS, src/lofar_models.py:119-123,138-140) against the three
+    separate launches it replaces and against fp64, B = 256: every stage's output."""
+    import ctypes as C
+    from lshm_amd import _lib as L
+    lib = L.load()
+    up = mode.startswith("up")
+    fwd = mode.endswith("forward")
+    g = torch.Generator().manual_seed({"down-forward": 1, "down-dgrad": 2, "up-forward": 3, "up-dgrad": 4}[mode])
+    ch = (96, 48, 24, 12) if up else (12, 24, 48, 96)
+    Ls = [16, 64, 256, 1024] if up else [1024, 256, 64, 16]
+    # forward: conv (down) / tconv (up) layers; dgrad: the data gradient of tconv (down direction) / conv (up direction)
+    kind = (3 if up else 2) if fwd else (2 if up else 3)
+    x = torch.randn(B, ch[0], Ls[0], generator=g)
+    ws_, bs_, saved = [], [], []
+    for k in range(3):
+        cin, cout = ch[k], ch[k + 1]
+        if fwd:
+            shape = (cin, cout, 4) if up else (cout, cin, 4)
+        else:  # the layer whose data gradient this stage is maps ch[k+1] -> ch[k] channels
+            shape = (ch[k], ch[k + 1], 4) if up else (ch[k + 1], ch[k], 4)
+        ws_.append(torch.randn(shape, generator=g) * (3.0 / (4 * max(cin, cout))) ** 0.5)
+        bs_.append(torch.randn(cout, generator=g) * 0.1)
+        saved.append(TF.elu(torch.randn(B, cout, Ls[k + 1], generator=g)))
+    xd = x.to(DEV)
+    wd, bd, sd = [t.to(DEV) for t in ws_], [t.to(DEV) for t in bs_], [t.to(DEV) for t in saved]
+    outs = [torch.full((B, ch[k + 1], Ls[k + 1]), float("nan"), device=DEV) for k in range(3)]
+    arr = lambda ts: (C.c_void_p * 3)(*[t.data_ptr() for t in ts])
+    pad = (0 if up else 1) if fwd else (1 if up else 0)
+    L.check(lib.lshm_conv1d_chain3(int(up), L.ptr(xd), arr(wd), arr(bd) if fwd else None, arr(outs), None if fwd else arr(sd),
+                                   int(fwd), pad, B, L.stream()), "conv1d_chain3")
+    torch.cuda.synchronize()
+    # the separate launches
+    cur = xd
+    for k in range(3):
+        ref = torch.empty_like(outs[k])
+        if fwd:
+            cin, cout, Lin = ch[k], ch[k + 1], Ls[k]
+            nws = lib.lshm_conv_workspace_floats(kind, B, cin, cout, 1, Lin)
+            wsb = torch.empty(max(nws, 1), device=DEV)
+            L.check(lib.lshm_conv_fwd(kind, L.ptr(cur), L.ptr(wd[k]), L.ptr(bd[k]), L.ptr(ref), B, cin, cout, 1, Lin, 0, 0, 1,
+                                      L.ptr(wsb), nws, L.stream()))
+        else:  # data gradient of the layer (ch[k+1] -> ch[k] channels, input length Ls[k+1])
+            cin, cout, Lin = ch[k + 1], ch[k], Ls[k + 1]
+            nws = lib.lshm_conv_workspace_floats(kind, B, cin, cout, 1, Lin)
+            wsb = torch.empty(max(nws, 1), device=DEV)
+            L.check(lib.lshm_conv_dgrad(kind, L.ptr(cur), L.ptr(wd[k]), L.ptr(ref), L.ptr(sd[k]), B, cin, cout, 1, Lin, 0, 0,
+                                        L.ptr(wsb), nws, L.stream()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(outs[k]).all(), (mode, k)
+        assert rel_err(outs[k], ref) < 2e-6, (mode, k)
+        cur = ref
+    # fp64 on five samples
+    cur = x[list(SAMPLES)].double()
+    for k in range(3):
+        if fwd:
+            y = TF.elu(_ref_layer(kind, cur, ws_[k].double(), bs_[k].double()))
+        else:
+            xin = torch.zeros(len(SAMPLES), ch[k + 1], Ls[k + 1], dtype=torch.float64, requires_grad=True)
+            _ref_layer(kind, xin, ws_[k].double(), None).backward(cur)
+            sv = saved[k][list(SAMPLES)].double()
+            y = xin.grad * torch.where(sv > 0, torch.ones_like(sv), sv + 1.0)
+        assert rel_err(outs[k][list(SAMPLES)], y) < 2e-5, (mode, k)
+        cur = y.detach()
