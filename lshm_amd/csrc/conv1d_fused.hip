@@ -30,7 +30,7 @@ struct FusedBwd1dArgs {
   const void* big[2];
   const float* w[2];       // [CS][CB][4] (Conv1d: (Cout, Cin, 4); ConvTranspose1d: (Cin, Cout, 4))
   float* partial[2];       // one slab of CS*CB*4 + 16 floats per workgroup
-  void* dout[2];           // conv layer: gradient w.r.t. big (element type of big); transposed: w.r.t. small (float)
+  void* dout[2];           // conv layer: gradient w.r.t. big (element type of big); transposed: w.r.t. small (element type of small)
   long s_bs, big_bs, d_bs;
   int Ls, Lb, ntiles;
 };
@@ -46,7 +46,7 @@ __device__ __forceinline__ float quad_dpp(float v) {
 // two wavefronts per SIMD (at most 256 registers, accumulators included): with one, nothing hides the latency of a
 // tile's loads but the next tile's prefetch; the 12 / 8 kernels keep 96 accumulator registers and therefore do
 // NOT hold a second tile in registers (PF == false) -- the other wavefront of the SIMD covers the wait instead
-template <int CS, int CB, bool CONV, bool DACT, bool WLDS, class TB>
+template <int CS, int CB, bool CONV, bool DACT, bool WLDS, class TB, class TS = float>  // TB / TS: element types of `big` / `small`
 __global__ __launch_bounds__(256, 2) void conv1d_bwd_fused2_kernel(const FusedBwd1dArgs a) {
   constexpr bool PF = CS <= 8;
   constexpr int GA = CS / 4, GB = CB / 4;
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_bwd_fused2_kernel(const FusedBw
   __shared__ float comb[4][SLAB];
   __shared__ f32x4 wl[WLDS ? 4 * WSTR : 1];
   const int pr = blockIdx.y;
-  const float* __restrict__ small = a.small[pr];
+  const TS* __restrict__ small = reinterpret_cast<const TS*>(a.small[pr]);
   const TB* __restrict__ big = reinterpret_cast<const TB*>(a.big[pr]);
   const float* __restrict__ w = a.w[pr];
   float* __restrict__ partial = a.partial[pr];
@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_bwd_fused2_kernel(const FusedBw
   float rx[GA], rm[GB];
   auto load_tile = [&](int tile) {
     const int b = tile / tiles_per, p0 = (tile - b * tiles_per) * 64 + 4 * slot;
-    const float* sb = small + (long)b * a.s_bs + p0;
+    const TS* sb = small + (long)b * a.s_bs + p0;
     const TB* bb = big + (long)b * a.big_bs + 4L * p0;
 #pragma unroll
     for (int x = 0; x < GA; ++x) {
-      ra[x] = *reinterpret_cast<const f32x4*>(sb + (long)(4 * x + q) * Ls);
-      if constexpr (CONV) rx[x] = p0 + 4 < Ls ? sb[(long)(4 * x + q) * Ls + 4] : 0.f;
+      ra[x] = Elem<TS>::ld4(sb + (long)(4 * x + q) * Ls);
+      if constexpr (CONV) rx[x] = p0 + 4 < Ls ? Elem<TS>::ld(sb + (long)(4 * x + q) * Ls + 4) : 0.f;
     }
 #pragma unroll
     for (int g = 0; g < GB; ++g) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_bwd_fused2_kernel(const FusedBw
           r2[m][st] = keep + quad_dpp<0x4E>(send);  // quad_perm [2,3,0,1]
         }
       }
-      float* dsm = reinterpret_cast<float*>(a.dout[pr]) + (long)b * a.d_bs + p0;
+      TS* dsm = reinterpret_cast<TS*>(a.dout[pr]) + (long)b * a.d_bs + p0;
 #pragma unroll
       for (int m = 0; m < GA; ++m) {
         f32x4 o = r2[m];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_bwd_fused2_kernel(const FusedBw
 #pragma unroll
           for (int st = 0; st < 4; ++st) o[st] *= elu_grad_from_out(ca[m][st]);
         }
-        *reinterpret_cast<f32x4*>(dsm + (long)(4 * m + q) * Ls) = o;
+        Elem<TS>::st4(dsm + (long)(4 * m + q) * Ls, o);
       }
     } else {
       // ---- data gradient of the conv layer: all-gather the small channels of one position over the quad, then this
@@ -277,13 +277,13 @@ bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
 // one slab of Cs*Cb*4 + 16 floats per workgroup at ws (and ws2 for the second problem); returns the grid size
 int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs,
                       float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks,
-                      hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd) {
+                      hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd, int small_bf16) {
   const bool two = small2 != nullptr;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!conv1d_bwd_fused2_supported(Cs, Cb, pad) || Ls % 64 || Lb != 4 * Ls || s_bs % 4 || big_bs % 4 || fd.dx_bs % 4 ||
       !fd.w || !fd.dx || !al16(small) || !al16(big) || !al16(fd.w) || !al16(fd.dx) ||
       (two && (!big2 || !fd.w2 || !fd.dx2 || !al16(small2) || !al16(big2) || !al16(fd.w2) || !al16(fd.dx2))) ||
-      (big_bf16 && !(Cs == 8 && Cb == 4))) {
+      (big_bf16 && !(Cs == 8 && Cb == 4)) || (small_bf16 && !big_bf16)) {
     set_last_error("conv1d_bwd_fused: unsupported layer shape, stride or alignment");
     return LSHM_ERR_UNSUPPORTED;
   }
@@ -303,17 +303,19 @@ int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const 
   *grid_out = grid;
   const dim3 g(grid, two ? 2 : 1);
   const bool dact = fd.dact != 0;
-#define LSHM_FUSED2(CS, CB, CONV, WL, T)                                                                            \
-  do {                                                                                                              \
-    if (dact) hipLaunchKernelGGL((conv1d_bwd_fused2_kernel<CS, CB, CONV, true, WL, T>), g, dim3(256), 0, st, a);    \
-    else hipLaunchKernelGGL((conv1d_bwd_fused2_kernel<CS, CB, CONV, false, WL, T>), g, dim3(256), 0, st, a);        \
+#define LSHM_FUSED2(CS, CB, CONV, WL, T, TS_)                                                                          \
+  do {                                                                                                                 \
+    if (dact) hipLaunchKernelGGL((conv1d_bwd_fused2_kernel<CS, CB, CONV, true, WL, T, TS_>), g, dim3(256), 0, st, a);  \
+    else hipLaunchKernelGGL((conv1d_bwd_fused2_kernel<CS, CB, CONV, false, WL, T, TS_>), g, dim3(256), 0, st, a);      \
   } while (0)
-  if (Cs == 12 && pad == 0) LSHM_FUSED2(12, 8, false, true, float);
-  else if (Cs == 12) LSHM_FUSED2(12, 8, true, true, float);
-  else if (pad == 0 && big_bf16) LSHM_FUSED2(8, 4, false, false, bf16);
-  else if (pad == 0) LSHM_FUSED2(8, 4, false, false, float);
-  else if (big_bf16) LSHM_FUSED2(8, 4, true, false, bf16);
-  else LSHM_FUSED2(8, 4, true, false, float);
+  if (Cs == 12 && pad == 0) LSHM_FUSED2(12, 8, false, true, float, float);
+  else if (Cs == 12) LSHM_FUSED2(12, 8, true, true, float, float);
+  else if (pad == 0 && big_bf16 && small_bf16) LSHM_FUSED2(8, 4, false, false, bf16, bf16);
+  else if (pad == 0 && big_bf16) LSHM_FUSED2(8, 4, false, false, bf16, float);
+  else if (pad == 0) LSHM_FUSED2(8, 4, false, false, float, float);
+  else if (big_bf16 && small_bf16) LSHM_FUSED2(8, 4, true, false, bf16, bf16);
+  else if (big_bf16) LSHM_FUSED2(8, 4, true, false, bf16, float);
+  else LSHM_FUSED2(8, 4, true, false, float, float);
 #undef LSHM_FUSED2
   return check_launch("conv1d_bwd_fused");
 }

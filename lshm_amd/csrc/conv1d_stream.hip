@@ -22,18 +22,19 @@ __device__ __forceinline__ float uniform_load(const float* q) { return *(cfloat_
 // upsampling direction: big[b, cb, 4j + t - pad] = bias[cb] + sum_cs small[b, cs, j] * w[cs, cb, t]
 //   pad = 0: forward of ConvTranspose1d(k4, s4);  pad = 1: data gradient of Conv1d(k4, s4, p1)
 // TO: element type of `big` (bf16 storage of the image-sized tensors, see common.h)
-template <int CS, int CB, bool PAD, class TO = float>
+// TS: element type of `small`; `dact` has big's shape and element type
+template <int CS, int CB, bool PAD, class TO = float, class TS = float>
 __global__ __launch_bounds__(256) void tconv1d_stream_kernel(const Conv1dDgradParams p0, const Conv1dDgradParams p1) {
   const Conv1dDgradParams& p = blockIdx.y ? p1 : p0;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)p.B * p.Ls) return;
   const int b = (int)(idx / p.Ls), j = (int)(idx - (long)b * p.Ls);
-  const float* xs = p.s + (long)b * p.s_bs + j;
+  const TS* xs = reinterpret_cast<const TS*>(p.s) + (long)b * p.s_bs + j;
   float xv[CS], xn[CS];
 #pragma unroll
   for (int cs = 0; cs < CS; ++cs) {
-    xv[cs] = xs[(long)cs * p.Ls];
-    xn[cs] = (PAD && j + 1 < p.Ls) ? xs[(long)cs * p.Ls + 1] : 0.f;
+    xv[cs] = Elem<TS>::ld(xs + (long)cs * p.Ls);
+    xn[cs] = (PAD && j + 1 < p.Ls) ? Elem<TS>::ld(xs + (long)cs * p.Ls + 1) : 0.f;
   }
   const long obase = (long)b * p.big_bs + 4 * (long)j;
 #pragma unroll
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void tconv1d_stream_kernel(const Conv1dDgradPa
       for (int r = 0; r < 4; ++r) acc[r] = elu(acc[r]);
     }
     if (p.dact) {
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(p.dact + g);
+      const f32x4 sv = Elem<TO>::ld4(reinterpret_cast<const TO*>(p.dact) + g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[r] *= elu_grad_from_out(sv[r]);
     }
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(256) void tconv1d_stream_kernel(const Conv1dDgradPa
 
 // downsampling direction: y[b, co, j] = bias[co] + sum_{ci,t} w[co, ci, t] * x[b, ci, 4j - pad + t]
 //   pad = 1: forward of Conv1d(k4, s4, p1);  pad = 0: data gradient of ConvTranspose1d(k4, s4)
-// TI: element type of x
-template <int CIN, int COUT, bool PAD, class TI = float>
+// TI: element type of x; TO: of y (and of dact, which has y's shape)
+template <int CIN, int COUT, bool PAD, class TI = float, class TO = float>
 __global__ __launch_bounds__(256) void conv1d_stream_kernel(const Conv1dFwdParams p0, const Conv1dFwdParams p1) {
   const Conv1dFwdParams& p = blockIdx.y ? p1 : p0;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -103,8 +104,8 @@ __global__ __launch_bounds__(256) void conv1d_stream_kernel(const Conv1dFwdParam
     }
     const long g = obase + (long)co * p.Lo;
     if (p.act) acc = elu(acc);
-    if (p.dact) acc *= elu_grad_from_out(p.dact[g]);
-    p.y[g] = acc;
+    if (p.dact) acc *= elu_grad_from_out(Elem<TO>::ld(reinterpret_cast<const TO*>(p.dact) + g));
+    Elem<TO>::st(reinterpret_cast<TO*>(p.y) + g, acc);
   }
 }
 
@@ -134,7 +135,7 @@ template <int CTRL>
 __device__ __forceinline__ float quad_swap(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-template <int CS, int CB, class TB, bool DG>
+template <int CS, int CB, class TB, bool DG, class TS = float>  // TS: element type of `small` (and of the fused data gradient)
 __device__ __forceinline__ void conv1d_wgrad_stream_body(const float* __restrict__ small0,
                                                          const float* __restrict__ small1, long s_bs,
                                                          const float* __restrict__ big0_,
@@ -143,7 +144,7 @@ __device__ __forceinline__ void conv1d_wgrad_stream_body(const float* __restrict
                                                          float* __restrict__ partial1, int Ls, int Lb,
                                                          int pad, int bias_from, int ntiles, DgradArgs dg) {
   static_assert(!DG || (CB == 4 && CS == 8), "fused data gradient: 8 -> 4 channel layers");
-  const float* small = blockIdx.y ? small1 : small0;
+  const TS* small = reinterpret_cast<const TS*>(blockIdx.y ? small1 : small0);
   const TB* big = reinterpret_cast<const TB*>(blockIdx.y ? big1_ : big0_);  // TB: element type of `big`
   float* partial = blockIdx.y ? partial1 : partial0;
   constexpr int GA = CS / 4, GB = CB / 4;
@@ -165,20 +166,20 @@ __device__ __forceinline__ void conv1d_wgrad_stream_body(const float* __restrict
   const int tiles_per = Ls / 64;
   const int nwaves = gridDim.x * 4, w0 = blockIdx.x * 4 + wave;
   f32x4 wq[DG ? CS : 1];  // w[cs][cb = q][0..3]
-  float* dsmall = nullptr;
+  TS* dsmall = nullptr;
   if constexpr (DG) {
     const float* w = blockIdx.y ? dg.w1 : dg.w0;
-    dsmall = blockIdx.y ? dg.d1 : dg.d0;
+    dsmall = reinterpret_cast<TS*>(blockIdx.y ? dg.d1 : dg.d0);
 #pragma unroll
     for (int cs = 0; cs < CS; ++cs) wq[cs] = *reinterpret_cast<const f32x4*>(w + ((long)cs * CB + q) * 4);
   }
   f32x4 ra[GA], rb[GB][4];
   auto load_tile = [&](int tile) {
     const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * 64;
-    const float* sb = small + (long)b * s_bs + j0 + 4 * slot;
+    const TS* sb = small + (long)b * s_bs + j0 + 4 * slot;
     const TB* bb = big + (long)b * big_bs + 4L * (j0 + 4 * slot) - pad;
 #pragma unroll
-    for (int a = 0; a < GA; ++a) ra[a] = *reinterpret_cast<const f32x4*>(sb + (long)(4 * a + q) * Ls);
+    for (int a = 0; a < GA; ++a) ra[a] = Elem<TS>::ld4(sb + (long)(4 * a + q) * Ls);
     if (pad && j0 == 0 && slot == 0) {  // the window of position 0 starts one element before the row
 #pragma unroll
       for (int g = 0; g < GB; ++g) {
@@ -267,13 +268,13 @@ __device__ __forceinline__ void conv1d_wgrad_stream_body(const float* __restrict
         }
       }
       const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * 64;
-      float* db_ = dsmall + (long)b * dg.d_bs + j0 + 4 * slot;
+      TS* db_ = dsmall + (long)b * dg.d_bs + j0 + 4 * slot;
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         f32x4 o;
 #pragma unroll
         for (int st = 0; st < 4; ++st) o[st] = r2[m][st] * elu_grad_from_out(ca[m][st]);
-        *reinterpret_cast<f32x4*>(db_ + (long)(4 * m + q) * Ls) = o;
+        Elem<TS>::st4(db_ + (long)(4 * m + q) * Ls, o);
       }
     }
   }
@@ -305,7 +306,7 @@ __device__ __forceinline__ void conv1d_wgrad_stream_body(const float* __restrict
   }
 }
 
-template <int CS, int CB, class TB = float>
+template <int CS, int CB, class TB = float, class TS = float>
 __global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* __restrict__ small0,
                                                                   const float* __restrict__ small1, long s_bs,
                                                                   const float* __restrict__ big0,
@@ -313,12 +314,12 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_stream_kernel(const float* _
                                                                   float* __restrict__ partial0,
                                                                   float* __restrict__ partial1, int Ls, int Lb,
                                                                   int pad, int bias_from, int ntiles) {
-  conv1d_wgrad_stream_body<CS, CB, TB, false>(small0, small1, s_bs, big0, big1, big_bs, partial0, partial1, Ls, Lb, pad,
-                                              bias_from, ntiles, DgradArgs{});
+  conv1d_wgrad_stream_body<CS, CB, TB, false, TS>(small0, small1, s_bs, big0, big1, big_bs, partial0, partial1, Ls, Lb, pad,
+                                                  bias_from, ntiles, DgradArgs{});
 }
 // weight + bias + data gradient of the 8 -> 4 channel transposed layer (204 registers: two wavefronts per SIMD; capped
 // at 168 for three it spills 10 and runs 81 us instead of 61)
-template <class TB>
+template <class TB, class TS = float>
 __global__ __launch_bounds__(256) void conv1d_bwd_fused_kernel(const float* __restrict__ small0,
                                                                   const float* __restrict__ small1, long s_bs,
                                                                   const float* __restrict__ big0,
@@ -326,8 +327,8 @@ __global__ __launch_bounds__(256) void conv1d_bwd_fused_kernel(const float* __re
                                                                   float* __restrict__ partial0,
                                                                   float* __restrict__ partial1, int Ls, int Lb,
                                                                   int bias_from, int ntiles, DgradArgs dg) {
-  conv1d_wgrad_stream_body<8, 4, TB, true>(small0, small1, s_bs, big0, big1, big_bs, partial0, partial1, Ls, Lb, 0,
-                                           bias_from, ntiles, dg);
+  conv1d_wgrad_stream_body<8, 4, TB, true, TS>(small0, small1, s_bs, big0, big1, big_bs, partial0, partial1, Ls, Lb, 0,
+                                               bias_from, ntiles, dg);
 }
 
 bool conv1d_wgrad_stream_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
@@ -344,12 +345,12 @@ bool conv1d_bwd_fused_supported(int Cs, int Cb, int pad) {
 int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
                         int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16,
-                        const FusedDgrad* fd) {
+                        const FusedDgrad* fd, int small_bf16) {
   // every fused layer but the original 8 -> 4 transposed one (which keeps its own kernel unless LSHM_FUSED2_ALL=1)
   static const bool fused2_all = getenv("LSHM_FUSED2_ALL") != nullptr;
   if (fd && fd->dx && (fused2_all || !(Cs == 8 && Cb == 4 && pad == 0) || !fd->dact))
     return conv1d_bwd_fused2(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, max_blocks, st,
-                             grid_out, big_bf16, *fd);
+                             grid_out, big_bf16, *fd, small_bf16);
   const float* w = fd ? fd->w : nullptr;
   const float* w2 = fd ? fd->w2 : nullptr;
   float* dsmall = fd ? fd->dx : nullptr;
@@ -371,58 +372,66 @@ int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, cons
   if (grid > max_blocks) grid = max_blocks;
   *grid_out = grid;
   const dim3 g(grid, small2 ? 2 : 1);
-  if (big_bf16 && Cs != 8) { set_last_error("conv1d_wgrad_stream: bf16 storage only for the outermost layers"); return LSHM_ERR_UNSUPPORTED; }
-  if (dsmall && big_bf16)
-    hipLaunchKernelGGL((conv1d_bwd_fused_kernel<bf16>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs, ws, ws2,
-                       Ls, Lb, bias_from, ntiles, dg);
-  else if (dsmall)
-    hipLaunchKernelGGL((conv1d_bwd_fused_kernel<float>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs, ws, ws2,
-                       Ls, Lb, bias_from, ntiles, dg);
-  else if (Cs == 8 && big_bf16)
-    hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<8, 4, bf16>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs,
-                       ws, ws2, Ls, Lb, pad, bias_from, ntiles);
-  else if (Cs == 8)
-    hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<8, 4>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs,
-                       ws, ws2, Ls, Lb, pad, bias_from, ntiles);
-  else
-    hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<12, 8>), g, dim3(256), 0, st, small, small2, s_bs, big, big2,
-                       big_bs, ws, ws2, Ls, Lb, pad, bias_from, ntiles);
+  // bf16 storage: `big` for both outer layer shapes, `small` (and the fused data gradient) for the outermost one
+  if (small_bf16 && !(Cs == 8 && big_bf16)) { set_last_error("conv1d_wgrad_stream: a bf16 `small` needs the outermost layer with bf16 `big`"); return LSHM_ERR_UNSUPPORTED; }
+#define LSHM_WGS(CS_, CB_, TB_, TS_) \
+  hipLaunchKernelGGL((conv1d_wgrad_stream_kernel<CS_, CB_, TB_, TS_>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs, ws, ws2, Ls, Lb, pad, bias_from, ntiles)
+#define LSHM_BFK(TB_, TS_) \
+  hipLaunchKernelGGL((conv1d_bwd_fused_kernel<TB_, TS_>), g, dim3(256), 0, st, small, small2, s_bs, big, big2, big_bs, ws, ws2, Ls, Lb, bias_from, ntiles, dg)
+  if (dsmall) {
+    if (big_bf16 && small_bf16) LSHM_BFK(bf16, bf16);
+    else if (big_bf16) LSHM_BFK(bf16, float);
+    else LSHM_BFK(float, float);
+  } else if (Cs == 8) {
+    if (big_bf16 && small_bf16) LSHM_WGS(8, 4, bf16, bf16);
+    else if (big_bf16) LSHM_WGS(8, 4, bf16, float);
+    else LSHM_WGS(8, 4, float, float);
+  } else {
+    if (big_bf16) LSHM_WGS(12, 8, bf16, float);
+    else LSHM_WGS(12, 8, float, float);
+  }
+#undef LSHM_WGS
+#undef LSHM_BFK
   return check_launch("conv1d_wgrad_stream");
 }
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 bool tconv1d_stream_supported(const Conv1dDgradParams& p) {
-  const bool shape = (p.Cs == 8 && p.Cb == 4) || (p.Cs == 12 && p.Cb == 8 && !p.big_bf16);
+  const bool shape = (p.Cs == 8 && p.Cb == 4 && (!p.s_bf16 || p.big_bf16)) || (p.Cs == 12 && p.Cb == 8 && !p.s_bf16);
   return shape && (p.pad == 0 || p.pad == 1) && p.Lb == 4 * p.Ls && p.big_bs % 4 == 0 && aligned16(p.big) &&
          aligned16(p.w) && (!p.dact || aligned16(p.dact));
 }
 bool conv1d_stream_supported(const Conv1dFwdParams& p) {
-  const bool shape = (p.Cin == 4 && p.Cout == 8) || (p.Cin == 8 && p.Cout == 12 && !p.x_bf16);
+  const bool shape = (p.Cin == 4 && p.Cout == 8 && (!p.y_bf16 || p.x_bf16)) || (p.Cin == 8 && p.Cout == 12 && !p.y_bf16);
   return shape && (p.pad == 0 || p.pad == 1) && p.L == 4 * p.Lo && p.x_bs % 4 == 0 && aligned16(p.x) && aligned16(p.w);
 }
 
 int tconv1d_stream(const Conv1dDgradParams& p, const Conv1dDgradParams* p1, hipStream_t st) {
   const dim3 grid(cdiv((long)p.B * p.Ls, 256), p1 ? 2 : 1);
   const Conv1dDgradParams& q = p1 ? *p1 : p;
-#define LSHM_LAUNCH(CS, CB, T)                                                                                \
-  if (p.pad) hipLaunchKernelGGL((tconv1d_stream_kernel<CS, CB, true, T>), grid, dim3(256), 0, st, p, q);       \
-  else hipLaunchKernelGGL((tconv1d_stream_kernel<CS, CB, false, T>), grid, dim3(256), 0, st, p, q)
-  if (p.Cs == 8 && p.big_bf16) { LSHM_LAUNCH(8, 4, bf16); }
-  else if (p.Cs == 8) { LSHM_LAUNCH(8, 4, float); }
-  else { LSHM_LAUNCH(12, 8, float); }
+#define LSHM_LAUNCH(CS, CB, T, TS_)                                                                           \
+  if (p.pad) hipLaunchKernelGGL((tconv1d_stream_kernel<CS, CB, true, T, TS_>), grid, dim3(256), 0, st, p, q);  \
+  else hipLaunchKernelGGL((tconv1d_stream_kernel<CS, CB, false, T, TS_>), grid, dim3(256), 0, st, p, q)
+  if (p.Cs == 8 && p.big_bf16 && p.s_bf16) { LSHM_LAUNCH(8, 4, bf16, bf16); }
+  else if (p.Cs == 8 && p.big_bf16) { LSHM_LAUNCH(8, 4, bf16, float); }
+  else if (p.Cs == 8) { LSHM_LAUNCH(8, 4, float, float); }
+  else if (p.big_bf16) { LSHM_LAUNCH(12, 8, bf16, float); }
+  else { LSHM_LAUNCH(12, 8, float, float); }
 #undef LSHM_LAUNCH
   return check_launch("tconv1d_stream");
 }
 int conv1d_stream(const Conv1dFwdParams& p, const Conv1dFwdParams* p1, hipStream_t st) {
   const dim3 grid(cdiv((long)p.B * p.Lo, 256), p1 ? 2 : 1);
   const Conv1dFwdParams& q = p1 ? *p1 : p;
-#define LSHM_LAUNCH(CI, CO, T)                                                                                \
-  if (p.pad) hipLaunchKernelGGL((conv1d_stream_kernel<CI, CO, true, T>), grid, dim3(256), 0, st, p, q);        \
-  else hipLaunchKernelGGL((conv1d_stream_kernel<CI, CO, false, T>), grid, dim3(256), 0, st, p, q)
-  if (p.Cin == 4 && p.x_bf16) { LSHM_LAUNCH(4, 8, bf16); }
-  else if (p.Cin == 4) { LSHM_LAUNCH(4, 8, float); }
-  else { LSHM_LAUNCH(8, 12, float); }
+#define LSHM_LAUNCH(CI, CO, T, TO_)                                                                           \
+  if (p.pad) hipLaunchKernelGGL((conv1d_stream_kernel<CI, CO, true, T, TO_>), grid, dim3(256), 0, st, p, q);   \
+  else hipLaunchKernelGGL((conv1d_stream_kernel<CI, CO, false, T, TO_>), grid, dim3(256), 0, st, p, q)
+  if (p.Cin == 4 && p.x_bf16 && p.y_bf16) { LSHM_LAUNCH(4, 8, bf16, bf16); }
+  else if (p.Cin == 4 && p.x_bf16) { LSHM_LAUNCH(4, 8, bf16, float); }
+  else if (p.Cin == 4) { LSHM_LAUNCH(4, 8, float, float); }
+  else if (p.x_bf16) { LSHM_LAUNCH(8, 12, bf16, float); }
+  else { LSHM_LAUNCH(8, 12, float, float); }
 #undef LSHM_LAUNCH
   return check_launch("conv1d_stream");
 }

@@ -20,13 +20,15 @@ namespace lshm {
 //   (dy in {py-1, py}, dx in {px-1, px})
 // Tile: TH small rows x TW small columns; 4 wavefronts, each (TH*TW/16)/4 m-tiles of 16 columns.
 // ----------------------------------------------------------------------------------------------
-template <int CS, int CB, int TH, int TW>
+template <int CS, int CB, int TH, int TW, class TO = float>  // TO: element type of `big` and of `dact` (bf16 storage, common.h)
 __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __restrict__ small, long s_bs,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias,
-                                                             float* __restrict__ big, long big_bs,
-                                                             const float* __restrict__ dact, int Hs, int Ws,
+                                                             float* __restrict__ big_, long big_bs,
+                                                             const float* __restrict__ dact_, int Hs, int Ws,
                                                              int act, int ntiles) {
+  TO* __restrict__ big = reinterpret_cast<TO*>(big_);
+  const TO* __restrict__ dact = reinterpret_cast<const TO*>(dact_);
   constexpr int K = CS * 9, KS = (K + 3) / 4;       // k-steps of 4
   constexpr int N = 4 * CB, NT = (N + 15) / 16;     // n-tiles of 16
   constexpr int PH = TH + 2, PW = TW + 2;           // input patch with halo
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
   __syncthreads();
   // ---- coalesced float4 stores (and the ELU' multiply for the backward use)
   const int Hb = 2 * Hs, Wb = 2 * Ws;
-  float* bb = big + (long)b * big_bs;
-  const float* db = dact ? dact + (long)b * big_bs : nullptr;
+  TO* bb = big + (long)b * big_bs;
+  const TO* db = dact ? dact + (long)b * big_bs : nullptr;
   for (int i = t; i < CB * 2 * TH * OW / 4; i += 256) {
     const int e = 4 * i;
     const int co = e / (2 * TH * OW), r = e - co * (2 * TH * OW);
@@ -166,11 +168,11 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
     const long g = ((long)co * Hb + 2 * m0 + oy) * Wb + 2 * n0 + ox;
     f32x4 v = *reinterpret_cast<const f32x4*>(&otile[e]);
     if (db) {
-      const f32x4 sv = *reinterpret_cast<const f32x4*>(db + g);
+      const f32x4 sv = Elem<TO>::ld4(db + g);
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] *= elu_grad_from_out(sv[q]);
     }
-    *reinterpret_cast<f32x4*>(bb + g) = v;
+    Elem<TO>::st4(bb + g, v);
   }
   }  // tile loop
 }
@@ -186,14 +188,16 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
 // Wavefront (rp, ch) takes small rows {2rp, 2rp+1} and input channels 4ch..4ch+3 (64 weight
 // registers, resident); the two channel halves of a row meet in LDS and are added half 0 + half 1.
 // ----------------------------------------------------------------------------------------------
-template <int TH, class TO = float>  // TO: element type of `big` (bf16 storage, common.h)
-__global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restrict__ small, long s_bs,
+template <int TH, class TO = float, class TS = float>  // TO: element type of `big` and `dact`, TS: of `small` (bf16 storage, common.h)
+__global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restrict__ small_, long s_bs,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ big_, long big_bs,
-                                                            const float* __restrict__ dact, int Hs, int Ws,
+                                                            const float* __restrict__ dact_, int Hs, int Ws,
                                                             int act, int ntiles) {
   TO* __restrict__ big = reinterpret_cast<TO*>(big_);
+  const TO* __restrict__ dact = reinterpret_cast<const TO*>(dact_);
+  const TS* __restrict__ small = reinterpret_cast<const TS*>(small_);
   constexpr int CS = 8, CB = 4, TW = 64;
   constexpr int PH = TH + 2, PW = TW + 2;
   static_assert(TH == 4, "two small rows per wavefront pair");
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restr
     const int b = tile / (tiles_x * tiles_y);
     const int tr_ = tile - b * (tiles_x * tiles_y);
     const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
-    const float* sb = small + (long)b * s_bs;
+    const TS* sb = small + (long)b * s_bs;
 #pragma unroll
     for (int k = 0; k < NV4; ++k) {
       const int i = k * 256 + t;
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restr
       const int iy = m0 + py - 1;
       rv[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (i < CS * PH * (TW / 4) && (unsigned)iy < (unsigned)Hs)
-        rv[k] = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + iy) * Ws + n0 + 4 * c4);
+        rv[k] = Elem<TS>::ld4(sb + ((long)cs * Hs + iy) * Ws + n0 + 4 * c4);
     }
 #pragma unroll
     for (int k = 0; k < NHL; ++k) {
@@ -237,7 +241,7 @@ __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restr
       const int iy = m0 + py - 1, ix = side ? n0 + TW : n0 - 1;
       rh[k] = 0.f;
       if (i < CS * PH * 2 && (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws)
-        rh[k] = sb[((long)cs * Hs + iy) * Ws + ix];
+        rh[k] = Elem<TS>::ld(sb + ((long)cs * Hs + iy) * Ws + ix);
     }
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
@@ -322,8 +326,8 @@ __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restr
         for (int r = 0; r < 4; ++r) { o0[r] = elu(o0[r]); o1[r] = elu(o1[r]); }
       }
       if (dact) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(dact + g);
-        const f32x4 v1 = *reinterpret_cast<const f32x4*>(dact + g + 4);
+        const f32x4 v0 = Elem<TO>::ld4(dact + g);
+        const f32x4 v1 = Elem<TO>::ld4(dact + g + 4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { o0[r] *= elu_grad_from_out(v0[r]); o1[r] *= elu_grad_from_out(v1[r]); }
       }
@@ -341,20 +345,25 @@ bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws) {
 
 int tconv2d_direct(const float* small, long s_bs, const float* w, const float* bias, float* big,
                    long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
-                   hipStream_t st, int big_bf16) {
-  if (big_bf16 && !(Cs == 8 && Cb == 4)) { set_last_error("tconv2d_direct: bf16 storage only for the outermost layer"); return LSHM_ERR_UNSUPPORTED; }
+                   hipStream_t st, int big_bf16, int small_bf16) {
+  // bf16 storage: `big` (and `dact`, which has its shape) for both outer layers, `small` for the outermost one
+  if (small_bf16 && !(Cs == 8 && Cb == 4 && big_bf16)) { set_last_error("tconv2d_direct: a bf16 `small` needs the outermost layer with bf16 `big`"); return LSHM_ERR_UNSUPPORTED; }
   if (Cs == 8 && Cb == 4) {
     const int ntiles = (Ws / 64) * (Hs / 4) * B;
-    if (big_bf16)
-      hipLaunchKernelGGL((tconv2d_q4_kernel<4, bf16>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, small, s_bs, w,
-                         bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    const dim3 grid(ntiles < 1024 ? ntiles : 1024);
+    if (big_bf16 && small_bf16)
+      hipLaunchKernelGGL((tconv2d_q4_kernel<4, bf16, bf16>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    else if (big_bf16)
+      hipLaunchKernelGGL((tconv2d_q4_kernel<4, bf16>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
     else
-      hipLaunchKernelGGL((tconv2d_q4_kernel<4>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, small, s_bs, w,
-                         bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+      hipLaunchKernelGGL((tconv2d_q4_kernel<4>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
   } else if (Cs == 12 && Cb == 8) {
     const int ntiles = (Ws / 32) * (Hs / 8) * B;
-    hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st,
-                       small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    const dim3 grid(ntiles < 768 ? ntiles : 768);
+    if (big_bf16)
+      hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32, bf16>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    else
+      hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
   } else {
     set_last_error("tconv2d_direct: unsupported shape");
     return LSHM_ERR_UNSUPPORTED;
@@ -375,12 +384,13 @@ namespace lshm {
 // waves), fragments are read straight from the patch.  Accumulators stay in registers across all
 // tiles of the (persistent) workgroup; one slab per workgroup is combined by reduce_partials.
 // ----------------------------------------------------------------------------------------------
-template <int CS, int CB, int TH, int TW, class TB = float>  // TB: element type of `big`
-__global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* __restrict__ small, long s_bs,
+template <int CS, int CB, int TH, int TW, class TB = float, class TS = float>  // TB / TS: element types of `big` / `small`
+__global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* __restrict__ small_, long s_bs,
                                                                   const float* __restrict__ big_, long big_bs,
                                                                   float* __restrict__ partial, int Hs, int Ws,
                                                                   int ntiles, int bias_from) {
   const TB* __restrict__ big = reinterpret_cast<const TB*>(big_);
+  const TS* __restrict__ small = reinterpret_cast<const TS*>(small_);
   // bias_from: 0 none, 1 bias gradient = sum of `small` (conv layer), 2 = sum of `big` (transposed conv);
   // every element passes through this thread's registers on its way to LDS, and a thread always stages
   // the same channel, so the sums cost one add per float4
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
     const int b = tile / (tiles_x * tiles_y);
     const int tr_ = tile - b * (tiles_x * tiles_y);
     const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
-    const float* sb = small + (long)b * s_bs;
+    const TS* sb = small + (long)b * s_bs;
     const TB* bb = big + (long)b * big_bs;
     // small tile: [cs][TH*TW] as float4 rows of TW
 #pragma unroll
@@ -438,7 +448,7 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
       if (i < CS * TH * (TW / 4)) {
         const int c4 = i % (TW / 4), rr = i / (TW / 4);
         const int row = rr % TH, cs = rr / TH;
-        rs[qq] = *reinterpret_cast<const f32x4*>(sb + ((long)cs * Hs + m0 + row) * Ws + n0 + 4 * c4);
+        rs[qq] = Elem<TS>::ld4(sb + ((long)cs * Hs + m0 + row) * Ws + n0 + 4 * c4);
       }
     }
     // big patch: rows 2*m0-1 .. 2*m0+2*TH, cols 2*n0-1 .. 2*n0+2*TW (zero outside the image)
@@ -601,34 +611,35 @@ size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb) {
 
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
-                        hipStream_t st, GradJobs* defer, int big_bf16) {
+                        hipStream_t st, GradJobs* defer, int big_bf16, int small_bf16) {
   if (!db) bias_from = 0;
-  if (big_bf16 && !(Cs == 8 && Cb == 4)) { set_last_error("conv2d_wgrad_direct: bf16 storage only for the outermost layer"); return LSHM_ERR_UNSUPPORTED; }
+  // bf16 storage: `big` for the two outer layer shapes, `small` for the outermost one (8 / 4 channels)
+  if ((big_bf16 && Cs == 24) || (small_bf16 && !(Cs == 8 && Cb == 4))) { set_last_error("conv2d_wgrad_direct: bf16 storage only for the outer layers"); return LSHM_ERR_UNSUPPORTED; }
   if (wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv2d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   int grid;
+#define LSHM_WG2D(CS_, CB_, TH_, TW_, TB_, TS_) \
+  hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<CS_, CB_, TH_, TW_, TB_, TS_>), dim3(grid), dim3(256), 0, st, small, s_bs, big, big_bs, ws, Hs, Ws, ntiles, bias_from)
   if (Cs == 8 && Cb == 4) {
     const int ntiles = (Ws / 64) * (Hs / 4) * B;
     grid = ntiles < 1024 ? ntiles : 1024;  // 112 VGPRs, 37 KB of LDS: four workgroups per CU; 4096 tiles at B = 256 -> 4 full rounds
-    if (big_bf16)
-      hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<8, 4, 4, 64, bf16>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
-                         big_bs, ws, Hs, Ws, ntiles, bias_from);
-    else
-      hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<8, 4, 4, 64>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
-                         big_bs, ws, Hs, Ws, ntiles, bias_from);
+    if (big_bf16 && small_bf16) LSHM_WG2D(8, 4, 4, 64, bf16, bf16);
+    else if (big_bf16) LSHM_WG2D(8, 4, 4, 64, bf16, float);
+    else if (small_bf16) LSHM_WG2D(8, 4, 4, 64, float, bf16);
+    else LSHM_WG2D(8, 4, 4, 64, float, float);
   } else if (Cs == 12 && Cb == 8) {
     const int ntiles = (Ws / 32) * (Hs / 8) * B;
     grid = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<12, 8, 8, 32>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
-                       big_bs, ws, Hs, Ws, ntiles, bias_from);
+    if (big_bf16) LSHM_WG2D(12, 8, 8, 32, bf16, float);
+    else LSHM_WG2D(12, 8, 8, 32, float, float);
   } else if (Cs == 24 && Cb == 12) {
     const int ntiles = (Ws / 16) * (Hs / 8) * B;
     grid = ntiles < 768 ? ntiles : 768;
-    hipLaunchKernelGGL((conv2d_wgrad_direct_kernel<24, 12, 8, 16>), dim3(grid), dim3(256), 0, st, small, s_bs, big,
-                       big_bs, ws, Hs, Ws, ntiles, bias_from);
+    LSHM_WG2D(24, 12, 8, 16, float, float);
   } else {
     set_last_error("conv2d_wgrad_direct: unsupported shape");
     return LSHM_ERR_UNSUPPORTED;
   }
+#undef LSHM_WG2D
   int rc = check_launch("conv2d_wgrad_direct");
   if (rc) return rc;
   const int nw = Cs * Cb * 16, slab = nw + wgrad_bias_pad(Cs, Cb);
@@ -654,13 +665,14 @@ namespace lshm {
 // The input patch of a TH x TW output tile sits in LDS once; A fragments are read at
 // patch[ci][2oy+ky][2ox+kx] (bank = 2*lane + kx: conflict-free); weights live in registers.
 // ----------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int TH, int TW>
-__global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __restrict__ x, long x_bs,
+template <int CIN, int COUT, int TH, int TW, class TI = float>  // TI: element type of x (bf16 storage, common.h)
+__global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __restrict__ x_, long x_bs,
                                                             const float* __restrict__ w,
                                                             const float* __restrict__ bias,
                                                             float* __restrict__ y, long y_bs,
                                                             const float* __restrict__ dact, int Ho, int Wo,
                                                             int act, int ntiles) {
+  const TI* __restrict__ x = reinterpret_cast<const TI*>(x_);
   constexpr int KS = CIN * 4;  // k-steps: (ci, ky), 4 kx taps each
   constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
   constexpr int MT = TH * TW / 16, MW = MT / 4, TPR = TW / 16;
@@ -680,14 +692,14 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
     const int b = tile / (tiles_x * tiles_y);
     const int tr_ = tile - b * (tiles_x * tiles_y);
     const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
-    const float* xb = x + (long)b * x_bs;
+    const TI* xb = x + (long)b * x_bs;
     __syncthreads();
     for (int i = t; i < CIN * PH * (2 * TW / 4); i += 256) {
       const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
       const int prow = rr % PH, ci = rr / PH;
       const int iy = 2 * m0 - 1 + prow;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)iy < (unsigned)H) v = *reinterpret_cast<const f32x4*>(xb + ((long)ci * H + iy) * W + 2 * n0 + 4 * c4);
+      if ((unsigned)iy < (unsigned)H) v = Elem<TI>::ld4(xb + ((long)ci * H + iy) * W + 2 * n0 + 4 * c4);
       float* d = &patch[(ci * PH + prow) * PW + 1 + 4 * c4];
       d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
     }
@@ -696,7 +708,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
       const int prow = rr % PH, ci = rr / PH;
       const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
       float v = 0.f;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = xb[((long)ci * H + iy) * W + ix];
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = Elem<TI>::ld(xb + ((long)ci * H + iy) * W + ix);
       patch[(ci * PH + prow) * PW + (side ? PW - 1 : 0)] = v;
     }
     __syncthreads();
@@ -750,13 +762,15 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
 // 32 weight registers stay resident for the whole launch); the four per-channel partial tiles meet in
 // LDS and are added in channel order (fixed order: bitwise reproducible) by the wavefront that owns the row.
 // ----------------------------------------------------------------------------------------------
-template <int COUT, int TH, class TI = float>  // TI: element type of x
+template <int COUT, int TH, class TI = float, class TO = float>  // TI: element type of x, TO: of y and dact
 __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restrict__ x_, long x_bs,
                                                         const float* __restrict__ w,
-                                                        const float* __restrict__ bias, float* __restrict__ y,
-                                                        long y_bs, const float* __restrict__ dact, int Ho, int Wo,
+                                                        const float* __restrict__ bias, float* __restrict__ y_,
+                                                        long y_bs, const float* __restrict__ dact_, int Ho, int Wo,
                                                         int act, int ntiles) {
   const TI* __restrict__ x = reinterpret_cast<const TI*>(x_);
+  TO* __restrict__ y = reinterpret_cast<TO*>(y_);
+  const TO* __restrict__ dact = reinterpret_cast<const TO*>(dact_);
   constexpr int CIN = 4, TW = 64;
   constexpr int NH = COUT / 4;
   constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;  // even row stride keeps the ds_read_b64 at column 2*ox aligned
@@ -888,11 +902,11 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
         o[r] = act ? elu(v) : v;
       }
       if (dact) {
-        const f32x4 sv = *reinterpret_cast<const f32x4*>(dact + g);
+        const f32x4 sv = Elem<TO>::ld4(dact + g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] *= elu_grad_from_out(sv[r]);
       }
-      *reinterpret_cast<f32x4*>(y + g) = o;
+      Elem<TO>::st4(y + g, o);
     }
   }
 }
@@ -908,13 +922,15 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
 // multiply; weight gradient on v_mfma_f32_16x16x4 from the small tile and the patch, accumulators kept in
 // registers across the tiles of the persistent workgroup (the same MFMA sequence as the stand-alone kernel).
 // ----------------------------------------------------------------------------------------------
-template <class TB>  // TB: element type of `big` (the gradient image; bf16 storage, common.h)
+template <class TB, class TS = float>  // TB: element type of `big` (the gradient image), TS: of `small` and `dsmall`
 __global__ __launch_bounds__(256, 2) void tconv2d_bwd_fused_kernel(const float* __restrict__ big_, long big_bs,
-                                                                   const float* __restrict__ small, long s_bs,
+                                                                   const float* __restrict__ small_, long s_bs,
                                                                    const float* __restrict__ w,
-                                                                   float* __restrict__ dsmall, float* __restrict__ partial,
+                                                                   float* __restrict__ dsmall_, float* __restrict__ partial,
                                                                    int Hs, int Ws, int ntiles, int dact) {
   const TB* __restrict__ big = reinterpret_cast<const TB*>(big_);
+  const TS* __restrict__ small = reinterpret_cast<const TS*>(small_);
+  TS* __restrict__ dsmall = reinterpret_cast<TS*>(dsmall_);
   constexpr int CS = 8, CB = 4, TH = 4, TW = 64, NH = CS / 4;
   constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
   constexpr int TP = TH * TW, LDS_S = TP + 2;
@@ -971,7 +987,7 @@ __global__ __launch_bounds__(256, 2) void tconv2d_bwd_fused_kernel(const float* 
     // the saved input this thread finishes in the epilogue: row m0 + wave, columns n0 + 4 (lane / 4) .., channel 4h + q
 #pragma unroll
     for (int h = 0; h < NH; ++h)
-      rs[h] = *reinterpret_cast<const f32x4*>(small + (long)b * s_bs + ((long)(4 * h + q) * Hs + m0 + wave) * Ws + n0 + 4 * (lane >> 2));
+      rs[h] = Elem<TS>::ld4(small + (long)b * s_bs + ((long)(4 * h + q) * Hs + m0 + wave) * Ws + n0 + 4 * (lane >> 2));
   };
   if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1056,7 +1072,7 @@ __global__ __launch_bounds__(256, 2) void tconv2d_bwd_fused_kernel(const float* 
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] *= elu_grad_from_out(sv[h][r]);
       }
-      *reinterpret_cast<f32x4*>(dsmall + g) = o;
+      Elem<TS>::st4(dsmall + g, o);
       float* d = &stile[(4 * h + q) * LDS_S + wave * TW + 4 * (lane >> 2)];
       d[0] = sv[h][0]; d[1] = sv[h][1]; d[2] = sv[h][2]; d[3] = sv[h][3];
     }
@@ -1109,26 +1125,28 @@ bool tconv2d_bwd_fused_supported(int Cs, int Cb, int Hs, int Ws) { return Cs == 
 // weight + bias + data gradient of the 8 -> 4 transposed layer; one slab per workgroup in ws (conv2d_wgrad_direct_workspace_floats)
 int tconv2d_bwd_fused(const float* small, long s_bs, const float* big, long big_bs, const float* w, float* dsmall, int dact,
                       float* dw, float* db, int B, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
-                      GradJobs* defer, int big_bf16) {
+                      GradJobs* defer, int big_bf16, int small_bf16) {
   constexpr int Cs = 8, Cb = 4;
   if (wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("tconv2d_bwd_fused: workspace too small"); return LSHM_ERR_WORKSPACE; }
   if (!tconv2d_bwd_fused_supported(Cs, Cb, Hs, Ws) || s_bs % 4 || big_bs % 4 || (reinterpret_cast<uintptr_t>(small) & 15) ||
-      (reinterpret_cast<uintptr_t>(big) & 15) || (reinterpret_cast<uintptr_t>(dsmall) & 15) || (reinterpret_cast<uintptr_t>(w) & 15)) {
-    set_last_error("tconv2d_bwd_fused: unsupported shape or alignment");
+      (reinterpret_cast<uintptr_t>(big) & 15) || (reinterpret_cast<uintptr_t>(dsmall) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
+      (small_bf16 && !big_bf16)) {
+    set_last_error("tconv2d_bwd_fused: unsupported shape, alignment or storage combination");
     return LSHM_ERR_UNSUPPORTED;
   }
   const int ntiles = (Ws / 64) * (Hs / 4) * B;
   const int grid = ntiles < 512 ? ntiles : 512;  // 62 KB of LDS: two workgroups per CU
   int rc;
-  if (big_bf16) {
-    if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(&tconv2d_bwd_fused_kernel<bf16>), 256, 0, "tconv2d_bwd_fused"))) return rc;
-    hipLaunchKernelGGL((tconv2d_bwd_fused_kernel<bf16>), dim3(grid), dim3(256), 0, st, big, big_bs, small, s_bs, w, dsmall, ws, Hs,
-                       Ws, ntiles, dact);
-  } else {
-    if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(&tconv2d_bwd_fused_kernel<float>), 256, 0, "tconv2d_bwd_fused"))) return rc;
-    hipLaunchKernelGGL((tconv2d_bwd_fused_kernel<float>), dim3(grid), dim3(256), 0, st, big, big_bs, small, s_bs, w, dsmall, ws, Hs,
-                       Ws, ntiles, dact);
-  }
+#define LSHM_F2D(TB_, TS_)                                                                                                       \
+  do {                                                                                                                           \
+    if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(&tconv2d_bwd_fused_kernel<TB_, TS_>), 256, 0, "tconv2d_bwd_fused"))) return rc; \
+    hipLaunchKernelGGL((tconv2d_bwd_fused_kernel<TB_, TS_>), dim3(grid), dim3(256), 0, st, big, big_bs, small, s_bs, w, dsmall, ws, Hs, \
+                       Ws, ntiles, dact);                                                                                        \
+  } while (0)
+  if (big_bf16 && small_bf16) LSHM_F2D(bf16, bf16);
+  else if (big_bf16) LSHM_F2D(bf16, float);
+  else LSHM_F2D(float, float);
+#undef LSHM_F2D
   if ((rc = check_launch("tconv2d_bwd_fused"))) return rc;
   const int nw = Cs * Cb * 16, slab = nw + 16;
   if (defer) {
@@ -1148,22 +1166,27 @@ bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo) {
 }
 
 int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
-                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st, int x_bf16) {
-  if (x_bf16 && !(Cin == 4 && Cout == 8)) { set_last_error("conv2d_direct: bf16 storage only for the outermost layer"); return LSHM_ERR_UNSUPPORTED; }
+                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st, int x_bf16, int y_bf16) {
+  // bf16 storage: x for both outer layer shapes; y (and dact, which has its shape) for the outermost one
+  if (y_bf16 && !(Cin == 4 && Cout == 8)) { set_last_error("conv2d_direct: a bf16 output only for the outermost layer"); return LSHM_ERR_UNSUPPORTED; }
   if (Cin == 4 && Cout == 8) {
     const int ntiles = (Wo / 64) * (Ho / 4) * B;
-    if (x_bf16)
-      hipLaunchKernelGGL((conv2d_q4_kernel<8, 4, bf16>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x, x_bs, w,
-                         bias, y, y_bs, dact, Ho, Wo, act, ntiles);
-    else
-      hipLaunchKernelGGL((conv2d_q4_kernel<8, 4>), dim3(ntiles < 768 ? ntiles : 768), dim3(256), 0, st, x, x_bs, w,
-                         bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+    const dim3 grid(ntiles < 768 ? ntiles : 768);
+#define LSHM_Q4(TI_, TO_) hipLaunchKernelGGL((conv2d_q4_kernel<8, 4, TI_, TO_>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles)
+    if (x_bf16 && y_bf16) LSHM_Q4(bf16, bf16);
+    else if (x_bf16) LSHM_Q4(bf16, float);
+    else if (y_bf16) LSHM_Q4(float, bf16);
+    else LSHM_Q4(float, float);
+#undef LSHM_Q4
   } else if (Cin == 8 && Cout == 12) {
     const int ntiles = (Wo / 32) * (Ho / 8) * B;
     // 38 KB of LDS and <= 128 VGPRs: four workgroups per CU, so the 1024 tiles of B = 256 are resident at once
     // (768 workgroups left a second round with a third of the machine busy)
-    hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32>), dim3(ntiles < 1024 ? ntiles : 1024), dim3(256), 0, st, x,
-                       x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+    const dim3 grid(ntiles < 1024 ? ntiles : 1024);
+    if (x_bf16)
+      hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32, bf16>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+    else
+      hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
   } else {
     set_last_error("conv2d_direct: unsupported shape");
     return LSHM_ERR_UNSUPPORTED;
@@ -1407,7 +1430,7 @@ size_t conv1d_wgrad_direct_workspace_floats(int Cs, int Cb) { return (size_t)204
 int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
                         size_t wsf, int accumulate, hipStream_t st, const float* small2, const float* big2,
-                        float* dw2, float* db2, GradJobs* defer, int big_bf16, const FusedDgrad* fd) {
+                        float* dw2, float* db2, GradJobs* defer, int big_bf16, const FusedDgrad* fd, int small_bf16) {
   const int G = small2 ? 2 : 1;
   if (wsf < G * conv1d_wgrad_direct_workspace_floats(Cs, Cb)) { set_last_error("conv1d_wgrad_direct: workspace too small"); return LSHM_ERR_WORKSPACE; }
   if (!db) bias_from = 0;
@@ -1420,7 +1443,7 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
   const int slab = Cs * Cb * 4 + 16;
   int grid = 0;
   int rc = conv1d_wgrad_stream(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, bias_from,
-                               2048 / G, st, &grid, big_bf16, fd);
+                               2048 / G, st, &grid, big_bf16, fd, small_bf16);
 
   if (rc) return rc;
   if (defer) {

@@ -1065,10 +1065,15 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->off1d = e->ae[1].cw[0];
   e->bf = cfg->precision == LSHM_PRECISION_BF16_STORAGE;
   if (e->bf) {
-    // bf16 tensors: the three reconstructions, the row / column residuals and every image-sized gradient.  The
-    // layers that touch them: the last decoder layer of each autoencoder and the first encoder layer of netT / netF.
-    for (int a = 0; a < 3; ++a) e->ae[a].dec[5].out_bf16 = 1;
-    for (int a = 1; a < 3; ++a) e->ae[a].enc[0].in_bf16 = 1;
+    // bf16 tensors: the three reconstructions, the row / column residuals, every image-sized gradient, and (round 3) the
+    // 8-channel half-resolution tensors -- conv0's output and tconv4's output of each autoencoder with their gradients.
+    // A layer flag covers the tensor AND the gradient with respect to it.
+    for (int a = 0; a < 3; ++a) {
+      e->ae[a].dec[5].out_bf16 = 1;                                // x1 / x2 / x3 and their gradients
+      e->ae[a].enc[0].out_bf16 = e->ae[a].enc[1].in_bf16 = 1;      // conv0's output (B, 8, half resolution)
+      e->ae[a].dec[4].out_bf16 = e->ae[a].dec[5].in_bf16 = 1;      // tconv4's output
+    }
+    for (int a = 1; a < 3; ++a) e->ae[a].enc[0].in_bf16 = 1;       // the row / column residuals
   }
   e->Moff = add_param(e, "mod.M", {cfg->K, e->D});
   // split-K / reduction scratch: the largest consumer among wgrads, KHM and the recon partials

@@ -1137,14 +1137,14 @@ int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t 
   return launch_auto<Conv2dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1) {
-  if ((g_tune_force < 0 || p.x_bf16) && conv1d_stream_supported(p) && (!p1 || conv1d_stream_supported(*p1))) return conv1d_stream(p, p1, st);
-  if (p.x_bf16) { set_last_error("conv1d: bf16 input needs the streaming kernel"); return LSHM_ERR_UNSUPPORTED; }
+  if ((g_tune_force < 0 || p.x_bf16 || p.y_bf16) && conv1d_stream_supported(p) && (!p1 || conv1d_stream_supported(*p1))) return conv1d_stream(p, p1, st);
+  if (p.x_bf16 || p.y_bf16) { set_last_error("conv1d: bf16 tensors need the streaming kernel"); return LSHM_ERR_UNSUPPORTED; }
   if (!fits32(span(p.x_bs, p.B, (long)p.Cin * p.L), (long)p.Cout * p.Cin * 4)) return LSHM_ERR_UNSUPPORTED;
   return launch_auto<Conv1dFwd>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }
 int conv1d_dgrad(const Conv1dDgradParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dDgradParams* p1) {
-  if ((g_tune_force < 0 || p.big_bf16) && tconv1d_stream_supported(p) && (!p1 || tconv1d_stream_supported(*p1))) return tconv1d_stream(p, p1, st);
-  if (p.big_bf16) { set_last_error("tconv1d: bf16 output needs the streaming kernel"); return LSHM_ERR_UNSUPPORTED; }
+  if ((g_tune_force < 0 || p.big_bf16 || p.s_bf16) && tconv1d_stream_supported(p) && (!p1 || tconv1d_stream_supported(*p1))) return tconv1d_stream(p, p1, st);
+  if (p.big_bf16 || p.s_bf16) { set_last_error("tconv1d: bf16 tensors need the streaming kernel"); return LSHM_ERR_UNSUPPORTED; }
   if (!fits32(span(p.s_bs, p.B, (long)p.Cs * p.Ls), (long)p.Cs * p.Cb * 4)) return LSHM_ERR_UNSUPPORTED;
   return launch_auto<Conv1dDgrad>(p, p1, p.M, p.N, 1, ws, wsf, st);
 }

@@ -47,7 +47,8 @@ struct Conv1dFwdParams {
   int act;
   int M, N, K;
   SplitK sk;
-  int x_bf16 = 0;  // x is a bf16 tensor (streaming kernels of the outermost layers only)
+  int x_bf16 = 0;  // x is a bf16 tensor (streaming kernels of the two outer layers only)
+  int y_bf16 = 0;  // y (and dact, which has its shape) is a bf16 tensor (outermost layer only)
 };
 struct Conv1dDgradParams {
   const float* s; const float* w; const float* bias; float* big; const float* dact;
@@ -56,7 +57,8 @@ struct Conv1dDgradParams {
   int act;
   int M, N, K;
   SplitK sk;
-  int big_bf16 = 0;  // big is a bf16 tensor (streaming kernels of the outermost layers only)
+  int big_bf16 = 0;  // big (and dact, which has its shape) is a bf16 tensor (streaming kernels of the two outer layers only)
+  int s_bf16 = 0;    // s is a bf16 tensor (outermost layer only)
 };
 struct Conv1dWgradParams {
   const float* s; const float* big; float* dw;
@@ -145,11 +147,11 @@ bool conv1d_bwd_fused_supported(int Cs, int Cb, int pad);
 bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad);
 int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs,
                       float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks,
-                      hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd);
+                      hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd, int small_bf16 = 0);
 int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, const float* big, const float* big2,
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
                         int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16 = 0,
-                        const FusedDgrad* fd = nullptr);
+                        const FusedDgrad* fd = nullptr, int small_bf16 = 0);
 bool tconv1d_stream_supported(const Conv1dDgradParams& p);
 int tconv1d_stream(const Conv1dDgradParams& p, const Conv1dDgradParams* p1, hipStream_t st);
 // mode: 0 static heuristic, 1 time the tile configurations on first use of a shape; force >= 0 pins one configuration
@@ -172,23 +174,24 @@ int igemm_tuning_import(const char* text);          // returns the entries read
 bool tconv2d_direct_supported(int Cs, int Cb, int Hs, int Ws);
 int tconv2d_direct(const float* small, long s_bs, const float* w, const float* bias, float* big,
                    long big_bs, const float* dact, int B, int Cs, int Cb, int Hs, int Ws, int act,
-                   hipStream_t st, int big_bf16 = 0);
+                   hipStream_t st, int big_bf16 = 0, int small_bf16 = 0);
 
 bool conv2d_direct_supported(int Cin, int Cout, int Ho, int Wo);
 int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, float* y, long y_bs,
-                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st, int x_bf16 = 0);
+                  const float* dact, int B, int Cin, int Cout, int Ho, int Wo, int act, hipStream_t st, int x_bf16 = 0,
+                  int y_bf16 = 0);
 bool conv2d_wgrad_direct_supported(int Cs, int Cb, int Hs, int Ws);
 size_t conv2d_wgrad_direct_workspace_floats(int Cs, int Cb);
 // db (optional): bias gradient fused; bias_from 1: dz is `small` (conv), 2: dz is `big` (transposed conv)
 int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long big_bs, float* dw, float* db,
                         int bias_from, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
-                        hipStream_t st, GradJobs* defer = nullptr, int big_bf16 = 0);
+                        hipStream_t st, GradJobs* defer = nullptr, int big_bf16 = 0, int small_bf16 = 0);
 
 // one-pass backward (data + weight + bias gradient) of the outermost 2-D decoder layer (8 -> 4 channels)
 bool tconv2d_bwd_fused_supported(int Cs, int Cb, int Hs, int Ws);
 int tconv2d_bwd_fused(const float* small, long s_bs, const float* big, long big_bs, const float* w, float* dsmall, int dact,
                       float* dw, float* db, int B, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
-                      GradJobs* defer = nullptr, int big_bf16 = 0);
+                      GradJobs* defer = nullptr, int big_bf16 = 0, int small_bf16 = 0);
 
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
@@ -204,7 +207,7 @@ int conv1d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
                         int bias_from, int nbias, int B, int Cs, int Cb, int Ls, int Lb, int pad, float* ws,
                         size_t wsf, int accumulate, hipStream_t st, const float* small2 = nullptr,
                         const float* big2 = nullptr, float* dw2 = nullptr, float* db2 = nullptr,
-                        GradJobs* defer = nullptr, int big_bf16 = 0, const FusedDgrad* fd = nullptr);
+                        GradJobs* defer = nullptr, int big_bf16 = 0, const FusedDgrad* fd = nullptr, int small_bf16 = 0);
 
 // ---- LDS-resident chains of three k4 s4 1-D layers (chain1d.hip) -------------------------------
 // one stage: weights, optional bias, global output (B, Cout, Lout) and either ELU (act) or the ELU' multiply by the

@@ -119,9 +119,9 @@ int conv_layer_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, float* ws, 
   conv_out_dims(L, Ho, Wo);
   switch (L.kind) {
     case 0: {
-      if (!io2 && conv2d_direct_supported(L.Cin, L.Cout, Ho, Wo) && !L.out_bf16)
+      if (!io2 && conv2d_direct_supported(L.Cin, L.Cout, Ho, Wo))  // (the launcher refuses storage combinations it has no kernel for)
         return conv2d_direct(io.x, L.in_bs, io.w, io.b, io.y, L.out_bs, nullptr, L.B, L.Cin, L.Cout, Ho, Wo, act, st,
-                             L.in_bf16);
+                             L.in_bf16, L.out_bf16);
       if (L.in_bf16 || L.out_bf16) return bf16_unsupported();
       const Conv2dFwdParams p = p_conv2d_fwd(L, io, act, Ho, Wo);
       if (!io2) return conv2d_fwd(p, ws, wsf, st);
@@ -129,9 +129,9 @@ int conv_layer_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, float* ws, 
       return conv2d_fwd(p, ws, wsf, st, &q);
     }
     case 1: {
-      if (!io2 && tconv2d_direct_supported(L.Cin, L.Cout, L.Hin, L.Win) && !L.in_bf16)
+      if (!io2 && tconv2d_direct_supported(L.Cin, L.Cout, L.Hin, L.Win))
         return tconv2d_direct(io.x, L.in_bs, io.w, io.b, io.y, L.out_bs, nullptr, L.B, L.Cin, L.Cout, L.Hin, L.Win,
-                              act, st, L.out_bf16);
+                              act, st, L.out_bf16, L.in_bf16);
       if (L.in_bf16 || L.out_bf16) return bf16_unsupported();
       const Conv2dDgradParams p = p_tconv2d_fwd(L, io, act);
       if (!io2) return conv2d_dgrad(p, ws, wsf, st);
@@ -139,23 +139,25 @@ int conv_layer_fwd(const ConvLayer& L, const ConvFwdIO& io, int act, float* ws, 
       return conv2d_dgrad(p, ws, wsf, st, &q);
     }
     case 2: {
-      if (L.out_bf16) return bf16_unsupported();
       Conv1dFwdParams p = p_conv1d_fwd(L, io, act, Wo);
       p.x_bf16 = L.in_bf16;
-      if (L.in_bf16 && !conv1d_stream_supported(p)) return bf16_unsupported();
+      p.y_bf16 = L.out_bf16;
+      if ((L.in_bf16 || L.out_bf16) && !conv1d_stream_supported(p)) return bf16_unsupported();
       if (!io2) return conv1d_fwd(p, ws, wsf, st);
       Conv1dFwdParams q = p_conv1d_fwd(L, *io2, act, Wo);
       q.x_bf16 = L.in_bf16;
+      q.y_bf16 = L.out_bf16;
       return conv1d_fwd(p, ws, wsf, st, &q);
     }
     default: {
-      if (L.in_bf16) return bf16_unsupported();
       Conv1dDgradParams p = p_tconv1d_fwd(L, io, act, Wo);
       p.big_bf16 = L.out_bf16;
-      if (L.out_bf16 && !tconv1d_stream_supported(p)) return bf16_unsupported();
+      p.s_bf16 = L.in_bf16;
+      if ((L.in_bf16 || L.out_bf16) && !tconv1d_stream_supported(p)) return bf16_unsupported();
       if (!io2) return conv1d_dgrad(p, ws, wsf, st);
       Conv1dDgradParams q = p_tconv1d_fwd(L, *io2, act, Wo);
       q.big_bf16 = L.out_bf16;
+      q.s_bf16 = L.in_bf16;
       return conv1d_dgrad(p, ws, wsf, st, &q);
     }
   }
@@ -183,10 +185,10 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
   int Ho, Wo;
   conv_out_dims(L, Ho, Wo);
   switch (L.kind) {
-    case 0: {  // dx (big) from dz (small)
-      if (!io2 && tconv2d_direct_supported(L.Cout, L.Cin, Ho, Wo) && !L.out_bf16 && !(L.in_bf16 && io.dact_in))
+    case 0: {  // dx (big) from dz (small); the ELU' reference (the layer's saved input) has dx's storage type
+      if (!io2 && tconv2d_direct_supported(L.Cout, L.Cin, Ho, Wo))
         return tconv2d_direct(io.dz, L.out_bs, io.w, nullptr, io.dx, L.in_bs, io.dact_in, L.B, L.Cout, L.Cin, Ho, Wo,
-                              0, st, L.in_bf16);
+                              0, st, L.in_bf16, L.out_bf16);
       if (L.in_bf16 || L.out_bf16) return bf16_unsupported();
       const Conv2dDgradParams p = p_conv2d_dgrad(L, io, Ho, Wo);
       if (!io2) return conv2d_dgrad(p, ws, wsf, st);
@@ -194,9 +196,9 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
       return conv2d_dgrad(p, ws, wsf, st, &q);
     }
     case 1: {  // dx (small) = strided conv of dz (big) with the same weight tensor
-      if (!io2 && conv2d_direct_supported(L.Cout, L.Cin, L.Hin, L.Win) && !L.in_bf16)
+      if (!io2 && conv2d_direct_supported(L.Cout, L.Cin, L.Hin, L.Win))
         return conv2d_direct(io.dz, L.out_bs, io.w, nullptr, io.dx, L.in_bs, io.dact_in, L.B, L.Cout, L.Cin, L.Hin,
-                             L.Win, 0, st, L.out_bf16);
+                             L.Win, 0, st, L.out_bf16, L.in_bf16);
       if (L.in_bf16 || L.out_bf16) return bf16_unsupported();
       const Conv2dFwdParams p = p_tconv2d_dgrad(L, io, Ho, Wo);
       if (!io2) return conv2d_fwd(p, ws, wsf, st);
@@ -204,23 +206,25 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
       return conv2d_fwd(p, ws, wsf, st, &q);
     }
     case 2: {  // dx (big, the layer's input) from dz (small)
-      if (L.out_bf16 || (L.in_bf16 && io.dact_in)) return bf16_unsupported();
       Conv1dDgradParams p = p_conv1d_dgrad(L, io, Wo);
       p.big_bf16 = L.in_bf16;
-      if (L.in_bf16 && !tconv1d_stream_supported(p)) return bf16_unsupported();
+      p.s_bf16 = L.out_bf16;
+      if ((L.in_bf16 || L.out_bf16) && !tconv1d_stream_supported(p)) return bf16_unsupported();
       if (!io2) return conv1d_dgrad(p, ws, wsf, st);
       Conv1dDgradParams q = p_conv1d_dgrad(L, *io2, Wo);
       q.big_bf16 = L.in_bf16;
+      q.s_bf16 = L.out_bf16;
       return conv1d_dgrad(p, ws, wsf, st, &q);
     }
     default: {  // dx (small) = strided conv of dz (big, the layer's output gradient)
-      if (L.in_bf16) return bf16_unsupported();
       Conv1dFwdParams p = p_tconv1d_dgrad(L, io, Wo);
       p.x_bf16 = L.out_bf16;
-      if (L.out_bf16 && !conv1d_stream_supported(p)) return bf16_unsupported();
+      p.y_bf16 = L.in_bf16;
+      if ((L.in_bf16 || L.out_bf16) && !conv1d_stream_supported(p)) return bf16_unsupported();
       if (!io2) return conv1d_fwd(p, ws, wsf, st);
       Conv1dFwdParams q = p_tconv1d_dgrad(L, *io2, Wo);
       q.x_bf16 = L.out_bf16;
+      q.y_bf16 = L.in_bf16;
       return conv1d_fwd(p, ws, wsf, st, &q);
     }
   }
@@ -231,7 +235,7 @@ bool conv_layer_bwd_fusable(const ConvLayer& L, const ConvWgradIO& io, const Con
   // the ELU' reference of the data gradient, if any, must be the layer's own input (it is, for every layer behind an ELU)
   if (dio.dact_in && dio.dact_in != io.x) return false;
   if (L.kind == 1)  // 2-D transposed: the outermost decoder layer (8 -> 4 channels)
-    return !getenv("LSHM_BWD_FUSED2D_OFF") && !L.in_bf16 && tconv2d_bwd_fused_supported(L.Cin, L.Cout, L.Hin, L.Win);
+    return !getenv("LSHM_BWD_FUSED2D_OFF") && tconv2d_bwd_fused_supported(L.Cin, L.Cout, L.Hin, L.Win);
   if (L.kind == 3)  // transposed: small = the layer's input, big = dz
     return conv1d_bwd_fused_supported(L.Cin, L.Cout, 0) && (dio.dact_in || conv1d_bwd_fused2_supported(L.Cin, L.Cout, 0)) &&
            conv1d_wgrad_direct_supported(L.Cin, L.Cout, L.Win);
@@ -266,9 +270,10 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
   float* gemm_ws = ws + BIAS_WS_FLOATS;
   const size_t gemm_wsf = ws_floats - BIAS_WS_FLOATS;
   int rc;
-  // bf16 storage: the `big` tensor (the layer's input for a conv, its output gradient for a transposed conv) may be bf16
+  // bf16 storage: the `big` tensor (the layer's input for a conv, its output gradient for a transposed conv) of the two
+  // outer layers and the `small` one of the outermost layer may be bf16; the kernels' launchers refuse the rest
   const int big_bf16 = tr ? L.out_bf16 : L.in_bf16;
-  if ((tr ? L.in_bf16 : L.out_bf16)) return bf16_unsupported();  // `small` side: never stored as bf16
+  const int small_bf16 = tr ? L.in_bf16 : L.out_bf16;
   if (L.kind < 2) {
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
     if (fuse) {
@@ -277,15 +282,15 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
         return LSHM_ERR_UNSUPPORTED;
       }
       return tconv2d_bwd_fused(io.x, s_bs, io.dz, big_bs, fuse->w, fuse->dx, fuse->dact_in ? 1 : 0, io.dw, io.db, L.B, Hs, Ws,
-                               gemm_ws, gemm_wsf, accumulate, st, defer, big_bf16);
+                               gemm_ws, gemm_wsf, accumulate, st, defer, big_bf16, small_bf16);
     }
     if (!io2 && conv2d_wgrad_direct_supported(Cs, Cb, Hs, Ws) &&
         gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
       // weight and bias gradient in one pass (dz is `big` for the transposed conv, `small` otherwise)
       return conv2d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.B, Cs, Cb, Hs,
-                                 Ws, gemm_ws, gemm_wsf, accumulate, st, defer, big_bf16);
+                                 Ws, gemm_ws, gemm_wsf, accumulate, st, defer, big_bf16, small_bf16);
     } else {
-      if (big_bf16) return bf16_unsupported();
+      if (big_bf16 || small_bf16) return bf16_unsupported();
       Conv2dWgradParams p{small_of(io), big_of(io), io.dw, L.B, Cs, Hs, Ws, Cb, s_bs, big_bs,
                           g.M, g.N, g.K, accumulate, {}};
       if (io2) {
@@ -312,10 +317,11 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
       return conv1d_wgrad_direct(small_of(io), s_bs, big_of(io), big_bs, io.dw, io.db, tr ? 2 : 1, L.Cout, L.B, Cs,
                                  Cb, Ls, Lb, tr ? 0 : 1, gemm_ws, gemm_wsf, accumulate, st,
                                  io2 ? small_of(*io2) : nullptr, io2 ? big_of(*io2) : nullptr,
-                                 io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr, defer, big_bf16, fuse ? &fd : nullptr);
+                                 io2 ? io2->dw : nullptr, io2 ? io2->db : nullptr, defer, big_bf16, fuse ? &fd : nullptr,
+                                 small_bf16);
     }
     if (fuse) { set_last_error("conv wgrad: fused data gradient not available for this layer"); return LSHM_ERR_UNSUPPORTED; }
-    if (big_bf16) return bf16_unsupported();
+    if (big_bf16 || small_bf16) return bf16_unsupported();
     static const bool use_mid = getenv("LSHM_WGRAD_MID_OFF") == nullptr;
     if (use_mid && gemm_wsf >= G * conv1d_wgrad_mid_workspace_floats(Cs, Cb) &&
         conv1d_wgrad_mid_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(io), big_of(io)) &&

@@ -111,8 +111,9 @@ def _single_process(lbfgs):
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("path", ["torch", "engine", "engine-one-rank-fails"])
-@pytest.mark.parametrize("lbfgs", [False, True], ids=["adam", "lbfgs"])
+@pytest.mark.parametrize("lbfgs,path", [(False, "torch"), (True, "torch"), (False, "engine"), (True, "engine"),
+                                        (False, "engine-one-rank-fails")],  # (the fallback decision is made at construction: one optimiser suffices)
+                         ids=["adam-torch", "lbfgs-torch", "adam-engine", "lbfgs-engine", "adam-engine-one-rank-fails"])
 def test_two_ranks_on_one_gpu_equal_the_global_batch(lbfgs, path):
     """engine -> all-reduce -> optimiser on two ranks == one process on the global batch: replicated parameters
     identical across ranks (bitwise) and equal to the global-batch parameters to 2e-5; the logged terms are the
@@ -124,8 +125,6 @@ def test_two_ranks_on_one_gpu_equal_the_global_batch(lbfgs, path):
     communicator; the ranks must agree to fall back together instead of issuing mismatched collectives."""
     if path != "torch" and not os.path.exists(FAKE_RCCL):
         pytest.fail("tests/fake_rccl/libfake_rccl.so is not built (make testlibs)")
-    if path == "engine-one-rank-fails" and lbfgs:
-        pytest.skip("the fallback decision is made at construction: one optimiser suffices")
     got = _run_two_ranks(lbfgs, engine_comm=path != "torch", fail_rank=1 if path == "engine-one-rank-fails" else None)
     ref = _single_process(lbfgs)
     p0, p1 = torch.from_numpy(got[0][1]), torch.from_numpy(got[1][1])
