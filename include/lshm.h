@@ -140,6 +140,20 @@ int lshm_conv_bwd_fused(int kind, const float* x, const float* dz, const float* 
  * w[k] / bias[k] (bias may be NULL) in the layers' own torch layouts; dact (NULL or 3 pointers): out[k] *= ELU'(dact[k]). */
 int lshm_conv1d_chain3(int up, const float* x, const float* const* w, const float* const* bias, float* const* out,
                        const float* const* dact, int act, int pad, int B, lshm_stream_t stream);
+/* The dense middle of AutoEncoder1DCNN(latent_dim=16, rica=True) as ONE launch per direction (src/lofar_models.py:
+ * 127-135,165-176 and their backward): 16 batch rows per workgroup stay in LDS through the four layers.
+ *   forward: cat1 (B,784) = [conv5 output | elu(fcuv1(uvh))] -> z1 = elu(fc1) (B,16) -> mu = elu(fc2in) (B,16 inside a
+ *     (B,ldmu) matrix: the shared latent buffer) -> cat3[:, :16] = elu(fc2out) (cat3 (B,32); its columns 16..31 =
+ *     elu(fcuv3(uvh)) must already be there) -> d0 = fc3(cat3) (B,768).  wb = {fc1.weight, fc1.bias, fc2in.weight,
+ *     fc2in.bias, fc2out.weight, fc2out.bias, fc3.weight, fc3.bias} (torch layouts).
+ *   backward: dd0 (B,768) = gradient of fc3's output -> dcat3 (B,32), dzmu (B,16) (with the latent-term gradient gmu
+ *     added before the ELU' multiply), dz1 (B,16), dcat1 (B,784): the pre-activation gradients the weight gradients
+ *     and conv5's data gradient read.  w = {fc1.weight, fc2in.weight, fc2out.weight, fc3.weight}. */
+int lshm_dense1d_fwd(const float* cat1, const float* const* wb, float* z1, float* mu, long ldmu, float* cat3, float* d0, int B,
+                     lshm_stream_t stream);
+int lshm_dense1d_bwd(const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
+                     const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
+                     lshm_stream_t stream);
 /* dz = gy * ELU'(y) from the saved output y                      (autograd of F.elu) */
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t stream);
 

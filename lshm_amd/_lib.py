@@ -62,6 +62,9 @@ _SIGNATURES = {
     "lshm_conv_bwd_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lshm_conv1d_chain3": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "lshm_dense1d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p]),
+    "lshm_dense1d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lshm_elu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "lshm_linear_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "lshm_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,

@@ -10,6 +10,8 @@
 //   * results go through an LDS output tile and leave as full-row float4 stores, with bias, ELU and
 //     the ELU' multiply of the backward pass fused.
 // Arithmetic is v_mfma_f32_16x16x4_f32 (exact fp32).
+#include <stdlib.h>
+
 #include "kernels.h"
 
 namespace lshm {
@@ -359,7 +361,8 @@ int tconv2d_direct(const float* small, long s_bs, const float* w, const float* b
       hipLaunchKernelGGL((tconv2d_q4_kernel<4>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
   } else if (Cs == 12 && Cb == 8) {
     const int ntiles = (Ws / 32) * (Hs / 8) * B;
-    const dim3 grid(ntiles < 768 ? ntiles : 768);
+    static const int cap = [] { const char* v = getenv("LSHM_GRID_TCONV2D_12_8"); return v && atoi(v) > 0 ? atoi(v) : 768; }();
+    const dim3 grid(ntiles < cap ? ntiles : cap);
     if (big_bf16)
       hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32, bf16>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
     else
@@ -1182,7 +1185,8 @@ int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, 
     const int ntiles = (Wo / 32) * (Ho / 8) * B;
     // 38 KB of LDS and <= 128 VGPRs: four workgroups per CU, so the 1024 tiles of B = 256 are resident at once
     // (768 workgroups left a second round with a third of the machine busy)
-    const dim3 grid(ntiles < 1024 ? ntiles : 1024);
+    static const int cap = [] { const char* v = getenv("LSHM_GRID_CONV2D_8_12"); return v && atoi(v) > 0 ? atoi(v) : 1024; }();
+    const dim3 grid(ntiles < cap ? ntiles : cap);
     if (x_bf16)
       hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32, bf16>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
     else

@@ -365,6 +365,13 @@ static void recon_launch_t(bool upd, const float* x, const T* x1, const T* x2, c
     hipLaunchKernelGGL((recon_kernel<false, true, T>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho, inv_n, P,
                        part, gx1p, gx2, gx3c);
 }
+int recon_sum7(const float* block_partials, int planes, int P, double* sums7, hipStream_t st) {
+  hipLaunchKernelGGL(sum7_kernel, dim3(7), dim3(1024), 0, st, reinterpret_cast<const double*>(block_partials),
+                     (long)planes * (P / TILE) * (P / TILE), sums7);
+  return check_launch("recon_sum7");
+}
+// sums7 == nullptr: the per-block partials are left in block_partials and the caller runs recon_sum7 later (the sums are
+// only needed where the loss terms are assembled, which is not on the critical path of the step)
 static int recon_launch(bool upd, const float* x, const float* x1, const float* x2, const float* x3c, float* y1,
                         float* y2, float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
                         float* gx3c, float* block_partials, hipStream_t st, float grad_scale, int bf = 0) {
@@ -381,7 +388,7 @@ static int recon_launch(bool upd, const float* x, const float* x1, const float* 
     recon_launch_t<float>(upd, x, x1, x2, x3c, y1, y2, y3, rho, inv_n, P, part, gx1p, gx2, gx3c, grid, st);
   }
   int rc = check_launch("recon_losses");
-  if (rc) return rc;
+  if (rc || !sums7) return rc;
   hipLaunchKernelGGL(sum7_kernel, dim3(7), dim3(1024), 0, st, part,
                      (long)grid.x * grid.y * grid.z, sums7);
   return check_launch("recon_sum7");

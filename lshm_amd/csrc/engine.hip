@@ -80,6 +80,7 @@ struct lshm_engine {
   // forwards that do not depend on each other -- the no-grad forward that closes iteration k and the closure
   // forward that opens iteration k+1 -- run side by side on two streams, each with `ws` or `ws + alt_base` as base.
   size_t o_fpart, fwd_floats, alt_base;
+  size_t o_recon_part;  // per-block partial sums of the reconstruction pass (its own buffer: their seven sums may be made later, beside the backward)
   hipStream_t fstream = nullptr;  // the no-grad forward + shared reconstruction pass, beside the next closure forward
   // Two "lanes" of backward scratch: netT and netF (independent given AE1's output, identical
   // shapes) run as pairs inside the same launches, each with its own lane; o_part/o_wpart of a
@@ -98,6 +99,7 @@ struct lshm_engine {
   hipEvent_t latent_event;  // set while the latent-space terms of the current forward are in flight
   bool sim_started = false;  // cluster_similarity of the current forward already launched (side stream)
   bool recon_ready;         // the workspace already holds the reconstruction terms of the next closure
+  bool sum7_pending = false;  // ... as per-block partials: their seven sums are made on the latent-space stream of the next closure
   size_t o_latent_ws, latent_ws_floats;
   bool side_ok;
   bool pair_mode;  // netT/netF share launches (default) instead of running on two streams (LSHM_FORK=1)
@@ -282,7 +284,22 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   };
   auto both = [&](auto f) { Lin q{}; for (int g = 0; g < 2; ++g) f(q, g, A(g)); return q; };
   // (elu(fcuv1(uvh)) and elu(fcuv3(uvh)) are already in cat1 / cat3: the uv_features step)
-  if (c.rica) {
+  const bool dense_chain = a0.ndim == 1 && dense1d_supported(L, hd, c.rica);
+  if (dense_chain) {
+    // fc1 -> fc2in -> fc2out -> fc3 of the 1-D autoencoders as one launch (dense1d.hip); the latents are complete inside it,
+    // so the latent-space terms start right after it
+    steps.push_back([=](float* ws, hipStream_t st) -> int {
+      Dense1dFwdIO io[2];
+      for (int g = 0; g < G; ++g) {
+        const AEPlan& a = A(g);
+        io[g] = Dense1dFwdIO{ws + a.cat1, prm + a.fc1w, prm + a.fc1b, prm + a.fc2inw, prm + a.fc2inb, prm + a.fc2outw,
+                             prm + a.fc2outb, prm + a.fc3w, prm + a.fc3b, ws + a.z1, ws + e->o_Mu + a.mu_col, ws + a.cat3,
+                             ws + a.d0};
+      }
+      return dense1d_fwd(io[0], G > 1 ? &io[1] : nullptr, D, B, st);
+    });
+    if (latent_mark) *latent_mark = steps.size();
+  } else if (c.rica) {
     Lin q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = a.cat1; q.w[g] = a.fc1w; q.b[g] = a.fc1b; q.y[g] = a.z1; });
     q.ldx = 768 + hd; q.ldy = L; q.K = 768 + hd; q.N = L; q.act = 1;
     lin(q);
@@ -301,8 +318,8 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
       steps.push_back([=](float* ws, hipStream_t st) -> int { return copy2d(ws + src, D, ws + dst, L + hd, B, L, st); });
     }
   }
-  if (latent_mark) *latent_mark = steps.size();
-  {
+  if (!dense_chain) {
+    if (latent_mark) *latent_mark = steps.size();
     Lin q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = a.cat3; q.w[g] = a.fc3w; q.b[g] = a.fc3b; q.y[g] = a.d0; });
     q.ldx = L + hd; q.ldy = 768; q.K = L + hd; q.N = 768; q.act = 0;
     lin(q);
@@ -509,11 +526,24 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     });
     return release(false);
   };
+  // 1-D autoencoders: the four data gradients of the dense layers are one launch (dense1d.hip); the weight gradients
+  // below still read the buffers it fills
+  static const bool dense_bwd_on = getenv("LSHM_DENSE1D_BWD_OFF") == nullptr;
+  const bool dense_chain = dense_bwd_on && a0.ndim == 1 && dense1d_supported(L, hd, c.rica);
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
+    if (dense_chain) return (int)LSHM_OK;
     return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr);
   };
   // the latent-space gradient enters at fc3: whoever produced it beside the decoders is joined here, not earlier
   if (before_dense && (rc = (*before_dense)())) return rc;
+  if (dense_chain) {
+    Dense1dBwdIO io[2];
+    for (int g = 0; g < G; ++g)
+      io[g] = Dense1dBwdIO{ws + LA(g).o_dd0, ws + A(g).cat3, ws + e->o_Mu + A(g).mu_col, ws + e->o_gMu + A(g).mu_col, ws + A(g).z1,
+                           ws + A(g).cat1, prm + A(g).fc1w, prm + A(g).fc2inw, prm + A(g).fc2outw, prm + A(g).fc3w,
+                           ws + LA(g).o_dcat3, ws + LA(g).o_dzmu, ws + LA(g).o_dz1, ws + LA(g).o_dcat1};
+    if ((rc = dense1d_bwd(io[0], G > 1 ? &io[1] : nullptr, D, D, B, st))) return rc;
+  }
   // ---- fc3 (no activation on its output): dd0 is its pre-activation gradient
   for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{ws + A(g).cat3, ws + LA(g).o_dd0, grd + A(g).fc3w, grd + A(g).fc3b};
   if ((rc = wgrad(L + hd, 768, L + hd, 768))) return rc;
@@ -663,6 +693,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   const lshm_step_config& c = e->cfg;
   int rc;
   e->recon_ready = false;  // a new forward: whatever reconstruction terms the workspace held are stale
+  e->sum7_pending = false;
   if (e->pair_mode || !e->side_ok) {  // every launch of netT / netF carries both problems
     const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
     for (size_t i = 0; i < P.steps.size(); ++i) {
@@ -720,6 +751,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
 static int two_forwards(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws_a, hipStream_t st_a,
                         float* ws_b, hipStream_t st_b, bool skip_b_1d_output) {
   e->recon_ready = false;
+  e->sum7_pending = false;
   const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
   // default 0 (lock step, no gate).  Measured (profiles/r03/README.md): 0: 2.28 ms, 6: 2.32, 12: 2.39, 24: 2.49 -- a
   // latency-bound launch beside a bandwidth-bound one is starved (up to 10x longer), so like phases belong together
@@ -787,15 +819,25 @@ static int latent_losses(lshm_engine* e, const float* prm, float* grd, float* ws
 
 // forward of the three autoencoders with the latent-space terms overlapped (side stream if there is one)
 // latent-space terms on the side stream if there is one (joined in losses_and_backward), else in line
+static int pending_sum7(lshm_engine* e, float* ws, hipStream_t st) {
+  if (!e->sum7_pending) return LSHM_OK;
+  e->sum7_pending = false;
+  return recon_sum7(ws + e->o_recon_part, e->cfg.B * e->cfg.C, e->cfg.P, reinterpret_cast<double*>(ws + e->o_scal), st);
+}
 static int start_latent_losses(lshm_engine* e, const float* prm, float* grd, float* ws, hipStream_t st) {
   e->latent_event = nullptr;
-  if (!(e->side_ok && e->side_wgrad)) return latent_losses(e, prm, grd, ws, st);
+  int rc;
+  if (!(e->side_ok && e->side_wgrad)) {
+    if ((rc = pending_sum7(e, ws, st))) return rc;
+    return latent_losses(e, prm, grd, ws, st);
+  }
   hipEvent_t ev = e->take_event();
   if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->lstream, ev, 0) != hipSuccess) {
     set_last_error("engine: stream fork failed");
     return LSHM_ERR_ARG;
   }
-  int rc = latent_losses(e, prm, grd, ws, e->lstream);
+  if ((rc = pending_sum7(e, ws, e->lstream))) return rc;  // the sums of the reconstruction pass made with the previous forwards
+  rc = latent_losses(e, prm, grd, ws, e->lstream);
   if (rc) return rc;
   e->latent_event = e->take_event();
   if (hipEventRecord(e->latent_event, e->lstream) != hipSuccess) {
@@ -846,7 +888,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
   // (a gradient-free closure passes no gradient images: the kernel then only reads)
   if (!recon_done && (rc = recon_losses_fwd_bwd(x, ws + e->ae[0].out, ws + e->ae[1].out, ws + e->ae[2].out, y1, y2, y3,
                                  c.rho, planes, c.P, scal, grd ? ws + e->o_gx1p : nullptr, grd ? ws + e->o_gx2 : nullptr,
-                                 grd ? ws + e->o_gx3c : nullptr, ws + e->lane[0].o_part, st, (float)(1.0 / world), e->bf))) return rc;
+                                 grd ? ws + e->o_gx3c : nullptr, ws + e->o_recon_part, st, (float)(1.0 / world), e->bf))) return rc;
   const double inv_count = 1.0 / (world * (double)B * c.K * D);
   double* rica_part = scal + 16 + (B + c.bpb - 1) / c.bpb;  // [LOGCOSH3_BLOCKS][3]
   // The latent-space terms ran beside the decoders (their own stream).  Their scalars close the loss terms and
@@ -1144,6 +1186,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     la.o_dd0 = take(cur, (size_t)B * 768);
   }
   e->o_dMscratch = take(cur, (size_t)cfg->K * e->D);
+  e->o_recon_part = take(cur, recon_partials_floats(B * cfg->C, cfg->P));
   e->latent_ws_floats = khm_workspace_floats(B, e->D, cfg->K);
   e->o_latent_ws = take(cur, e->latent_ws_floats);
   e->latent_event = nullptr;
@@ -1334,10 +1377,13 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
   // forward -- so their last decoder layer is not run), enqueued in lock step
   int rc = concurrent ? two_forwards(e, params, x, uv, fws, fst, ws, st, true) : three_forward(e, params, x, uv, fws, fst);
   if (rc) return rc;
+  // concurrent: the seven sums of the pass (a 13 us launch the caller's stream would wait for) move to the latent-space
+  // stream of the next closure: nothing needs them before the loss terms are assembled there
   rc = multiplier_update_recon(x, fws + e->ae[0].out, fws + e->ae[1].out, fws + e->ae[2].out, y1, y2, y3, c.rho,
-                               c.B * c.C, c.P, reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
-                               ws + e->o_gx2, ws + e->o_gx3c, ws + e->lane[0].o_part, fst, (float)(1.0 / world), e->bf);
+                               c.B * c.C, c.P, concurrent ? nullptr : reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
+                               ws + e->o_gx2, ws + e->o_gx3c, ws + e->o_recon_part, fst, (float)(1.0 / world), e->bf);
   if (rc) return rc;
+  e->sum7_pending = concurrent;
   if (concurrent) {
     hipEvent_t evj = e->take_event();
     if (hipEventRecord(evj, fst) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {

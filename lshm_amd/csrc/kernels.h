@@ -225,6 +225,21 @@ struct Chain1dStage {
 bool conv1d_chain_supported(bool up, const int* ch, int L0);
 int conv1d_chain(bool up, const Chain1dStage* st, const float* in0, const float* in1, long in_bs, int pad, int B, hipStream_t s);
 
+// ---- the dense middle of AutoEncoder1DCNN (latent_dim 16, rica) as one launch per direction (dense1d.hip) ----------
+struct Dense1dFwdIO {
+  const float* cat1;                                   // (B, 784) [conv5 output | elu(fcuv1)]
+  const float *fc1w, *fc1b, *fc2inw, *fc2inb, *fc2outw, *fc2outb, *fc3w, *fc3b;
+  float *z1, *mu, *cat3, *d0;                          // (B,16), (B,16) inside Mu (ld ldmu), (B,32), (B,768)
+};
+struct Dense1dBwdIO {
+  const float *dd0, *cat3, *mu, *gmu, *z1, *cat1;      // gradient of fc3's output; saved activations; latent-term gradient
+  const float *fc1w, *fc2inw, *fc2outw, *fc3w;
+  float *dcat3, *dzmu, *dz1, *dcat1;                   // (B,32), (B,16), (B,16), (B,784)
+};
+bool dense1d_supported(int L, int hd, int rica);
+int dense1d_fwd(const Dense1dFwdIO& p, const Dense1dFwdIO* p1, long ldmu, int B, hipStream_t st);
+int dense1d_bwd(const Dense1dBwdIO& p, const Dense1dBwdIO* p1, long ldmu, long ldgmu, int B, hipStream_t st);
+
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0
 struct ConvLayer {
@@ -325,6 +340,8 @@ int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const
                          float grad_scale = 1.f, int bf = 0)  /* gradients (not the sums) are multiplied by grad_scale;
                                                                  bf: x1..x3c and the gradient images are bf16 */;
 size_t recon_partials_floats(int planes, int P);
+// second stage of the reconstruction pass on its own (multiplier_update_recon with sums7 == nullptr leaves it to the caller)
+int recon_sum7(const float* block_partials, int planes, int P, double* sums7, hipStream_t st);
 int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
                             float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
                             float* gx3c, float* block_partials, hipStream_t st, float grad_scale = 1.f, int bf = 0);
