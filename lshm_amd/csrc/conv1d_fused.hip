@@ -266,11 +266,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_bwd_fused2_kernel(const FusedBw
   }
 }
 
+bool conv1d_bwd_lds_supported(int Cs, int Cb, int Ls, int pad);
+int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs, float* ws,
+                   float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks, hipStream_t st, int* grid_out,
+                   const FusedDgrad& fd, int big_bf16);
 bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
   // 12 / 8 channels: 96 accumulator registers + the data-gradient working set do not fit two wavefronts per SIMD
   // (the compiler spills 80-330 registers; 67-129 us against 50 us for the two separate kernels, profiles/r03):
   // opt-in only (LSHM_FUSED2_12_8=1) until those layers get an LDS-staged form
-  const bool wide = getenv("LSHM_FUSED2_12_8") != nullptr;  // read per call: the parity tests switch it on for two cases
+  // -> the LDS-staged form below (conv1d_bwd_lds_kernel) is the default for them; LSHM_FUSED2_12_8=1 selects the register form
+  const bool wide = getenv("LSHM_FUSED2_12_8") != nullptr || getenv("LSHM_BWD_LDS_OFF") == nullptr;  // read per call (tests)
   return (wide && Cs == 12 && Cb == 8 && (pad == 0 || pad == 1)) || (Cs == 8 && Cb == 4 && (pad == 0 || pad == 1));
 }
 
@@ -278,6 +283,8 @@ bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
 int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs,
                       float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks,
                       hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd, int small_bf16) {
+  if (Cs == 12 && !small_bf16 && (big_bf16 || !getenv("LSHM_FUSED2_12_8")) && conv1d_bwd_lds_supported(Cs, Cb, Ls, pad))
+    return conv1d_bwd_lds(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, max_blocks, st, grid_out, fd, big_bf16);
   const bool two = small2 != nullptr;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!conv1d_bwd_fused2_supported(Cs, Cb, pad) || Ls % 64 || Lb != 4 * Ls || s_bs % 4 || big_bs % 4 || fd.dx_bs % 4 ||
@@ -318,6 +325,271 @@ int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const 
   else LSHM_FUSED2(8, 4, true, false, float, float);
 #undef LSHM_FUSED2
   return check_launch("conv1d_bwd_fused");
+}
+
+}  // namespace lshm
+
+namespace lshm {
+
+// ----------------------------------------------------------------------------------------------
+// One-pass backward of the 12 <-> 8 channel 1-D layers (tconv4: src/lofar_models.py:141, conv1: :116), LDS-staged:
+// the register form above keeps 96 accumulator registers for the 4x4x1 weight gradient and spills; here a tile of TP
+// small positions and the matching big segment are staged in LDS once (float4 loads, next tile in flight in
+// registers: the layout of conv1d_wgrad_mid_kernel) and BOTH products run on v_mfma_f32_16x16x4_f32 from it:
+//   weight gradient   dW[cs][(cb,t)] += small[cs][p] big[cb][4p - pad + t]        M = cs, N = 32, K = positions
+//   transposed layer  dsmall[p][cs]   = ELU'(small) * sum_(cb,t) big[cb][4p + t] w[cs][cb][t]     M = p, N = cs, K = 32
+//   conv layer        dbig[p][(cb,t)] = ELU'(big)   * sum_cs small[cs][p] w[cs][cb][t]            M = p, N = 32, K = 12
+// (a handful of accumulator registers; the weights of the data gradient are 6-8 registers per lane).  The conv
+// layer's output window of position p is big[4p - 1 .. 4p + 2]: results go through an LDS image at offset +1, so the
+// tile's aligned output quads need tap 0 of the position AFTER the tile -- one extra small column, a 12-term sum per
+// big channel.
+// ----------------------------------------------------------------------------------------------
+struct BwdLds1dArgs {
+  const float* small[2];
+  const float* big[2];
+  const float* w[2];
+  float* partial[2];
+  float* dout[2];
+  long s_bs, big_bs, d_bs;
+  int Ls, Lb, ntiles;
+};
+
+// TB: element type of the big tensor and (conv layer) of its gradient -- fp32, or bf16 storage
+template <int CS, int CB, int TP, bool CONV, bool DACT, typename TB>
+__global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs a) {
+  static_assert(CS <= 16 && CS % 4 == 0 && CB % 4 == 0 && TP % 64 == 0, "one 16-row tile of small channels");
+  constexpr int NT = CB / 4, NW = CS * CB * 4, SLAB = NW + 16;
+  constexpr int pad = CONV ? 1 : 0;
+  constexpr int LDS_S = TP + 2;   // small row pitch (== 2 mod 32); column TP holds the position after the tile (CONV)
+  constexpr int BP = 4 * TP + 8;  // big row pitch (== 8 mod 32); bimg[cb][1 + i] = big[cb][4 j0 + i], [0] = element before
+  constexpr int CPITCH = CB * 4 + 4;
+  constexpr int OB = CONV ? CB * BP : 0;
+  __shared__ __attribute__((aligned(16))) float smem[16 * LDS_S + CB * BP + OB];
+  float* stile = smem;
+  float* bimg = smem + 16 * LDS_S;
+  float* obuf = bimg + CB * BP;  // CONV: data-gradient image, logical element i of the tile at obuf[cb][1 + i]
+  const int pr = blockIdx.y;
+  const float* __restrict__ small = a.small[pr];
+  const TB* __restrict__ big = reinterpret_cast<const TB*>(a.big[pr]);
+  const float* __restrict__ w = a.w[pr];
+  float* __restrict__ dout = a.dout[pr];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 15, lk = lane >> 4;
+  const int Ls = a.Ls, Lb = a.Lb;
+  for (int i = t; i < 16 * LDS_S; i += 256) stile[i] = 0.f;  // rows >= CS stay zero
+  // data-gradient weights of this lane
+  float wd[CONV ? (CS / 4) * NT : CB];
+  if constexpr (CONV) {
+#pragma unroll
+    for (int s = 0; s < CS / 4; ++s)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) wd[s * NT + j] = w[(long)(4 * s + lk) * CB * 4 + 16 * j + lm];  // B[k = cs][n = (cb, t)]
+  } else {
+#pragma unroll
+    for (int s = 0; s < CB; ++s) wd[s] = lm < CS ? w[((long)lm * CB + s) * 4 + lk] : 0.f;  // B[k = (cb = s, t = lk)][n = cs]
+  }
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NQS = (CS * (TP / 4) + 255) / 256, NQB = (CB * TP + 255) / 256;
+  float bs_small[NQS], bs_big[NQB];
+#pragma unroll
+  for (int q = 0; q < NQS; ++q) bs_small[q] = 0.f;
+#pragma unroll
+  for (int q = 0; q < NQB; ++q) bs_big[q] = 0.f;
+  const int tiles_per = Ls / TP;
+  const int bofs = (lm >> 2) * BP + (lm & 3) + 1 - pad;  // weight-gradient B fragment: big channel 4 j + lm / 4, tap lm % 4
+  f32x4 rs[NQS], rb[NQB];
+  float rh = 0.f, rx = 0.f;
+  auto fetch = [&](int tile) {
+    const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * TP;
+    const float* sb = small + (long)b * a.s_bs + j0;
+    const TB* bb = big + (long)b * a.big_bs + 4L * j0;
+#pragma unroll
+    for (int q = 0; q < NQS; ++q) {
+      const int i = t + 256 * q;
+      rs[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CS * (TP / 4)) rs[q] = *reinterpret_cast<const f32x4*>(sb + (long)(i / (TP / 4)) * Ls + 4 * (i % (TP / 4)));
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+      const int i = t + 256 * q;
+      rb[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CB * TP) rb[q] = Elem<TB>::ld4(bb + (long)(i / TP) * Lb + 4 * (i % TP));
+    }
+    rh = (t < CB && pad && j0 > 0) ? Elem<TB>::ld(bb + (long)t * Lb - 1) : 0.f;                      // the element before the segment
+    if constexpr (CONV) rx = (t >= 64 && t < 64 + CS && j0 + TP < Ls) ? sb[(long)(t - 64) * Ls + TP] : 0.f;  // the position after the tile
+  };
+  if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * TP;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NQS; ++q) {
+      const int i = t + 256 * q;
+      if (i < CS * (TP / 4)) {
+        const f32x4 v = rs[q];
+        float* d = &stile[(i / (TP / 4)) * LDS_S + 4 * (i % (TP / 4))];
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        bs_small[q] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NQB; ++q) {
+      const int i = t + 256 * q;
+      if (i < CB * TP) {
+        const f32x4 v = rb[q];
+        float* d = &bimg[(i / TP) * BP + 1 + 4 * (i % TP)];
+        d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        bs_big[q] += (v[0] + v[1]) + (v[2] + v[3]);
+      }
+    }
+    if (t < CB) bimg[t * BP] = rh;
+    if constexpr (CONV) { if (t >= 64 && t < 64 + CS) stile[(t - 64) * LDS_S + TP] = rx; }
+    __syncthreads();
+    if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
+    // ---- weight gradient: groups of 4 positions, every 4th group per wavefront
+#pragma unroll 4
+    for (int s = wave; s < TP / 4; s += 4) {
+      const int p = 4 * s + lk;
+      const float av = stile[lm * LDS_S + p];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bimg[4 * j * BP + bofs + 4 * p], acc[j], 0, 0, 0);
+    }
+    // ---- data gradient: 16-position row tiles, every 4th per wavefront
+    if constexpr (!CONV) {
+      float* dsm = dout + (long)b * a.d_bs + j0;
+      for (int mt = wave; mt < TP / 16; mt += 4) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < CB; ++s) d = __builtin_amdgcn_mfma_f32_16x16x4f32(bimg[s * BP + 1 + 4 * (16 * mt + lm) + lk], wd[s], d, 0, 0, 0);
+        if (lm < CS) {  // lane: positions 16 mt + 4 lk .. + 3 of small channel lm
+          const int p = 16 * mt + 4 * lk;
+          if constexpr (DACT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] *= elu_grad_from_out(stile[lm * LDS_S + p + r]);
+          }
+          *reinterpret_cast<f32x4*>(dsm + (long)lm * Ls + p) = d;
+        }
+      }
+    } else {
+      for (int mt = wave; mt < TP / 16; mt += 4) {
+        f32x4 d[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) d[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < CS / 4; ++s) {
+          const float av = stile[(4 * s + lk) * LDS_S + 16 * mt + lm];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) d[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, wd[s * NT + j], d[j], 0, 0, 0);
+        }
+        // lane: positions 16 mt + 4 lk + r, column (cb = 4 j + lm / 4, t = lm % 4) -> logical element 4 p - 1 + t, kept at + 1
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) obuf[(4 * j + (lm >> 2)) * BP + 4 * (16 * mt + 4 * lk + r) + (lm & 3)] = d[j][r];
+      }
+      __syncthreads();
+      TB* dbg = reinterpret_cast<TB*>(dout) + (long)b * a.d_bs + 4L * j0;
+      for (int i = t; i < CB * TP; i += 256) {
+        const int cb = i / TP, c4 = i - cb * TP;
+        const float* o = obuf + cb * BP + 1 + 4 * c4;
+        f32x4 v = {o[0], o[1], o[2], o[3]};
+        if (c4 == TP - 1) {  // the tile's last element: tap 0 of the position after the tile
+          float s = 0.f;
+#pragma unroll
+          for (int cs = 0; cs < CS; ++cs) s = fmaf(stile[cs * LDS_S + TP], w[((long)cs * CB + cb) * 4], s);
+          v[3] = s;
+        }
+        if constexpr (DACT) {
+          const float* xb = bimg + cb * BP + 1 + 4 * c4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] *= elu_grad_from_out(xb[r]);
+        }
+        Elem<TB>::st4(dbg + (long)cb * Lb + 4 * c4, v);
+      }
+    }
+  }
+  // ---- weight-gradient images of the four wavefronts -> one slab (fixed order), bias partials
+  __syncthreads();
+  float* comb = smem + wave * CS * CPITCH;
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * lk + r;
+      if (row < CS) comb[row * CPITCH + 16 * j + lm] = acc[j][r];
+    }
+  __syncthreads();
+  float* out = a.partial[pr] + (size_t)blockIdx.x * SLAB;
+  for (int i = t; i < NW; i += 256) {
+    const int m = i / (CB * 4), n = i - m * (CB * 4);
+    const float* c0 = smem + m * CPITCH + n;
+    out[i] = (c0[0] + c0[CS * CPITCH]) + (c0[2 * CS * CPITCH] + c0[3 * CS * CPITCH]);
+  }
+  __syncthreads();
+  float* bred = bimg;  // [16 channels][4 waves]
+  constexpr int nch = CONV ? CS : CB;
+  for (int c = 0; c < nch; ++c) {
+    float v = 0.f;
+    if constexpr (CONV) {
+#pragma unroll
+      for (int q = 0; q < NQS; ++q) {
+        const int i = t + 256 * q;
+        if (i < CS * (TP / 4) && i / (TP / 4) == c) v += bs_small[q];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQB; ++q) {
+        const int i = t + 256 * q;
+        if (i < CB * TP && i / TP == c) v += bs_big[q];
+      }
+    }
+    v = wave_sum(v);
+    if (lane == 0) bred[c * 4 + wave] = v;
+  }
+  __syncthreads();
+  if (t < 16) out[NW + t] = t < nch ? (bred[t * 4] + bred[t * 4 + 1]) + (bred[t * 4 + 2] + bred[t * 4 + 3]) : 0.f;
+}
+
+bool conv1d_bwd_lds_supported(int Cs, int Cb, int Ls, int pad) {
+  return !getenv("LSHM_BWD_LDS_OFF") && Cs == 12 && Cb == 8 && Ls % 128 == 0 && (pad == 0 || pad == 1);
+}
+
+int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs, float* ws,
+                   float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks, hipStream_t st, int* grid_out,
+                   const FusedDgrad& fd, int big_bf16) {
+  const bool two = small2 != nullptr;
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (!conv1d_bwd_lds_supported(Cs, Cb, Ls, pad) || Lb != 4 * Ls || s_bs % 4 || big_bs % 4 || fd.dx_bs % 4 || !fd.w || !fd.dx ||
+      !al16(small) || !al16(big) || !al16(fd.dx) ||
+      (two && (!big2 || !fd.w2 || !fd.dx2 || !al16(small2) || !al16(big2) || !al16(fd.dx2)))) {
+    set_last_error("conv1d_bwd_lds: unsupported layer shape, stride or alignment");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  BwdLds1dArgs a;
+  a.small[0] = small; a.small[1] = two ? small2 : small;
+  a.big[0] = big; a.big[1] = two ? big2 : big;
+  a.w[0] = fd.w; a.w[1] = two ? fd.w2 : fd.w;
+  a.partial[0] = ws; a.partial[1] = two ? ws2 : ws;
+  a.dout[0] = fd.dx; a.dout[1] = two ? fd.dx2 : fd.dx;
+  a.s_bs = s_bs; a.big_bs = big_bs; a.d_bs = fd.dx_bs;
+  a.Ls = Ls; a.Lb = Lb; a.ntiles = (Ls / 128) * B;
+  int grid = a.ntiles < 512 ? a.ntiles : 512;
+  if (grid > max_blocks) grid = max_blocks;
+  if (grid < 1) grid = 1;
+  *grid_out = grid;
+  const dim3 g(grid, two ? 2 : 1);
+  const bool dact = fd.dact != 0;
+#define LSHM_BLDS(CONV_, DACT_, TB_) hipLaunchKernelGGL((conv1d_bwd_lds_kernel<12, 8, 128, CONV_, DACT_, TB_>), g, dim3(256), 0, st, a)
+  if (big_bf16) {
+    if (pad == 0) { if (dact) LSHM_BLDS(false, true, bf16); else LSHM_BLDS(false, false, bf16); }
+    else { if (dact) LSHM_BLDS(true, true, bf16); else LSHM_BLDS(true, false, bf16); }
+  } else {
+    if (pad == 0) { if (dact) LSHM_BLDS(false, true, float); else LSHM_BLDS(false, false, float); }
+    else { if (dact) LSHM_BLDS(true, true, float); else LSHM_BLDS(true, false, float); }
+  }
+#undef LSHM_BLDS
+  return check_launch("conv1d_bwd_lds");
 }
 
 }  // namespace lshm

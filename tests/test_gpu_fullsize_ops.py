@@ -146,9 +146,12 @@ def test_dense_layers_at_full_batch(K, N, act):
     assert rel_err(db, dz.double().sum(0)) < 5e-5
 
 
-@pytest.mark.parametrize("kind,i,elu_grad", [(3, 5, 1), (3, 4, 1), (2, 1, 1), (2, 0, 0), (2, 0, 1), (3, 5, 0), (1, 5, 1), (1, 5, 0)],
-                         ids=["tconv5", "tconv4", "conv1", "conv0", "conv0-elu", "tconv5-noelu", "2d-tconv5", "2d-tconv5-noelu"])
-def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, monkeypatch):
+@pytest.mark.parametrize("kind,i,elu_grad,form", [(3, 5, 1, ""), (3, 4, 1, "lds"), (2, 1, 1, "lds"), (3, 4, 0, "lds"), (2, 1, 0, "lds"),
+                                                  (3, 4, 1, "reg"), (2, 1, 1, "reg"), (2, 0, 0, ""), (2, 0, 1, ""), (3, 5, 0, ""),
+                                                  (1, 5, 1, ""), (1, 5, 0, "")],
+                         ids=["tconv5", "tconv4", "conv1", "tconv4-noelu", "conv1-noelu", "tconv4-registers", "conv1-registers",
+                              "conv0", "conv0-elu", "tconv5-noelu", "2d-tconv5", "2d-tconv5-noelu"])
+def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, form, monkeypatch):
     """lshm_conv_bwd_fused (weight + bias + data gradient from one read of dz and the saved input; backward of
     src/lofar_models.py:115-117,140-142) against the pair of kernels it replaces (lshm_conv_wgrad + lshm_conv_dgrad)
     and against fp64, at B = 256: the weight / bias gradients come from the same MFMA sequence as the stand-alone
@@ -157,8 +160,10 @@ def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, monkeypatch):
     from lshm_amd import _lib as L
     lib = L.load()
     ishape, wshape, cin, cout = _shapes(kind, i)
-    if kind >= 2 and 12 in (cin, cout):
-        monkeypatch.setenv("LSHM_FUSED2_12_8", "1")  # the 12 / 8 channel form is opt-in (slower than the pair it replaces)
+    if form == "reg":
+        monkeypatch.setenv("LSHM_FUSED2_12_8", "1")  # the register form of the 12 / 8 channel layers (opt-in: it spills)
+    else:
+        monkeypatch.delenv("LSHM_FUSED2_12_8", raising=False)  # default: the LDS-staged form (conv1d_bwd_lds_kernel)
     g = torch.Generator().manual_seed(31 * kind + i)
     x = TF.elu(torch.randn(ishape, generator=g))  # the saved input of a layer behind an ELU
     fan = (cout if kind in (1, 3) else cin) * (16 if kind < 2 else 4)
