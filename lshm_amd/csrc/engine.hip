@@ -284,9 +284,10 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   };
   auto both = [&](auto f) { Lin q{}; for (int g = 0; g < 2; ++g) f(q, g, A(g)); return q; };
   // (elu(fcuv1(uvh)) and elu(fcuv3(uvh)) are already in cat1 / cat3: the uv_features step)
-  const bool dense_chain = a0.ndim == 1 && dense1d_supported(L, hd, c.rica);
+  static const bool dense_2d = getenv("LSHM_DENSE2D_OFF") == nullptr;  // the 2-D autoencoder's dense middle has the same shape
+  const bool dense_chain = (a0.ndim == 1 || dense_2d) && dense1d_supported(L, hd, c.rica);
   if (dense_chain) {
-    // fc1 -> fc2in -> fc2out -> fc3 of the 1-D autoencoders as one launch (dense1d.hip); the latents are complete inside it,
+    // fc1 -> fc2in -> fc2out -> fc3 of an autoencoder as one launch (dense1d.hip); the latents are complete inside it,
     // so the latent-space terms start right after it
     steps.push_back([=](float* ws, hipStream_t st) -> int {
       Dense1dFwdIO io[2];
@@ -529,7 +530,8 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // 1-D autoencoders: the four data gradients of the dense layers are one launch (dense1d.hip); the weight gradients
   // below still read the buffers it fills
   static const bool dense_bwd_on = getenv("LSHM_DENSE1D_BWD_OFF") == nullptr;
-  const bool dense_chain = dense_bwd_on && a0.ndim == 1 && dense1d_supported(L, hd, c.rica);
+  static const bool dense_2d = getenv("LSHM_DENSE2D_OFF") == nullptr;
+  const bool dense_chain = dense_bwd_on && (a0.ndim == 1 || dense_2d) && dense1d_supported(L, hd, c.rica);
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     if (dense_chain) return (int)LSHM_OK;
     return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr);
