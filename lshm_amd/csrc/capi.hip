@@ -11,6 +11,9 @@
 #include <utility>
 
 namespace lshm {
+thread_local hipEvent_t launch_stop_event = nullptr;
+thread_local unsigned launch_stop_count = 0;
+
 static thread_local char g_err[256] = "";
 void set_last_error(const char* msg) {
   strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);

@@ -1,7 +1,11 @@
 // Shared device/host helpers for the LSHM gfx950 kernels.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+
+#include <tuple>
+#include <utility>
 
 #define LSHM_OK 0
 #define LSHM_ERR_ARG (-1)        // bad argument (null pointer, unsupported size)
@@ -18,6 +22,38 @@ int check_launch(const char* what);  // hipGetLastError -> code + message
 // kernel variant that cannot launch is thus a return code at the call site, never a failed or aborted dispatch.
 int kernel_budget_ok(const void* kernel, int threads, size_t dyn_lds, const char* what);
 int device_lds_bytes();  // LDS a workgroup may use on the current device (0: unknown)
+
+// A kernel's own completion signal as an event.  hipEventRecord puts a marker packet behind the last kernel of a stream,
+// and the NEXT kernel of that stream waits for the marker to retire: ~6 us of idle queue per record on the stream that
+// records (profiles/r03/step_timeline.txt: every launch behind a "dz ready" record has gap = 6).  While
+// `launch_stop_event` is set (StopEventScope), every launch of this thread goes through hipExtLaunchKernel with that
+// event as its stop event instead: the event completes with the kernel, no marker.  Kernels of one stream complete in
+// order, so after a scope the event stands for "everything the scope launched on that stream".
+extern thread_local hipEvent_t launch_stop_event;
+extern thread_local unsigned launch_stop_count;  // launches that carried a stop event (a scope that launched nothing must not be waited for)
+struct StopEventScope {
+  explicit StopEventScope(hipEvent_t ev) { launch_stop_event = ev; }
+  ~StopEventScope() { launch_stop_event = nullptr; }
+  StopEventScope(const StopEventScope&) = delete;
+  StopEventScope& operator=(const StopEventScope&) = delete;
+};
+template <typename... KArgs, typename Tuple, size_t... I>
+inline void launch_with_stop_event(void (*kernel)(KArgs...), dim3 g, dim3 b, unsigned lds, hipStream_t st, hipEvent_t ev,
+                                   Tuple& t, std::index_sequence<I...>) {
+  void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {static_cast<void*>(&std::get<I>(t))...};
+  (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, ptrs, lds, st, nullptr, ev, 0);
+}
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 g, dim3 b, unsigned lds, hipStream_t st, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+  if (hipEvent_t ev = launch_stop_event) {
+    std::tuple<KArgs...> t{static_cast<KArgs>(args)...};  // the kernel's own parameter types, as <<<>>> would convert
+    launch_with_stop_event(kernel, g, b, lds, st, ev, t, std::index_sequence_for<KArgs...>{});
+    ++launch_stop_count;
+  } else {
+    kernel<<<g, b, lds, st>>>(static_cast<KArgs>(args)...);
+  }
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -99,3 +135,7 @@ __device__ __forceinline__ T block_sum(T v, T* smem /* >= 16 */) {
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 }  // namespace lshm
+
+// every launch of the library goes through lshm::launch (see launch_stop_event above)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) ::lshm::launch(kernel, dim3(grid), dim3(block), lds, stream, ##__VA_ARGS__)

@@ -433,13 +433,35 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // once, after all backward passes).
   const bool side = wgrad_stream != nullptr && wgrad_stream != st;
   hipStream_t wst = side ? wgrad_stream : st;
+  // "dz ready" without a marker packet on `st` (common.h: launch_stop_event): the launches of one layer on `st` carry an
+  // event of their own as stop event; as long as nothing else has been put on `st` since, that event IS "everything on
+  // `st` so far", and the side stream waits for it directly.  Otherwise (first release of a pass, after callbacks,
+  // under capture, LSHM_STOP_EVENTS_OFF=1) an event is recorded as before.
+  static const bool stop_events = getenv("LSHM_STOP_EVENTS_OFF") == nullptr;
+  const bool use_stop = side && stop_events && !e->in_capture;
+  hipEvent_t last_ev = nullptr;
+  auto on_st = [&](auto&& f) -> int {
+    if (!use_stop) { last_ev = nullptr; return f(); }
+    hipEvent_t ev = e->take_event();
+    const unsigned before = launch_stop_count;
+    int r;
+    { StopEventScope sc(ev); r = f(); }
+    if (launch_stop_count != before) last_ev = ev;  // (a call that launched nothing leaves the state as it was)
+    return r;
+  };
   auto dz_ready = [&]() -> int {
     if (!side) return LSHM_OK;
+    if (last_ev) {
+      if (hipStreamWaitEvent(wst, last_ev, 0) == hipSuccess) return LSHM_OK;
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
     hipEvent_t ev = e->take_event();
     if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(wst, ev, 0) != hipSuccess) {
       set_last_error("engine: stream fork failed");
       return LSHM_ERR_ARG;
     }
+    if (use_stop) last_ev = ev;
     return LSHM_OK;
   };
   // The small layers' weight gradients are released in groups: every release costs a barrier packet
@@ -486,7 +508,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
           return conv_layer_wgrad(a0.dec[li], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
         });
       }
-      if ((rc = conv1d_chain(false, cs, dzin[0], dzin[1], a0.dec[3].out_bs, 0, B, st))) return rc;
+      if ((rc = on_st([&] { return conv1d_chain(false, cs, dzin[0], dzin[1], a0.dec[3].out_bs, 0, B, st); }))) return rc;
       if ((rc = release(true))) return rc;
       for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_gdec[1];
       i = 1;
@@ -505,8 +527,8 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     if (conv_layer_bwd_fusable(a0.dec[i], wg[0], dg[0]) && (G < 2 || conv_layer_bwd_fusable(a0.dec[i], wg[1], dg[1]))) {
       // outermost 1-D decoder layer: weight, bias and data gradient from one pass over dz and the saved input, on
       // the data-gradient stream (the closing sums still run on the other one, behind the next "dz ready" event)
-      if ((rc = conv_layer_wgrad(a0.dec[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs, &dg[0],
-                                 G > 1 ? &dg[1] : nullptr))) return rc;
+      if ((rc = on_st([&] { return conv_layer_wgrad(a0.dec[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs, &dg[0],
+                                                    G > 1 ? &dg[1] : nullptr); }))) return rc;
       for (int g = 0; g < G; ++g) dz[g] = dx[g];
       continue;
     }
@@ -514,7 +536,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       return conv_layer_wgrad(a0.dec[i], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
     });
     if ((rc = release(i >= 4))) return rc;
-    if ((rc = conv_layer_dgrad(a0.dec[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
+    if ((rc = on_st([&] { return conv_layer_dgrad(a0.dec[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr); }))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
   LinWgradIO lw[2];
@@ -534,17 +556,17 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   const bool dense_chain = dense_bwd_on && (a0.ndim == 1 || dense_2d) && dense1d_supported(L, hd, c.rica);
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     if (dense_chain) return (int)LSHM_OK;
-    return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr);
+    return on_st([&] { return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr); });
   };
   // the latent-space gradient enters at fc3: whoever produced it beside the decoders is joined here, not earlier
-  if (before_dense && (rc = (*before_dense)())) return rc;
+  if (before_dense) { last_ev = nullptr; if ((rc = (*before_dense)())) return rc; }
   if (dense_chain) {
     Dense1dBwdIO io[2];
     for (int g = 0; g < G; ++g)
       io[g] = Dense1dBwdIO{ws + LA(g).o_dd0, ws + A(g).cat3, ws + e->o_Mu + A(g).mu_col, ws + e->o_gMu + A(g).mu_col, ws + A(g).z1,
                            ws + A(g).cat1, prm + A(g).fc1w, prm + A(g).fc2inw, prm + A(g).fc2outw, prm + A(g).fc3w,
                            ws + LA(g).o_dcat3, ws + LA(g).o_dzmu, ws + LA(g).o_dz1, ws + LA(g).o_dcat1};
-    if ((rc = dense1d_bwd(io[0], G > 1 ? &io[1] : nullptr, D, D, B, st))) return rc;
+    if ((rc = on_st([&] { return dense1d_bwd(io[0], G > 1 ? &io[1] : nullptr, D, D, B, st); }))) return rc;
   }
   // ---- fc3 (no activation on its output): dd0 is its pre-activation gradient
   for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{ws + A(g).cat3, ws + LA(g).o_dd0, grd + A(g).fc3w, grd + A(g).fc3b};
@@ -612,7 +634,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
           return conv_layer_wgrad(a0.enc[li], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
         });
       }
-      if ((rc = conv1d_chain(true, cs, dzin[0], dzin[1], a0.enc[4].out_bs, 1, B, st))) return rc;
+      if ((rc = on_st([&] { return conv1d_chain(true, cs, dzin[0], dzin[1], a0.enc[4].out_bs, 1, B, st); }))) return rc;
       if ((rc = release(true))) return rc;
       fused_tail = false;
       for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_genc[2];
@@ -631,8 +653,8 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     if (dx[0] && conv_layer_bwd_fusable(a0.enc[i], wg[0], dg[0]) && (G < 2 || conv_layer_bwd_fusable(a0.enc[i], wg[1], dg[1]))) {
       // outer 1-D encoder layers: weight, bias and data gradient from one pass over dz and the saved input, on the
       // data-gradient stream; their closing sums run on the other one, behind the "dz ready" event below
-      if ((rc = conv_layer_wgrad(a0.enc[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs, &dg[0],
-                                 G > 1 ? &dg[1] : nullptr))) return rc;
+      if ((rc = on_st([&] { return conv_layer_wgrad(a0.enc[i], wg[0], nullptr, 0, 0, st, G > 1 ? &wg[1] : nullptr, &jobs, &dg[0],
+                                                    G > 1 ? &dg[1] : nullptr); }))) return rc;
       fused_tail = true;
       for (int g = 0; g < G; ++g) dz[g] = dx[g];
       continue;
@@ -643,7 +665,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     if ((rc = release(i <= 2))) return rc;
     fused_tail = false;
     if (i == 0 && !dinput[0]) break;
-    if ((rc = conv_layer_dgrad(a0.enc[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr))) return rc;
+    if ((rc = on_st([&] { return conv_layer_dgrad(a0.enc[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr); }))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
   }
   if (fused_tail && (rc = dz_ready())) return rc;
@@ -1212,7 +1234,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
       ok = ok && hipStreamCreateWithFlags(&e->fstream, hipStreamNonBlocking) == hipSuccess;
       {
         const char* v = getenv("LSHM_EVENT_POOL");
-        const int n = v ? atoi(v) : 128;
+        const int n = v ? atoi(v) : 256;
         e->events.resize(n >= 32 ? n : 32);
       }
       for (size_t i = 0; i < e->events.size() && ok; ++i)
