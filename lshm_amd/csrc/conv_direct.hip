@@ -360,8 +360,10 @@ int tconv2d_direct(const float* small, long s_bs, const float* w, const float* b
     else
       hipLaunchKernelGGL((tconv2d_q4_kernel<4>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
   } else if (Cs == 12 && Cb == 8) {
+    // 512 workgroups (two tiles each, two resident per CU): 31.6 / 32.6 us (tconv4 forward / conv1's data gradient) against
+    // 33.6 / 35.3 with 768 and 37.4 / 43.3 with 256; half-height tiles are no better at any grid size
+    static const int cap = [] { const char* v = getenv("LSHM_GRID_TCONV2D_12_8"); return v && atoi(v) > 0 ? atoi(v) : 512; }();
     const int ntiles = (Ws / 32) * (Hs / 8) * B;
-    static const int cap = [] { const char* v = getenv("LSHM_GRID_TCONV2D_12_8"); return v && atoi(v) > 0 ? atoi(v) : 768; }();
     const dim3 grid(ntiles < cap ? ntiles : cap);
     if (big_bf16)
       hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32, bf16>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
@@ -667,14 +669,21 @@ namespace lshm {
 // M = 16 consecutive ox per MFMA tile, N = Cout (<= 16), K steps = (ci, ky) with the 4 kx taps.
 // The input patch of a TH x TW output tile sits in LDS once; A fragments are read at
 // patch[ci][2oy+ky][2ox+kx] (bank = 2*lane + kx: conflict-free); weights live in registers.
+// A PERSISTENT, software-pipelined workgroup over small tiles: with one 8 x 32 tile per workgroup and every workgroup
+// of the launch resident at once (the first form of this kernel), all of them load, then all multiply, then all
+// store -- an ablation (profiles/r03/README.md) shows the phases of conv1's forward simply adding up (6.5 fixed + 8
+// loads + 8 matrix + 4.5 stores = 27 us for 46 MB).  Here a workgroup walks four 4 x 32 tiles (512 workgroups at
+// B = 256); the float4 loads of tile i+1 are issued into registers before the matrix instructions of tile i and
+// written to LDS after them, and the stores of tile i leave while tile i+1 computes: 26.8 -> 22.3 us (conv1 forward),
+// 25.7 -> 22.3 us (tconv4's data gradient); 256 / 1024 / 2048 workgroups: 26.3 / 22.8 / 29.0 us.
 // ----------------------------------------------------------------------------------------------
-template <int CIN, int COUT, int TH, int TW, class TI = float>  // TI: element type of x (bf16 storage, common.h)
+template <int CIN, int COUT, int TH, int TW, class TI = float>
 __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __restrict__ x_, long x_bs,
-                                                            const float* __restrict__ w,
-                                                            const float* __restrict__ bias,
-                                                            float* __restrict__ y, long y_bs,
-                                                            const float* __restrict__ dact, int Ho, int Wo,
-                                                            int act, int ntiles) {
+                                                                 const float* __restrict__ w,
+                                                                 const float* __restrict__ bias,
+                                                                 float* __restrict__ y, long y_bs,
+                                                                 const float* __restrict__ dact, int Ho, int Wo,
+                                                                 int act, int ntiles) {
   const TI* __restrict__ x = reinterpret_cast<const TI*>(x_);
   constexpr int KS = CIN * 4;  // k-steps: (ci, ky), 4 kx taps each
   constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
@@ -683,38 +692,61 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
   __shared__ float patch[CIN * PH * PW];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lm = lane & 15, lk = lane >> 4;
-  // B fragment of step s: lane (kk = kx = lk, n = co = lm) -> w[co][ci][ky][kx]
   float bf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) bf[s] = lm < COUT ? w[((long)lm * CIN * 4 + s) * 4 + lk] : 0.f;
   const float bv = (bias && lm < COUT) ? bias[lm] : 0.f;
-
   const int tiles_x = Wo / TW, tiles_y = Ho / TH;
   const int H = 2 * Ho, W = 2 * Wo;
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  constexpr int NV4 = (CIN * PH * (2 * TW / 4) + 255) / 256, NH = (CIN * PH * 2 + 255) / 256;
+  f32x4 rv[NV4];
+  float rh[NH];
+  auto load_tile = [&](int tile) {
     const int b = tile / (tiles_x * tiles_y);
     const int tr_ = tile - b * (tiles_x * tiles_y);
     const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
     const TI* xb = x + (long)b * x_bs;
-    __syncthreads();
-    for (int i = t; i < CIN * PH * (2 * TW / 4); i += 256) {
+#pragma unroll
+    for (int q = 0; q < NV4; ++q) {
+      const int i = q * 256 + t;
       const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
       const int prow = rr % PH, ci = rr / PH;
       const int iy = 2 * m0 - 1 + prow;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)iy < (unsigned)H) v = Elem<TI>::ld4(xb + ((long)ci * H + iy) * W + 2 * n0 + 4 * c4);
-      float* d = &patch[(ci * PH + prow) * PW + 1 + 4 * c4];
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      rv[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (i < CIN * PH * (2 * TW / 4) && (unsigned)iy < (unsigned)H) rv[q] = Elem<TI>::ld4(xb + ((long)ci * H + iy) * W + 2 * n0 + 4 * c4);
     }
-    for (int i = t; i < CIN * PH * 2; i += 256) {
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+      const int i = q * 256 + t;
       const int side = i & 1, rr = i >> 1;
       const int prow = rr % PH, ci = rr / PH;
       const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
-      float v = 0.f;
-      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = Elem<TI>::ld(xb + ((long)ci * H + iy) * W + ix);
-      patch[(ci * PH + prow) * PW + (side ? PW - 1 : 0)] = v;
+      rh[q] = 0.f;
+      if (i < CIN * PH * 2 && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) rh[q] = Elem<TI>::ld(xb + ((long)ci * H + iy) * W + ix);
+    }
+  };
+  if ((int)blockIdx.x < ntiles) load_tile(blockIdx.x);
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int b = tile / (tiles_x * tiles_y);
+    const int tr_ = tile - b * (tiles_x * tiles_y);
+    const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
+    __syncthreads();  // the previous tile's A fragments have been read
+#pragma unroll
+    for (int q = 0; q < NV4; ++q) {
+      const int i = q * 256 + t;
+      if (i < CIN * PH * (2 * TW / 4)) {
+        const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
+        float* d = &patch[rr * PW + 1 + 4 * c4];
+        d[0] = rv[q][0]; d[1] = rv[q][1]; d[2] = rv[q][2]; d[3] = rv[q][3];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NH; ++q) {
+      const int i = q * 256 + t;
+      if (i < CIN * PH * 2) patch[(i >> 1) * PW + ((i & 1) ? PW - 1 : 0)] = rh[q];
     }
     __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
     f32x4 acc[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -729,7 +761,6 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s], acc[i], 0, 0, 0);
       }
     }
-    // lane holds 4 consecutive ox of channel lm
     if (lm < COUT) {
 #pragma unroll
       for (int i = 0; i < MW; ++i) {
@@ -1182,15 +1213,13 @@ int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, 
     else LSHM_Q4(float, float);
 #undef LSHM_Q4
   } else if (Cin == 8 && Cout == 12) {
-    const int ntiles = (Wo / 32) * (Ho / 8) * B;
-    // 38 KB of LDS and <= 128 VGPRs: four workgroups per CU, so the 1024 tiles of B = 256 are resident at once
-    // (768 workgroups left a second round with a third of the machine busy)
-    static const int cap = [] { const char* v = getenv("LSHM_GRID_CONV2D_8_12"); return v && atoi(v) > 0 ? atoi(v) : 1024; }();
+    const int ntiles = (Wo / 32) * (Ho / 4) * B;
+    static const int cap = [] { const char* v = getenv("LSHM_GRID_CONV2D_8_12"); return v && atoi(v) > 0 ? atoi(v) : 512; }();
     const dim3 grid(ntiles < cap ? ntiles : cap);
     if (x_bf16)
-      hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32, bf16>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+      hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 4, 32, bf16>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
     else
-      hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 8, 32>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
+      hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 4, 32>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
   } else {
     set_last_error("conv2d_direct: unsupported shape");
     return LSHM_ERR_UNSUPPORTED;
