@@ -154,6 +154,14 @@ int lshm_dense1d_fwd(const float* cat1, const float* const* wb, float* z1, float
 int lshm_dense1d_bwd(const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
                      const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
                      lshm_stream_t stream);
+/* The same for the 2-D autoencoder of kharmonic_lofar.py (AutoEncoderCNN2(latent_dim=L, rica=True), L = 224 upstream
+ * (src/kharmonic_lofar.py:37, src/lofar_models.py:36-47,66-77); 224 and 256 are built, LSHM_ERR_UNSUPPORTED otherwise): every
+ * 16 above reads L (z1, mu (B,L); cat3 (B,L+16) with its columns L..L+15 = elu(fcuv3(uvh)) in place). */
+int lshm_dense2d_fwd(int L, const float* cat1, const float* const* wb, float* z1, float* mu, long ldmu, float* cat3, float* d0, int B,
+                     lshm_stream_t stream);
+int lshm_dense2d_bwd(int L, const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
+                     const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
+                     lshm_stream_t stream);
 /* dz = gy * ELU'(y) from the saved output y                      (autograd of F.elu) */
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t stream);
 

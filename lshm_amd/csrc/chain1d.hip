@@ -92,14 +92,21 @@ __device__ __forceinline__ void up_stage(const float* __restrict__ xs, int xoff,
     f32x4 acc[4];
 #pragma unroll
     for (int e = 0; e < 4; ++e) acc[e] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 bq[CIN / 4];  // w[ci = 4s + lk][co][0..3]: all of the tile's B fragments in flight at once
+    // w[ci = 4s + lk][co][0..3]: the tile's B fragments in flight at once, at most 8 k-steps (32 registers) per batch so that
+    // the kernel fits 64 VGPRs = two 16-wavefront workgroups per CU
+    constexpr int KS = CIN / 4, KC = KS % 8 == 0 ? 8 : (KS % 6 == 0 ? 6 : KS);
+    static_assert(KS % KC == 0, "whole batches of k-steps");
 #pragma unroll
-    for (int s = 0; s < CIN / 4; ++s) bq[s] = cok ? *reinterpret_cast<const f32x4*>(wp + (long)16 * s * COUT) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < KS; s0 += KC) {
+      f32x4 bq[KC];
 #pragma unroll
-    for (int s = 0; s < CIN / 4; ++s) {
-      const float a = ap[4 * s * PIN];
+      for (int s = 0; s < KC; ++s) bq[s] = cok ? *reinterpret_cast<const f32x4*>(wp + (long)16 * (s0 + s) * COUT) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[s][e], acc[e], 0, 0, 0);
+      for (int s = 0; s < KC; ++s) {
+        const float a = ap[4 * (s0 + s) * PIN];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bq[s][e], acc[e], 0, 0, 0);
+      }
     }
     if (cok) {
       const float bv = bias ? bias[co] : 0.f;

@@ -284,8 +284,7 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   };
   auto both = [&](auto f) { Lin q{}; for (int g = 0; g < 2; ++g) f(q, g, A(g)); return q; };
   // (elu(fcuv1(uvh)) and elu(fcuv3(uvh)) are already in cat1 / cat3: the uv_features step)
-  static const bool dense_2d = getenv("LSHM_DENSE2D_OFF") == nullptr;  // the 2-D autoencoder's dense middle has the same shape
-  const bool dense_chain = (a0.ndim == 1 || dense_2d) && dense1d_supported(L, hd, c.rica);
+  const bool dense_chain = dense1d_supported(L, hd, c.rica);  // latent width 16 (netT / netF) or 256 (the 2-D autoencoder)
   if (dense_chain) {
     // fc1 -> fc2in -> fc2out -> fc3 of an autoencoder as one launch (dense1d.hip); the latents are complete inside it,
     // so the latent-space terms start right after it
@@ -297,7 +296,7 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
                              prm + a.fc2outb, prm + a.fc3w, prm + a.fc3b, ws + a.z1, ws + e->o_Mu + a.mu_col, ws + a.cat3,
                              ws + a.d0};
       }
-      return dense1d_fwd(io[0], G > 1 ? &io[1] : nullptr, D, B, st);
+      return dense1d_fwd(io[0], G > 1 ? &io[1] : nullptr, D, B, st, L);
     });
     if (latent_mark) *latent_mark = steps.size();
   } else if (c.rica) {
@@ -553,8 +552,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // 1-D autoencoders: the four data gradients of the dense layers are one launch (dense1d.hip); the weight gradients
   // below still read the buffers it fills
   static const bool dense_bwd_on = getenv("LSHM_DENSE1D_BWD_OFF") == nullptr;
-  static const bool dense_2d = getenv("LSHM_DENSE2D_OFF") == nullptr;
-  const bool dense_chain = dense_bwd_on && (a0.ndim == 1 || dense_2d) && dense1d_supported(L, hd, c.rica);
+  const bool dense_chain = dense_bwd_on && dense1d_supported(L, hd, c.rica);
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     if (dense_chain) return (int)LSHM_OK;
     return on_st([&] { return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr); });
@@ -567,7 +565,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       io[g] = Dense1dBwdIO{ws + LA(g).o_dd0, ws + A(g).cat3, ws + e->o_Mu + A(g).mu_col, ws + e->o_gMu + A(g).mu_col, ws + A(g).z1,
                            ws + A(g).cat1, prm + A(g).fc1w, prm + A(g).fc2inw, prm + A(g).fc2outw, prm + A(g).fc3w,
                            ws + LA(g).o_dcat3, ws + LA(g).o_dzmu, ws + LA(g).o_dz1, ws + LA(g).o_dcat1};
-    if ((rc = on_st([&] { return dense1d_bwd(io[0], G > 1 ? &io[1] : nullptr, D, D, B, st); }))) return rc;
+    if ((rc = on_st([&] { return dense1d_bwd(io[0], G > 1 ? &io[1] : nullptr, D, D, B, st, L); }))) return rc;
   }
   // ---- fc3 (no activation on its output): dd0 is its pre-activation gradient
   for (int g = 0; g < G; ++g) lw[g] = LinWgradIO{ws + A(g).cat3, ws + LA(g).o_dd0, grd + A(g).fc3w, grd + A(g).fc3b};

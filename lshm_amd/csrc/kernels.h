@@ -236,9 +236,10 @@ struct Dense1dBwdIO {
   const float *fc1w, *fc2inw, *fc2outw, *fc3w;
   float *dcat3, *dzmu, *dz1, *dcat1;                   // (B,32), (B,16), (B,16), (B,784)
 };
-bool dense1d_supported(int L, int hd, int rica);
-int dense1d_fwd(const Dense1dFwdIO& p, const Dense1dFwdIO* p1, long ldmu, int B, hipStream_t st);
-int dense1d_bwd(const Dense1dBwdIO& p, const Dense1dBwdIO* p1, long ldmu, long ldgmu, int B, hipStream_t st);
+bool dense1d_supported(int L, int hd, int rica);  // the engine's choice
+bool dense1d_built(int L);                          // latent widths the kernels exist for
+int dense1d_fwd(const Dense1dFwdIO& p, const Dense1dFwdIO* p1, long ldmu, int B, hipStream_t st, int L = 16);  // L: 16 | 256
+int dense1d_bwd(const Dense1dBwdIO& p, const Dense1dBwdIO* p1, long ldmu, long ldgmu, int B, hipStream_t st, int L = 16);
 
 // ---- layer-level helpers (layers.hip): conv / tconv / linear, fwd + bwd -----
 // kind: 0 conv2d k4s2p1, 1 tconv2d k4s2p1, 2 conv1d k4s4p1, 3 tconv1d k4s4p0

@@ -279,30 +279,36 @@ def test_three_layer_chain_matches_the_three_launches(mode):
 
 
 @pytest.mark.parametrize("nb", [256, 37])
-def test_dense_middle_of_the_1d_autoencoder_as_one_launch(nb):
+@pytest.mark.parametrize("Ld", [16, 224, 256], ids=["latent16", "latent224", "latent256"])
+def test_dense_middle_of_the_1d_autoencoder_as_one_launch(nb, Ld):
     """lshm_dense1d_fwd / lshm_dense1d_bwd (fc1 -> fc2in -> fc2out -> fc3 of AutoEncoder1DCNN(latent_dim=16, rica=True) and the
-    data gradients back through them, src/lofar_models.py:127-135,165-176) against fp64, every output, at the full
-    batch and at a ragged one (37 rows: the last workgroup has 5)."""
+    data gradients back through them, src/lofar_models.py:127-135,165-176) and lshm_dense2d_fwd / _bwd (the same layers of
+    AutoEncoderCNN2(latent_dim=224 | 256, rica=True), :36-47,66-77) against fp64, every output, at the full batch and at a
+    ragged one (37 rows: the last workgroup has 5)."""
     import ctypes as C
     from lshm_amd import _lib as L
     lib = L.load()
     g = torch.Generator().manual_seed(5 + nb)
     R = lambda *s: torch.randn(*s, generator=g)
     cat1 = TF.elu(R(nb, 784))
-    W = {"fc1": R(16, 784) * 784 ** -0.5, "fc2in": R(16, 16) * 0.25, "fc2out": R(16, 16) * 0.25, "fc3": R(768, 32) * 32 ** -0.5}
+    W = {"fc1": R(Ld, 784) * 784 ** -0.5, "fc2in": R(Ld, Ld) * Ld ** -0.5, "fc2out": R(Ld, Ld) * Ld ** -0.5,
+         "fc3": R(768, Ld + 16) * (Ld + 16) ** -0.5}
     Bv = {k: R(v.shape[0]) * 0.1 for k, v in W.items()}
     uvh = TF.elu(R(nb, 16))
-    D = 256
+    D = 288
+    import functools
+    fwd, bwd = (lib.lshm_dense1d_fwd, lib.lshm_dense1d_bwd) if Ld == 16 else (functools.partial(lib.lshm_dense2d_fwd, Ld),
+                                                                             functools.partial(lib.lshm_dense2d_bwd, Ld))
     Mu = torch.zeros(nb, D)
-    cat3 = torch.zeros(nb, 32)
-    cat3[:, 16:] = uvh
+    cat3 = torch.zeros(nb, Ld + 16)
+    cat3[:, Ld:] = uvh
     dev = lambda t: t.to(DEV).contiguous()
     cat1d, Mud, cat3d = dev(cat1), dev(Mu), dev(cat3)
-    z1d, d0d = torch.empty(nb, 16, device=DEV), torch.empty(nb, 768, device=DEV)
+    z1d, d0d = torch.empty(nb, Ld, device=DEV), torch.empty(nb, 768, device=DEV)
     wb = [dev(t) for k in ("fc1", "fc2in", "fc2out", "fc3") for t in (W[k], Bv[k])]
     arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
-    mu_col = 224
-    L.check(lib.lshm_dense1d_fwd(L.ptr(cat1d), arr(wb), L.ptr(z1d), Mud.data_ptr() + 4 * mu_col, D, L.ptr(cat3d), L.ptr(d0d), nb,
+    mu_col = 272 if Ld == 16 else 0
+    L.check(fwd(L.ptr(cat1d), arr(wb), L.ptr(z1d), Mud.data_ptr() + 4 * mu_col, D, L.ptr(cat3d), L.ptr(d0d), nb,
                                  L.stream()), "dense1d_fwd")
     torch.cuda.synchronize()
     d = lambda t: t.double()
@@ -311,20 +317,20 @@ def test_dense_middle_of_the_1d_autoencoder_as_one_launch(nb):
     c = TF.elu(mu @ d(W["fc2out"]).t() + d(Bv["fc2out"]))
     c3 = torch.cat((c, d(uvh)), 1)
     d0 = c3 @ d(W["fc3"]).t() + d(Bv["fc3"])
-    assert rel_err(z1d, z1) < 1e-5 and rel_err(Mud[:, mu_col:mu_col + 16], mu) < 1e-5
+    assert rel_err(z1d, z1) < 1e-5 and rel_err(Mud[:, mu_col:mu_col + Ld], mu) < 1e-5
     assert rel_err(cat3d, c3) < 1e-5 and rel_err(d0d, d0) < 1e-5
-    assert torch.equal(Mud[:, :mu_col].cpu(), Mu[:, :mu_col])  # nothing outside the latent columns was touched
+    assert torch.equal(Mud[:, :mu_col].cpu(), Mu[:, :mu_col]) and torch.equal(Mud[:, mu_col + Ld:].cpu(), Mu[:, mu_col + Ld:])  # nothing outside the latent columns was touched
     # backward
     dd0, gmu = R(nb, 768), R(nb, D) * 0.1
-    outs = [torch.full(s, float("nan"), device=DEV) for s in ((nb, 32), (nb, 16), (nb, 16), (nb, 784))]
+    outs = [torch.full(s, float("nan"), device=DEV) for s in ((nb, Ld + 16), (nb, Ld), (nb, Ld), (nb, 784))]
     ws_ = [dev(W[k]) for k in ("fc1", "fc2in", "fc2out", "fc3")]
     gmud = dev(gmu)
-    L.check(lib.lshm_dense1d_bwd(L.ptr(dev(dd0)), L.ptr(cat3d), Mud.data_ptr() + 4 * mu_col, D, gmud.data_ptr() + 4 * mu_col, D,
+    L.check(bwd(L.ptr(dev(dd0)), L.ptr(cat3d), Mud.data_ptr() + 4 * mu_col, D, gmud.data_ptr() + 4 * mu_col, D,
                                  L.ptr(z1d), L.ptr(cat1d), arr(ws_), *[L.ptr(t) for t in outs], nb, L.stream()), "dense1d_bwd")
     torch.cuda.synchronize()
     eg = lambda y: torch.where(y > 0, torch.ones_like(y), y + 1.0)
     dcat3 = (d(dd0) @ d(W["fc3"])) * eg(c3)
-    dzmu = (dcat3[:, :16] @ d(W["fc2out"]) + d(gmu[:, mu_col:mu_col + 16])) * eg(mu)
+    dzmu = (dcat3[:, :Ld] @ d(W["fc2out"]) + d(gmu[:, mu_col:mu_col + Ld])) * eg(mu)
     dz1 = (dzmu @ d(W["fc2in"])) * eg(z1)
     dcat1 = (dz1 @ d(W["fc1"])) * eg(d(cat1))
     for got, ref in zip(outs, (dcat3, dzmu, dz1, dcat1)):
