@@ -283,7 +283,8 @@ bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
 int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs,
                       float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks,
                       hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd, int small_bf16) {
-  if (Cs == 12 && !small_bf16 && (big_bf16 || !getenv("LSHM_FUSED2_12_8")) && conv1d_bwd_lds_supported(Cs, Cb, Ls, pad))
+  if (((Cs == 12 && !small_bf16 && (big_bf16 || !getenv("LSHM_FUSED2_12_8"))) || (Cs == 8 && !small_bf16 && !big_bf16)) &&
+      conv1d_bwd_lds_supported(Cs, Cb, Ls, pad))
     return conv1d_bwd_lds(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, max_blocks, st, grid_out, fd, big_bf16);
   const bool two = small2 != nullptr;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
@@ -552,7 +553,10 @@ __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs 
 }
 
 bool conv1d_bwd_lds_supported(int Cs, int Cb, int Ls, int pad) {
-  return !getenv("LSHM_BWD_LDS_OFF") && Cs == 12 && Cb == 8 && Ls % 128 == 0 && (pad == 0 || pad == 1);
+  if (getenv("LSHM_BWD_LDS_OFF")) return false;
+  if (Cs == 12 && Cb == 8) return Ls % 128 == 0 && (pad == 0 || pad == 1);
+  // conv0 of the 1-D autoencoders (4 -> 8 channels, pad 1): the register form runs at 3.0 TB/s with two wavefronts per SIMD
+  return Cs == 8 && Cb == 4 && pad == 1 && Ls % 256 == 0 && !getenv("LSHM_BWD_LDS_8_4_OFF");
 }
 
 int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs, float* ws,
@@ -573,7 +577,8 @@ int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const flo
   a.partial[0] = ws; a.partial[1] = two ? ws2 : ws;
   a.dout[0] = fd.dx; a.dout[1] = two ? fd.dx2 : fd.dx;
   a.s_bs = s_bs; a.big_bs = big_bs; a.d_bs = fd.dx_bs;
-  a.Ls = Ls; a.Lb = Lb; a.ntiles = (Ls / 128) * B;
+  const int TP = Cs == 8 ? 256 : 128;
+  a.Ls = Ls; a.Lb = Lb; a.ntiles = (Ls / TP) * B;
   int grid = a.ntiles < 512 ? a.ntiles : 512;
   if (grid > max_blocks) grid = max_blocks;
   if (grid < 1) grid = 1;
@@ -581,7 +586,11 @@ int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const flo
   const dim3 g(grid, two ? 2 : 1);
   const bool dact = fd.dact != 0;
 #define LSHM_BLDS(CONV_, DACT_, TB_) hipLaunchKernelGGL((conv1d_bwd_lds_kernel<12, 8, 128, CONV_, DACT_, TB_>), g, dim3(256), 0, st, a)
-  if (big_bf16) {
+  if (Cs == 8) {
+    if (big_bf16) { set_last_error("conv1d_bwd_lds: the 8 / 4 channel form is fp32 only"); return LSHM_ERR_UNSUPPORTED; }
+    if (dact) hipLaunchKernelGGL((conv1d_bwd_lds_kernel<8, 4, 256, true, true, float>), g, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv1d_bwd_lds_kernel<8, 4, 256, true, false, float>), g, dim3(256), 0, st, a);
+  } else if (big_bf16) {
     if (pad == 0) { if (dact) LSHM_BLDS(false, true, bf16); else LSHM_BLDS(false, false, bf16); }
     else { if (dact) LSHM_BLDS(true, true, bf16); else LSHM_BLDS(true, false, bf16); }
   } else {

@@ -147,10 +147,11 @@ def test_dense_layers_at_full_batch(K, N, act):
 
 
 @pytest.mark.parametrize("kind,i,elu_grad,form", [(3, 5, 1, ""), (3, 4, 1, "lds"), (2, 1, 1, "lds"), (3, 4, 0, "lds"), (2, 1, 0, "lds"),
-                                                  (3, 4, 1, "reg"), (2, 1, 1, "reg"), (2, 0, 0, ""), (2, 0, 1, ""), (3, 5, 0, ""),
-                                                  (1, 5, 1, ""), (1, 5, 0, "")],
+                                                  (3, 4, 1, "reg"), (2, 1, 1, "reg"), (2, 0, 0, "lds"), (2, 0, 1, "lds"),
+                                                  (2, 0, 0, "reg84"), (2, 0, 1, "reg84"), (3, 5, 0, ""), (1, 5, 1, ""), (1, 5, 0, "")],
                          ids=["tconv5", "tconv4", "conv1", "tconv4-noelu", "conv1-noelu", "tconv4-registers", "conv1-registers",
-                              "conv0", "conv0-elu", "tconv5-noelu", "2d-tconv5", "2d-tconv5-noelu"])
+                              "conv0", "conv0-elu", "conv0-registers", "conv0-elu-registers", "tconv5-noelu", "2d-tconv5",
+                              "2d-tconv5-noelu"])
 def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, form, monkeypatch):
     """lshm_conv_bwd_fused (weight + bias + data gradient from one read of dz and the saved input; backward of
     src/lofar_models.py:115-117,140-142) against the pair of kernels it replaces (lshm_conv_wgrad + lshm_conv_dgrad)
@@ -160,6 +161,9 @@ def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, form, monkeypatch)
     from lshm_amd import _lib as L
     lib = L.load()
     ishape, wshape, cin, cout = _shapes(kind, i)
+    monkeypatch.delenv("LSHM_BWD_LDS_8_4_OFF", raising=False)
+    if form == "reg84":
+        monkeypatch.setenv("LSHM_BWD_LDS_8_4_OFF", "1")  # conv0 on the register form (what bf16 storage still uses)
     if form == "reg":
         monkeypatch.setenv("LSHM_FUSED2_12_8", "1")  # the register form of the 12 / 8 channel layers (opt-in: it spills)
     else:
