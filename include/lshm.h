@@ -125,7 +125,7 @@ int lshm_conv_wgrad_bf16(int kind, const float* x, const float* dz, float* dw, f
 /* Weight, bias AND data gradient of one layer from ONE pass over dz and the saved input x (the two calls above
  * read both tensors twice).  Available for the bandwidth-bound outer layers: 1-D k4 s4 conv / transposed conv
  * with 4 <-> 8 and 8 <-> 12 channels (src/lofar_models.py:115-117,140-142 backward) and the 2-D k4 s2 p1
- * transposed conv 8 -> 4 (:57 backward); LSHM_ERR_UNSUPPORTED otherwise.  elu_grad != 0: dx is multiplied by
+ * transposed convs 8 -> 4 and 12 -> 8 (:56-57 backward) and conv 8 -> 12 (:32 backward); LSHM_ERR_UNSUPPORTED otherwise.  elu_grad != 0: dx is multiplied by
  * ELU'(x) (x is then the saved ELU output feeding the layer).  dw / db / dx are overwritten. */
 int lshm_conv_bwd_fused(int kind, const float* x, const float* dz, const float* w, float* dw, float* db, float* dx,
                         int elu_grad, int B, int Cin, int Cout, int Hin, int Win, float* workspace,

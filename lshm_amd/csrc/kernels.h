@@ -193,6 +193,12 @@ int tconv2d_bwd_fused(const float* small, long s_bs, const float* big, long big_
                       float* dw, float* db, int B, int Hs, int Ws, float* ws, size_t wsf, int accumulate, hipStream_t st,
                       GradJobs* defer = nullptr, int big_bf16 = 0, int small_bf16 = 0);
 
+// one-pass backward of the 12 <-> 8 channel 2-D layers (tconv4, conv1), conv2d_fused.hip; conv != 0: conv layer
+bool conv2d_bwd_lds_supported(int Cs, int Cb, int Hs, int Ws);
+int conv2d_bwd_lds(const float* small, long s_bs, const float* big, long big_bs, const float* w, float* dout, int conv, int dact,
+                   float* dw, float* db, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
+                   hipStream_t st, GradJobs* defer = nullptr);
+
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
                                 const float* small, const float* big);
