@@ -10,8 +10,9 @@
 //        A fragments straight from the big patch, ELU' from the small tile, float4 stores from the accumulators;
 //   conv layer (conv1; small = dz, big = saved input x):
 //     dbig[cb][2m+py][2n+px] = ELU'(x) * sum_{cs,dy,dx} dz[cs][m+dy][n+dx] w[cs][cb][py-2dy+1][px-2dx+1]
-//     -- the all-parity form of tconv2d_direct_kernel: M = 16 consecutive n, N = (py, px, cb) = 32, K = (cs, 3 x 3
-//        neighbourhood) = 108; the small tile is staged WITH its halo ring for this (the weight gradient reads its
+//     -- one GEMM per row parity py: M = 16 consecutive n, N = (px, cb) = 16, K = (cs, 2 x 3 neighbourhood) = 72 (the
+//        all-parity form of tconv2d_direct_kernel has N = 32, K = 108: 3/2 of the matrix instructions and of the
+//        weight registers); the small tile is staged WITH its halo ring for this (the weight gradient reads its
 //        interior), results go through an LDS output tile, ELU' comes from the interior of the big patch.
 // Tiles are 4 x 32 small positions (8 x 64 big), 2048 of them at B = 256 over 512 persistent workgroups; the
 // weight-gradient accumulators (32 registers) live across all tiles of a workgroup and leave as one slab per
@@ -61,22 +62,24 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
   for (int i = t; i < SM_FLOATS; i += 256) simg[i] = 0.f;
 
   // ---- data-gradient weight fragments of this lane
-  constexpr int KS = CONV ? (CS * 9 + 3) / 4 : CB * 4;
-  constexpr int NTD = CONV ? 2 : 1;
+  // conv layer: one GEMM per output row parity py with the two column parities side by side in the 16-wide tile:
+  //   N = (px, cb), K = (cs, dyi in {0, 1}, dxp in {0, 1, 2}) = 72 (18 k-steps, 2/3 of the products useful; the form with all
+  //   four parities in N has K = 108 and 4/9), dy = py - 1 + dyi, dx = dxp - 1, ky = 3 - py - 2 dyi, kx = px - 2 dxp + 3
+  constexpr int KS = CONV ? CS * 6 / 4 : CB * 4;
+  constexpr int NTD = CONV ? 2 : 1;  // CONV: index = py
   float bf[KS][NTD];
   if constexpr (CONV) {
+    const int px = lm >> 3, co = lm & 7;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int k = 4 * s + lk;
-      const int cs = k / 9, r = k - cs * 9;
-      const int dy = r / 3 - 1, dx = r - (r / 3) * 3 - 1;
+      const int cs = k / 6, r = k - cs * 6;
+      const int dyi = r / 3, dxp = r - dyi * 3;
+      const int kx = px - 2 * dxp + 3;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = 16 * j + lm;
-        const int py = n / (2 * CB), px = (n / CB) & 1, co = n % CB;
-        const int ky = py - 2 * dy + 1, kx = px - 2 * dx + 1;
-        const bool ok = k < CS * 9 && (dy == py - 1 || dy == py) && (dx == px - 1 || dx == px);
-        bf[s][j] = ok ? w[(((long)cs * CB + co) * 4 + ky) * 4 + kx] : 0.f;
+      for (int py = 0; py < 2; ++py) {
+        const int ky = 3 - py - 2 * dyi;
+        bf[s][py] = (kx >= 0 && kx <= 3) ? w[(((long)cs * CB + co) * 4 + ky) * 4 + kx] : 0.f;
       }
     }
   } else {
@@ -241,35 +244,36 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
         }
       }
     } else {
-      f32x4 d[MW][2];
+      f32x4 d[MW][2];  // [m-tile][py]
 #pragma unroll
       for (int i = 0; i < MW; ++i) { d[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; d[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int k = 4 * s + lk;
-        const int cs = k / 9, r = k - cs * 9;
-        const int dyp = r / 3, dxp = r - dyp * 3;  // dy + 1, dx + 1: offsets into the haloed small image
-        const int koff = (k < CS * 9) ? (cs * SPH + dyp) * SPW + dxp : 0;
+        const int cs = k / 6, r = k - cs * 6;
+        const int dyi = r / 3, dxp = r - dyi * 3;
+        const int koff = (cs * SPH + dyi) * SPW + dxp;  // haloed small image: row + py + dyi, column + dxp
 #pragma unroll
         for (int i = 0; i < MW; ++i) {
           const int mt = wave * MW + i;
           const int row = mt / TPR, col = (mt - row * TPR) * 16;
-          const float av = (k < CS * 9) ? simg[koff + row * SPW + col + lm] : 0.f;
+          const float* ap = &simg[koff + row * SPW + col + lm];
 #pragma unroll
-          for (int j = 0; j < 2; ++j) d[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bf[s][j], d[i][j], 0, 0, 0);
+          for (int py = 0; py < 2; ++py) d[i][py] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[py * SPW], bf[s][py], d[i][py], 0, 0, 0);
         }
       }
+      {
+        const int px = lm >> 3, co = lm & 7;
 #pragma unroll
-      for (int i = 0; i < MW; ++i) {
-        const int mt = wave * MW + i;
-        const int row = mt / TPR, col = (mt - row * TPR) * 16 + 4 * lk;
+        for (int i = 0; i < MW; ++i) {
+          const int mt = wave * MW + i;
+          const int row = mt / TPR, col = (mt - row * TPR) * 16 + 4 * lk;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int n = 16 * j + lm;
-          const int py = n / (2 * CB), px = (n / CB) & 1, co = n % CB;
-          float* o = &otile[(co * 2 * TH + 2 * row + py) * OW + 2 * col + px];
+          for (int py = 0; py < 2; ++py) {
+            float* o = &otile[(co * 2 * TH + 2 * row + py) * OW + 2 * col + px];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[2 * r] = d[i][j][r];
+            for (int r = 0; r < 4; ++r) o[2 * r] = d[i][py][r];
+          }
         }
       }
       __syncthreads();
