@@ -17,10 +17,14 @@
 namespace lshm {
 
 // ----------------------------------------------------------------------------------------------
-// transposed conv k4 s2 p1 forward == conv k4 s2 p1 data gradient, all parities per workgroup.
+// transposed conv k4 s2 p1 forward == conv k4 s2 p1 data gradient (tconv4: 12 -> 8 channels).
 //   big[b, co, 2m+py, 2n+px] = bias[co] + sum_{cs,dy,dx} small[b, cs, m+dy, n+dx] * w[cs, co, py-2dy+1, px-2dx+1]
 //   (dy in {py-1, py}, dx in {px-1, px})
-// Tile: TH small rows x TW small columns; 4 wavefronts, each (TH*TW/16)/4 m-tiles of 16 columns.
+// One GEMM per output ROW parity py, the two column parities side by side in the 16-wide tile: M = 16 consecutive n,
+// N = (px, co) = 2 CB = 16, K = (cs, dyi in {0,1}, dxp in {0,1,2}) = 6 CS with dy = py - 1 + dyi, dx = dxp - 1 (a column
+// parity uses two of the three dxp: 2/3 of the products are useful; the first form of this kernel put all four parities
+// into N = 32 over the whole 3 x 3 neighbourhood, K = 9 CS with 4/9 useful -- 3/2 of the matrix instructions and of the
+// weight-fragment registers).  Tile: TH small rows x TW small columns; 4 wavefronts, each (TH*TW/16)/4 m-tiles.
 // ----------------------------------------------------------------------------------------------
 template <int CS, int CB, int TH, int TW, class TO = float>  // TO: element type of `big` and of `dact` (bf16 storage, common.h)
 __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __restrict__ small, long s_bs,
@@ -29,10 +33,10 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
                                                              float* __restrict__ big_, long big_bs,
                                                              const float* __restrict__ dact_, int Hs, int Ws,
                                                              int act, int ntiles) {
+  static_assert(2 * CB == 16 && (CS * 6) % 4 == 0, "(px, co) fills one 16-wide tile; whole k-steps");
   TO* __restrict__ big = reinterpret_cast<TO*>(big_);
   const TO* __restrict__ dact = reinterpret_cast<const TO*>(dact_);
-  constexpr int K = CS * 9, KS = (K + 3) / 4;       // k-steps of 4
-  constexpr int N = 4 * CB, NT = (N + 15) / 16;     // n-tiles of 16
+  constexpr int KS = CS * 6 / 4;                    // k-steps of 4
   constexpr int PH = TH + 2, PW = TW + 2;           // input patch with halo
   constexpr int MT = TH * TW / 16;                  // m-tiles per workgroup
   constexpr int MW = MT / 4;                        // m-tiles per wave
@@ -43,22 +47,19 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lm = lane & 15, lk = lane >> 4;
-  // ---- B fragments: lane (kk = lk, n = lm) of step s, tile j holds W'[4s+kk][16j+lm]
-  float bf[KS][NT];
+  const int px = lm >> 3, co = lm & 7;
+  // ---- B fragments: lane (kk = lk, n = lm = (px, co)) of step s, row parity py: ky = 3 - py - 2 dyi, kx = px - 2 dxp + 3
+  float bf[KS][2];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int k = 4 * s + lk;
-    const int cs = k / 9, r = k - cs * 9;
-    const int dy = r / 3 - 1, dx = r - (r / 3) * 3 - 1;
+    const int cs = k / 6, r = k - cs * 6;
+    const int dyi = r / 3, dxp = r - dyi * 3;
+    const int kx = px - 2 * dxp + 3;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = 16 * j + lm;
-      const int py = n / (2 * CB), px = (n / CB) & 1, co = n % CB;
-      const int ky = py - 2 * dy + 1, kx = px - 2 * dx + 1;
-      const bool ok = k < K && n < N && (dy == py - 1 || dy == py) && (dx == px - 1 || dx == px);
-      bf[s][j] = ok ? w[(((long)cs * CB + co) * 4 + ky) * 4 + kx] : 0.f;
-    }
+    for (int py = 0; py < 2; ++py) bf[s][py] = (kx >= 0 && kx <= 3) ? w[(((long)cs * CB + co) * 4 + 3 - py - 2 * dyi) * 4 + kx] : 0.f;
   }
+  const float bv = bias ? bias[co] : 0.f;
   // persistent over tiles: the weight fragments above are loaded once per workgroup; the next
   // tile's patch is fetched into registers while the current tile computes (software pipeline)
   const int tiles_x = Ws / TW, tiles_y = Hs / TH;
@@ -114,28 +115,28 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
   __syncthreads();
   if (tile + (int)gridDim.x < ntiles) load_tile(tile + gridDim.x);
 
-  f32x4 acc[MW][NT];
+  f32x4 acc[MW][2];  // [m-tile][py]
 #pragma unroll
   for (int i = 0; i < MW; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // m-tile index -> (row in tile, first column in tile)
   constexpr int TPR = TW / 16;  // m-tiles per tile row
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int k = 4 * s + lk;
-    const int cs = k / 9, r = k - cs * 9;
-    const int dyp = r / 3, dxp = r - dyp * 3;  // dy+1, dx+1
-    const int koff = (k < K) ? (cs * PH + dyp) * PW + dxp : 0;
+    const int cs = k / 6, r = k - cs * 6;
+    const int dyi = r / 3, dxp = r - dyi * 3;
+    const int koff = (cs * PH + dyi) * PW + dxp;  // patch row = row + py + dyi, column = col + dxp
 #pragma unroll
     for (int i = 0; i < MW; ++i) {
       const int mt = wave * MW + i;
       const int row = mt / TPR, col = (mt - row * TPR) * 16;
-      const float a = (k < K) ? patch[koff + row * PW + col + lm] : 0.f;
+      const float* ap = &patch[koff + row * PW + col + lm];
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s][j], acc[i][j], 0, 0, 0);
+      for (int py = 0; py < 2; ++py)
+        acc[i][py] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[py * PW], bf[s][py], acc[i][py], 0, 0, 0);
     }
   }
   // ---- accumulators -> LDS output tile [co][2*TH][2*TW] (bias + activation applied here)
@@ -144,17 +145,12 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
     const int mt = wave * MW + i;
     const int row = mt / TPR, col = (mt - row * TPR) * 16 + 4 * lk;  // 4 consecutive small columns
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = 16 * j + lm;
-      if (n < N) {
-        const int py = n / (2 * CB), px = (n / CB) & 1, co = n % CB;
-        const float bv = bias ? bias[co] : 0.f;
-        float* o = &otile[(co * 2 * TH + 2 * row + py) * OW + 2 * col + px];
+    for (int py = 0; py < 2; ++py) {
+      float* o = &otile[(co * 2 * TH + 2 * row + py) * OW + 2 * col + px];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[i][j][r] + bv;
-          o[2 * r] = act ? elu(v) : v;
-        }
+      for (int r = 0; r < 4; ++r) {
+        const float v = acc[i][py][r] + bv;
+        o[2 * r] = act ? elu(v) : v;
       }
     }
   }
@@ -165,9 +161,9 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
   const TO* db = dact ? dact + (long)b * big_bs : nullptr;
   for (int i = t; i < CB * 2 * TH * OW / 4; i += 256) {
     const int e = 4 * i;
-    const int co = e / (2 * TH * OW), r = e - co * (2 * TH * OW);
+    const int c = e / (2 * TH * OW), r = e - c * (2 * TH * OW);
     const int oy = r / OW, ox = r - oy * OW;
-    const long g = ((long)co * Hb + 2 * m0 + oy) * Wb + 2 * n0 + ox;
+    const long g = ((long)c * Hb + 2 * m0 + oy) * Wb + 2 * n0 + ox;
     f32x4 v = *reinterpret_cast<const f32x4*>(&otile[e]);
     if (db) {
       const f32x4 sv = Elem<TO>::ld4(db + g);
@@ -360,15 +356,23 @@ int tconv2d_direct(const float* small, long s_bs, const float* w, const float* b
     else
       hipLaunchKernelGGL((tconv2d_q4_kernel<4>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
   } else if (Cs == 12 && Cb == 8) {
-    // 512 workgroups (two tiles each, two resident per CU): 31.6 / 32.6 us (tconv4 forward / conv1's data gradient) against
-    // 33.6 / 35.3 with 768 and 37.4 / 43.3 with 256; half-height tiles are no better at any grid size
     static const int cap = [] { const char* v = getenv("LSHM_GRID_TCONV2D_12_8"); return v && atoi(v) > 0 ? atoi(v) : 512; }();
-    const int ntiles = (Ws / 32) * (Hs / 8) * B;
-    const dim3 grid(ntiles < cap ? ntiles : cap);
-    if (big_bf16)
-      hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32, bf16>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
-    else
-      hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    static const bool h8 = getenv("LSHM_TCONV2D_H8") != nullptr;
+    if (h8 || Hs % 4) {
+      const int ntiles = (Ws / 32) * (Hs / 8) * B;
+      const dim3 grid(ntiles < cap ? ntiles : cap);
+      if (big_bf16)
+        hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32, bf16>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+      else
+        hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 8, 32>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    } else {
+      const int ntiles = (Ws / 32) * (Hs / 4) * B;
+      const dim3 grid(ntiles < cap ? ntiles : cap);
+      if (big_bf16)
+        hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 4, 32, bf16>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+      else
+        hipLaunchKernelGGL((tconv2d_direct_kernel<12, 8, 4, 32>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
+    }
   } else {
     set_last_error("tconv2d_direct: unsupported shape");
     return LSHM_ERR_UNSUPPORTED;
