@@ -579,7 +579,8 @@ int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const flo
   a.s_bs = s_bs; a.big_bs = big_bs; a.d_bs = fd.dx_bs;
   const int TP = Cs == 8 ? 256 : 128;
   a.Ls = Ls; a.Lb = Lb; a.ntiles = (Ls / TP) * B;
-  static const int cap_env = [] { const char* v = getenv("LSHM_GRID_BWD_LDS"); return v && atoi(v) > 0 ? atoi(v) : 512; }();
+  static const int cap_env = [] { const char* v = getenv("LSHM_GRID_BWD_LDS"); return v && atoi(v) > 0 ? atoi(v) : 256; }();
+  // 256 workgroups per problem: 128 / 256 / 384 / 512 / 768 are within 0.01 ms of each other in the step; fewer slabs for the closing sums
   int grid = a.ntiles < cap_env ? a.ntiles : cap_env;
   if (grid > max_blocks) grid = max_blocks;
   if (grid < 1) grid = 1;
