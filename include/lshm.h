@@ -388,6 +388,13 @@ int lshm_engine_set_early_bucket(lshm_engine* e, int on);
 /* HIP device the engine was created on (-1: no device): every engine call makes it current, refuses a stream of
  * another device and refuses arena / workspace / input pointers that are not device memory of that device. */
 int lshm_engine_device(const lshm_engine* e);
+/* Diagnostic (an engine created with LSHM_PHASE_EVENTS=1 in the environment; LSHM_ERR_UNSUPPORTED otherwise): device
+ * timestamps at the phase boundaries of the last iteration (lshm_engine_backward_saved, the optimiser, then
+ * lshm_engine_multiplier_update_next_ex), in milliseconds after the closure's first launch; synchronises the device.
+ * ms[0..9] = closure entry (0), 1-D backward done, main-stream backward done, weight-gradient stream done, closure end,
+ * update entry (after the optimiser step), closure forward done, no-grad forward done, reconstruction pass done, update
+ * end; -1 for a phase the schedule did not run.  No profiler involved: each mark is one hipEventRecord. */
+int lshm_engine_phase_times(const lshm_engine* e, float* ms, int n);
 /* what the LAST engine call on `e` actually did (diagnostics, tests) */
 #define LSHM_ENGINE_USED_EARLY_BUCKET 1u       /* the netT / netF gradients went as an early all-reduce bucket */
 #define LSHM_ENGINE_USED_CONCURRENT_FORWARD 2u /* two forwards ran side by side (LSHM_NEXT_CONCURRENT_FORWARD) */

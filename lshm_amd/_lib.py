@@ -143,6 +143,7 @@ _SIGNATURES = {
     "lshm_engine_multiplier_update_next": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_multiplier_update_next_ex": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, C.c_uint, c_void_p]),
     "lshm_engine_device": (c_int, [c_void_p]),
+    "lshm_engine_phase_times": (c_int, [c_void_p, c_void_p, c_int]),
     "lshm_engine_last_flags": (C.c_uint, [c_void_p]),
     "lshm_engine_comm_early_bucket": (c_int, [c_void_p]),
     "lshm_engine_set_early_bucket": (c_int, [c_void_p, c_int]),

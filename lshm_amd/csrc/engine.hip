@@ -105,6 +105,12 @@ struct lshm_engine {
   bool pair_mode;  // netT/netF share launches (default) instead of running on two streams (LSHM_FORK=1)
   bool side_wgrad; // weight-gradient chain on the side stream (default; LSHM_WGRAD_INLINE=1 turns it off)
   hipEvent_t take_event() const { return events[next_event++ % events.size()]; }
+  // LSHM_PHASE_EVENTS=1 (diagnostic, lshm_engine_phase_times): timestamps at the phase boundaries of an iteration, unprofiled.
+  // Each is a marker packet (~6 us of idle queue on its stream), so the instrumented iteration is ~0.05 ms slower.
+  enum { PH_CLOSURE = 0, PH_BWD1D, PH_BWD_MAIN_END, PH_BWD_SIDE_END, PH_CLOSURE_END, PH_UPDATE, PH_FWD_CLOSURE_END, PH_FWD_NOGRAD_END,
+         PH_RECON_END, PH_UPDATE_END, PH_COUNT };
+  std::vector<hipEvent_t> phase;
+  void mark(int which, hipStream_t s) const { if (!phase.empty() && !in_capture) (void)hipEventRecord(phase[which], s); }
   size_t part_floats;
   size_t ws_floats;
   int device;      // HIP device current at creation (-1: none); the side stream and the events live there
@@ -973,6 +979,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     early_bucket = true;
     e->last_flags |= LSHM_ENGINE_USED_EARLY_BUCKET;
   }
+  e->mark(lshm_engine::PH_BWD1D, st);
   if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st, e->bf))) return rc;
   {
     const int i0[1] = {0};
@@ -981,6 +988,8 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     float* di0[1] = {nullptr};
     if ((rc = ae_backward(e, 1, i0, prm, grd, in0, dz0, di0, ws, 2, st, wgs))) return rc;
   }
+  e->mark(lshm_engine::PH_BWD_MAIN_END, st);
+  if (wgs) e->mark(lshm_engine::PH_BWD_SIDE_END, wgs);
   if (wgs) {  // the weight-gradient chain joins here, before anything consumes the gradients
     hipEvent_t evj = e->take_event();
     if (hipEventRecord(evj, wgs) != hipSuccess || hipStreamWaitEvent(st, evj, 0) != hipSuccess) {
@@ -1237,7 +1246,13 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
       bool ok = ((wp && wp[0] == 'n') ? hipStreamCreateWithFlags(&e->wstream, hipStreamNonBlocking)
                                       : hipStreamCreateWithPriority(&e->wstream, hipStreamNonBlocking, (wp && wp[0] == 'h') ? phi : plo)) == hipSuccess;
       ok = ok && hipStreamCreateWithFlags(&e->lstream, hipStreamNonBlocking) == hipSuccess;
-      ok = ok && hipStreamCreateWithFlags(&e->fstream, hipStreamNonBlocking) == hipSuccess;
+      {  // the no-grad forward's stream ABOVE the caller's: the reconstruction pass and with it the backward wait for that
+         // chain (it is the longer one: it also runs the 1-D output layers), the closure forward beside it has ~0.2 ms of
+         // slack (profiles/r03/phase_times.txt).  2.127 against 2.141 ms; below: 2.139 (LSHM_FST_PRIORITY=normal|low for A/B)
+        const char* fp = getenv("LSHM_FST_PRIORITY");
+        ok = ok && ((fp && fp[0] == 'n') ? hipStreamCreateWithFlags(&e->fstream, hipStreamNonBlocking)
+                                         : hipStreamCreateWithPriority(&e->fstream, hipStreamNonBlocking, (fp && fp[0] == 'l') ? plo : phi)) == hipSuccess;
+      }
       {
         const char* v = getenv("LSHM_EVENT_POOL");
         const int n = v ? atoi(v) : 256;
@@ -1246,6 +1261,11 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
       for (size_t i = 0; i < e->events.size() && ok; ++i)
         ok = ok && hipEventCreateWithFlags(&e->events[i], hipEventDisableTiming) == hipSuccess;
       e->side_ok = ok;
+      if (ok && getenv("LSHM_PHASE_EVENTS")) {
+        e->phase.resize(lshm_engine::PH_COUNT);
+        for (auto& ev : e->phase) ok = ok && hipEventCreate(&ev) == hipSuccess;
+        if (!ok) e->phase.clear();
+      }
     }
     (void)hipGetLastError();
   }
@@ -1318,6 +1338,19 @@ int lshm_engine_set_comm(lshm_engine* e, lshm_comm* comm) {
 }
 
 int lshm_engine_device(const lshm_engine* e) { return e ? e->device : -1; }
+int lshm_engine_phase_times(const lshm_engine* e, float* ms, int n) {
+  if (!e || !ms || n < 1) { set_last_error("engine_phase_times: bad argument"); return LSHM_ERR_ARG; }
+  if (e->phase.empty()) { set_last_error("engine_phase_times: the engine was created without LSHM_PHASE_EVENTS=1"); return LSHM_ERR_UNSUPPORTED; }
+  if (hipDeviceSynchronize() != hipSuccess) { set_last_error("engine_phase_times: device synchronisation failed"); return LSHM_ERR_ARG; }
+  for (int i = 0; i < n; ++i) {
+    ms[i] = -1.f;  // an event that was never recorded (a phase this schedule does not have)
+    if (i < lshm_engine::PH_COUNT && hipEventElapsedTime(&ms[i], e->phase[lshm_engine::PH_CLOSURE], e->phase[i]) != hipSuccess) {
+      ms[i] = -1.f;
+      (void)hipGetLastError();
+    }
+  }
+  return LSHM_OK;
+}
 unsigned lshm_engine_last_flags(const lshm_engine* e) { return e ? e->last_flags : 0u; }
 int lshm_engine_comm_early_bucket(const lshm_engine* e) {
   return (e && e->comm && e->cstream && e->side_ok && e->side_wgrad && e->pair_mode && e->early_ok) ? 1 : 0;
@@ -1370,9 +1403,12 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
   e->next_event = 0;
   const bool recon_done = e->recon_ready;
   e->recon_ready = false;
+  e->mark(lshm_engine::PH_CLOSURE, st);
   int rc = start_latent_losses(e, params, grads, ws, st);
   if (rc) return rc;
-  return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st, recon_done);
+  rc = losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st, recon_done);
+  e->mark(lshm_engine::PH_CLOSURE_END, st);
+  return rc;
 }
 
 int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, const float* x, const float* uv,
@@ -1395,6 +1431,7 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
                           e->pair_mode;
   hipStream_t fst = concurrent ? e->fstream : st;
   float* fws = concurrent ? ws + e->alt_base : ws;
+  e->mark(lshm_engine::PH_UPDATE, st);
   if (concurrent) {
     hipEvent_t ev = e->take_event();
     if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(fst, ev, 0) != hipSuccess) {
@@ -1407,12 +1444,15 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
   // forward -- so their last decoder layer is not run), enqueued in lock step
   int rc = concurrent ? two_forwards(e, params, x, uv, fws, fst, ws, st, true) : three_forward(e, params, x, uv, fws, fst);
   if (rc) return rc;
+  if (concurrent) e->mark(lshm_engine::PH_FWD_CLOSURE_END, st);
+  e->mark(lshm_engine::PH_FWD_NOGRAD_END, fst);
   // concurrent: the seven sums of the pass (a 13 us launch the caller's stream would wait for) move to the latent-space
   // stream of the next closure: nothing needs them before the loss terms are assembled there
   rc = multiplier_update_recon(x, fws + e->ae[0].out, fws + e->ae[1].out, fws + e->ae[2].out, y1, y2, y3, c.rho,
                                c.B * c.C, c.P, concurrent ? nullptr : reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
                                ws + e->o_gx2, ws + e->o_gx3c, ws + e->o_recon_part, fst, (float)(1.0 / world), e->bf);
   if (rc) return rc;
+  e->mark(lshm_engine::PH_RECON_END, fst);
   e->sum7_pending = concurrent;
   if (concurrent) {
     hipEvent_t evj = e->take_event();
@@ -1422,6 +1462,7 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
     }
     e->last_flags |= LSHM_ENGINE_USED_CONCURRENT_FORWARD;
   }
+  e->mark(lshm_engine::PH_UPDATE_END, st);
   e->recon_ready = true;
   return LSHM_OK;
 }

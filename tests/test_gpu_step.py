@@ -852,6 +852,31 @@ def test_engine_reports_its_device_and_refuses_what_is_not_on_it():
     assert torch.isfinite(tr.params).all() and not torch.equal(before, tr.params)
 
 
+def test_phase_timestamps_are_opt_in_and_ordered(monkeypatch):
+    """lshm_engine_phase_times (include/lshm.h): an engine created under LSHM_PHASE_EVENTS=1 reports the device time of the
+    phase boundaries of the last iteration in the order the schedule runs them; any other engine refuses; the marks do
+    not change the trajectory."""
+    import ctypes as C
+    from lshm_amd import _lib as L
+    plain, *_ = _trainer(4, 4, 2, 2)
+    ms = (C.c_float * 10)()
+    assert plain.lib.lshm_engine_phase_times(plain._h, ms, 10) == -3
+    monkeypatch.setenv("LSHM_PHASE_EVENTS", "1")
+    tr, *_ = _trainer(4, 4, 2, 2)
+    monkeypatch.delenv("LSHM_PHASE_EVENTS")
+    for _ in range(3):
+        plain.step()
+        tr.step()
+    L.check(tr.lib.lshm_engine_phase_times(tr._h, ms, 10), "phase_times")
+    t = list(ms)
+    assert t[0] == 0.0 and all(v >= 0.0 for v in t)
+    # closure: 1-D backward <= main-stream end <= join; weight-gradient stream end <= join; then Adam, the two forwards, the pass
+    assert t[1] <= t[2] <= t[4] and t[3] <= t[4] <= t[5]
+    assert t[5] <= t[6] <= t[9] and t[5] <= t[7] <= t[8] <= t[9]
+    torch.cuda.synchronize()
+    assert torch.equal(plain.params, tr.params)
+
+
 def test_admm_loop_with_staged_minibatches_is_the_recompute_trajectory():
     """The loop upstream runs (src/kharmonic_lofar.py:116-131): ten ADMM iterations per minibatch, the terms read
     back every iteration, the next minibatch uploaded from pinned host memory on a copy stream meanwhile
