@@ -250,6 +250,12 @@ int lshm_rica_update_dictionary_bf16(const float* Xt, float* A, const float* St,
 int lshm_residual_split(const float* x, const float* x1, float* out_row, float* out_col, int planes,
                         int P, lshm_stream_t stream);
 int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_stream_t stream);
+/* netT.conv0 and netF.conv0 (Conv1d(4, 8, 4, stride=4, padding=1) + ELU, src/lofar_models.py:115) of the row- and the
+ * column-vectorised residual (x - x1) / 2 (src/kharmonic_lofar.py:142-147) in ONE launch straight from x and x1
+ * ((B,4,128,128) each): neither vectorisation is written.  yT, yF: (B, 8, 4096).  Bitwise the results of
+ * lshm_residual_split followed by lshm_conv_fwd_pair; for a forward whose activations are not kept. */
+int lshm_resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF,
+                     const float* bF, float* yF, int B, lshm_stream_t stream);
 size_t lshm_recon_workspace_floats(int planes, int P);
 /* sums7 = [sum e^2, y1.r1, sum r1^2, y2.r2, sum r2^2, y3.r3, sum r3^2]; gradients scaled by 1/n;
  * x3c / gx3c are in the column-vectorised (per-plane transposed) layout of the third AE.

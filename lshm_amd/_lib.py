@@ -92,6 +92,7 @@ _SIGNATURES = {
     "lshm_logcosh_fwd_bwd": (c_int, [c_void_p, c_long, c_int, c_int, c_float, c_void_p, c_void_p, c_long,
                                      c_int, c_void_p]),
     "lshm_residual_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lshm_resid_conv0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lshm_plane_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lshm_rica_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "lshm_rica_loss_grad": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -65,6 +65,8 @@ struct lshm_engine {
     const float* uv = nullptr;
     std::vector<lshm::FwdStep> steps;
     size_t latent_mark = 0, output1d_mark = 0;
+    size_t resid_mark = 0;        // steps[resid_mark] = residual_split, steps[resid_mark + 1] = conv0 of netT / netF
+    lshm::FwdStep resid_conv0;    // both in one launch, neither vectorisation written (resid_conv0.hip); empty: not available
   } plan;
   int D;        // L + 2 Lt
   int hdim;     // 4 H
@@ -382,7 +384,8 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
 // The three forwards of the default (paired) schedule as one step list: harmonic features + the six layers fed by
 // them alone, the 2-D autoencoder, the residual split, netT and netF as paired launches.
 static void three_forward_steps(const lshm_engine* e, const float* prm, const float* x, const float* uv,
-                                std::vector<FwdStep>& steps, size_t* latent_mark, size_t* output1d_mark) {
+                                std::vector<FwdStep>& steps, size_t* latent_mark, size_t* output1d_mark,
+                                size_t* resid_mark = nullptr, FwdStep* resid_conv0_step = nullptr) {
   const lshm_step_config& c = e->cfg;
   steps.push_back([=](float* ws, hipStream_t st) -> int {
     UvLayers ul;
@@ -399,6 +402,20 @@ static void three_forward_steps(const lshm_engine* e, const float* prm, const fl
   const int i0[1] = {0};
   const Src in0[1] = {Src{x, 0}};
   ae_forward_steps(e, 1, i0, prm, in0, 0, steps, nullptr, nullptr);
+  if (resid_mark) *resid_mark = steps.size();
+  if (resid_conv0_step) {
+    // a forward whose 1-D activations nobody reads afterwards may run conv0 of netT / netF straight from x and the 2-D
+    // reconstruction (fp32 storage, the layer shapes of kharmonic_lofar.py)
+    const AEPlan& aT = e->ae[1];
+    const AEPlan& aF = e->ae[2];
+    *resid_conv0_step = nullptr;
+    if (!e->bf && e->pair_mode && resid_conv0_supported(c.C, c.P, aT.enc[0].Cin, aT.enc[0].Cout, aT.enc[0].Win) &&
+        aT.enc[0].out_bs == aF.enc[0].out_bs)
+      *resid_conv0_step = [=](float* ws, hipStream_t st) -> int {
+        return resid_conv0(x, ws + e->ae[0].out, prm + aT.cw[0], prm + aT.cb[0], ws + aT.act[0], prm + aF.cw[0], prm + aF.cb[0],
+                           ws + aF.act[0], aT.enc[0].out_bs, c.B, st);
+      };
+  }
   steps.push_back([=](float* ws, hipStream_t st) -> int {
     return residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st, e->bf);
   });
@@ -709,7 +726,7 @@ static const lshm_engine::FwdPlan& forward_plan(lshm_engine* e, const float* prm
   if (P.prm != prm || P.x != x || P.uv != uv || P.steps.empty()) {
     P.steps.clear();
     P.prm = prm; P.x = x; P.uv = uv;
-    three_forward_steps(e, prm, x, uv, P.steps, &P.latent_mark, &P.output1d_mark);
+    three_forward_steps(e, prm, x, uv, P.steps, &P.latent_mark, &P.output1d_mark, &P.resid_mark, &P.resid_conv0);
   }
   return P;
 }
@@ -788,8 +805,18 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
   const int n = (int)P.steps.size();
   const int lead = stagger_env < 0 ? 0 : stagger_env > n ? n : stagger_env;
   int rc;
+  // chain a is the forward whose activations are not kept (the no-grad forward): its residual split + conv0 pair is one launch
+  const bool fused_a = skip_b_1d_output && P.resid_conv0 && P.resid_mark + 1 < (size_t)n;
   for (int i = 0; i < n + lead; ++i) {
-    if (i < n && (rc = P.steps[i](ws_a, st_a))) return rc;
+    if (i < n) {
+      if (fused_a && (size_t)i == P.resid_mark) {
+        // (nothing: the residual is formed on the fly by the next step)
+      } else if (fused_a && (size_t)i == P.resid_mark + 1) {
+        if ((rc = P.resid_conv0(ws_a, st_a))) return rc;
+      } else if ((rc = P.steps[i](ws_a, st_a))) {
+        return rc;
+      }
+    }
     if (lead > 0 && i == lead - 1) {
       hipEvent_t gate = e->take_event();
       if (hipEventRecord(gate, st_a) != hipSuccess || hipStreamWaitEvent(st_b, gate, 0) != hipSuccess) {

@@ -199,6 +199,11 @@ int conv2d_bwd_lds(const float* small, long s_bs, const float* big, long big_bs,
                    float* dw, float* db, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
                    hipStream_t st, GradJobs* defer = nullptr);
 
+// conv0 of netT and netF from x and the 2-D reconstruction in one launch, no materialised residual (resid_conv0.hip)
+bool resid_conv0_supported(int C, int P, int Cin, int Cout, int L1d);
+int resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,
+                float* yF, long y_bs, int B, hipStream_t st);
+
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
                                 const float* small, const float* big);
