@@ -277,17 +277,64 @@ int channel_sum_direct(const float* dz, long bs, int B, int C, long HW, float* d
 // reconstruction terms of the next one read the same seven arrays, so they can share one pass.
 // GRAD = false: only the seven sums (the gradient-free closures of a line search).
 // T: element type of the three reconstructions and of the three gradient images (x and the multipliers are fp32)
-template <bool UPD, bool GRAD = true, class T = float>
+// FROMA: the reconstructions of netT / netF are not read but formed here from the inputs of their last layer
+// (ReconFromA: x2 = netT.tconv5(aT), x3c = netF.tconv5(aF), ConvTranspose1d(8, C, 4, stride=4), src/lofar_models.py:142, no
+// activation): every image element is one tap of one position, eight multiply-adds over cached values -- in the order of
+// tconv1d_stream_kernel, so the values are bitwise the ones that kernel would have written.  The forward that feeds this
+// pass then stops one layer early: 0.13 GB less written, 0.2 GB less read per iteration.
+struct ReconFromA {
+  const float* aT; const float* aF;                                    // (B, 8, P*P/4), batch stride a_bs
+  const float* wT; const float* bT; const float* wF; const float* bF;  // (8, C, 4), (C)
+  long a_bs;
+  int C;                                                               // image channels = planes per sample
+};
+template <bool UPD, bool GRAD = true, class T = float, bool FROMA = false>
 __global__ __launch_bounds__(256) void recon_kernel(
     const float* __restrict__ x, const T* __restrict__ x1, const T* __restrict__ x2,
     const T* __restrict__ x3c, float* y1, float* y2, float* y3, float rho, float inv_n, int P,
     double* __restrict__ partials, T* __restrict__ gx1p, T* __restrict__ gx2,
-    T* __restrict__ gx3c) {
+    T* __restrict__ gx3c, const ReconFromA fa) {
   __shared__ float tile[TILE][TILE + 1];
   __shared__ float red[4][8];
   const TileIdx t = tile_idx(P);
+  // FROMA: this thread's tap (its image column and its transposed-tile column are both == threadIdx.x mod 4) of the eight
+  // input channels of both layers and the biases of this plane's channel.  The activations a 32 x 32 tile needs are
+  // 32 rows x 8 positions x 8 channels per layer: staged in LDS with two float4 loads per thread and layer (reading them
+  // per element through the vector cache -- 64 more load instructions per thread -- made the pass 0.11 ms slower)
+  __shared__ __attribute__((aligned(16))) float stage[FROMA ? 2 * 8 * TILE * 8 : 4];
+  float wt[FROMA ? 8 : 1], wf[FROMA ? 8 : 1], bt = 0.f, bfv = 0.f;
+  if constexpr (FROMA) {
+    const int b = blockIdx.z / fa.C, ch = blockIdx.z - b * fa.C, tap = threadIdx.x & 3;
+    const long LA = (long)P * P / 4;
+    const int h0 = blockIdx.y * TILE, w0 = blockIdx.x * TILE;
+    {  // sT[cs][rr][k] = aT[cs][(h0 + rr) * P / 4 + w0 / 4 + k],  sF[cs][q][k] = aF[cs][(w0 + q) * P / 4 + h0 / 4 + k]
+      const int tid = threadIdx.y * TILE + threadIdx.x, cs = tid >> 5, rr = tid & 31;
+      const float* pT = fa.aT + (long)b * fa.a_bs + cs * LA + (long)(h0 + rr) * (P / 4) + w0 / 4;
+      const float* pF = fa.aF + (long)b * fa.a_bs + cs * LA + (long)(w0 + rr) * (P / 4) + h0 / 4;
+      f32x4* dT = reinterpret_cast<f32x4*>(&stage[(cs * TILE + rr) * 8]);
+      f32x4* dF = reinterpret_cast<f32x4*>(&stage[8 * TILE * 8 + (cs * TILE + rr) * 8]);
+      dT[0] = *reinterpret_cast<const f32x4*>(pT); dT[1] = *reinterpret_cast<const f32x4*>(pT + 4);
+      dF[0] = *reinterpret_cast<const f32x4*>(pF); dF[1] = *reinterpret_cast<const f32x4*>(pF + 4);
+    }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = Elem<T>::ld(x3c + t.col_off[i]);
+    for (int cs = 0; cs < 8; ++cs) {
+      wt[cs] = fa.wT[(cs * fa.C + ch) * 4 + tap];
+      wf[cs] = fa.wF[(cs * fa.C + ch) * 4 + tap];
+    }
+    bt = fa.bT[ch]; bfv = fa.bF[ch];
+    __syncthreads();
+    const float* sF = stage + 8 * TILE * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {  // x3c at (column w0 + ty + 8 i, row h0 + tx): position (c * P + r) / 4 of the column-vectorised sequence
+      float v = bfv;
+#pragma unroll
+      for (int cs = 0; cs < 8; ++cs) v = fmaf(sF[(cs * TILE + threadIdx.y + 8 * i) * 8 + (threadIdx.x >> 2)], wf[cs], v);
+      tile[threadIdx.y + 8 * i][threadIdx.x] = v;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[threadIdx.y + 8 * i][threadIdx.x] = Elem<T>::ld(x3c + t.col_off[i]);
+  }
   __syncthreads();
   float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float g3[4];
@@ -296,7 +343,15 @@ __global__ __launch_bounds__(256) void recon_kernel(
     const long o = t.row_off[i];
     // x and the multipliers are not needed again soon (streamed); x2 / x3 were just written and the
     // three gradients are read next by the backward: leave those to the cache
-    const float xv = __builtin_nontemporal_load(x + o), a1 = Elem<T>::ld(x1 + o), a2 = Elem<T>::ld(x2 + o);
+    const float xv = __builtin_nontemporal_load(x + o), a1 = Elem<T>::ld(x1 + o);
+    float a2;
+    if constexpr (FROMA) {
+      a2 = bt;
+#pragma unroll
+      for (int cs = 0; cs < 8; ++cs) a2 = fmaf(stage[(cs * TILE + threadIdx.y + 8 * i) * 8 + (threadIdx.x >> 2)], wt[cs], a2);
+    } else {
+      a2 = Elem<T>::ld(x2 + o);
+    }
     const float a3 = tile[threadIdx.x][threadIdx.y + 8 * i];
     const float r1 = xv - a1, h = 0.5f * r1, r2 = h - a2, r3 = h - a3;
     const float e = a1 + a2 + a3 - xv;
@@ -357,13 +412,13 @@ static void recon_launch_t(bool upd, const float* x, const T* x1, const T* x2, c
                            hipStream_t st) {
   if (!gx1p && !upd)  // no gradient buffers: the sums alone
     hipLaunchKernelGGL((recon_kernel<false, false, T>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho, inv_n,
-                       P, part, gx1p, gx2, gx3c);
+                       P, part, gx1p, gx2, gx3c, ReconFromA{});
   else if (upd)
     hipLaunchKernelGGL((recon_kernel<true, true, T>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho, inv_n, P,
-                       part, gx1p, gx2, gx3c);
+                       part, gx1p, gx2, gx3c, ReconFromA{});
   else
     hipLaunchKernelGGL((recon_kernel<false, true, T>), grid, dim3(TILE, 8), 0, st, x, x1, x2, x3c, y1, y2, y3, rho, inv_n, P,
-                       part, gx1p, gx2, gx3c);
+                       part, gx1p, gx2, gx3c, ReconFromA{});
 }
 int recon_sum7(const float* block_partials, int planes, int P, double* sums7, hipStream_t st) {
   hipLaunchKernelGGL(sum7_kernel, dim3(7), dim3(1024), 0, st, reinterpret_cast<const double*>(block_partials),
@@ -399,6 +454,27 @@ int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const
                          float* block_partials, hipStream_t st, float grad_scale, int bf) {
   return recon_launch(false, x, x1, x2, x3c, const_cast<float*>(y1), const_cast<float*>(y2), const_cast<float*>(y3),
                       rho, planes, P, sums7, gx1p, gx2, gx3c, block_partials, st, grad_scale, bf);
+}
+// multiplier_update_recon with the reconstructions of netT / netF formed from the inputs of their last layer (fp32 storage;
+// sums left as per-block partials: recon_sum7 finishes them)
+bool recon_from_a_supported(int C, int P, int Cin, int Cout, int Ls) {
+  return !getenv("LSHM_RECON_FROM_A_OFF") && Cin == 8 && Cout == C && C >= 1 && C <= 8 && P % TILE == 0 && (long)Ls * 4 == (long)P * P;
+}
+int multiplier_update_recon_from_a(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT,
+                                   const float* bT, const float* wF, const float* bF, int C, float* y1, float* y2, float* y3,
+                                   float rho, int planes, int P, float* gx1p, float* gx2, float* gx3c, float* block_partials,
+                                   hipStream_t st, float grad_scale) {
+  if (P % TILE || planes % C) { set_last_error("recon_losses: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
+  if (!x || !x1 || !aT || !aF || !wT || !bT || !wF || !bF || !gx1p || !gx2 || !gx3c || !block_partials) {
+    set_last_error("recon_losses: null pointer");
+    return LSHM_ERR_ARG;
+  }
+  const double n = (double)planes * P * P;
+  const ReconFromA fa{aT, aF, wT, bT, wF, bF, a_bs, C};
+  hipLaunchKernelGGL((recon_kernel<true, true, float, true>), dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st, x, x1,
+                     (const float*)nullptr, (const float*)nullptr, y1, y2, y3, rho, (float)(grad_scale / n), P,
+                     reinterpret_cast<double*>(block_partials), gx1p, gx2, gx3c, fa);
+  return check_launch("recon_losses");
 }
 // y_k += rho r_k, then the reconstruction terms of the next closure with the updated multipliers
 int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,

@@ -795,7 +795,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
 // measured slower (see below).  The second forward does not need the reconstructions of netT / netF
 // (skip_b_1d_output).
 static int two_forwards(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws_a, hipStream_t st_a,
-                        float* ws_b, hipStream_t st_b, bool skip_b_1d_output) {
+                        float* ws_b, hipStream_t st_b, bool skip_b_1d_output, bool skip_a_1d_output = false) {
   e->recon_ready = false;
   e->sum7_pending = false;
   const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
@@ -811,6 +811,8 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
     if (i < n) {
       if (fused_a && (size_t)i == P.resid_mark) {
         // (nothing: the residual is formed on the fly by the next step)
+      } else if (skip_a_1d_output && (size_t)i == P.output1d_mark) {
+        // (nothing: the reconstruction pass forms x2 / x3c from this layer's input)
       } else if (fused_a && (size_t)i == P.resid_mark + 1) {
         if ((rc = P.resid_conv0(ws_a, st_a))) return rc;
       } else if ((rc = P.steps[i](ws_a, st_a))) {
@@ -1469,15 +1471,27 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
   // concurrent: the no-grad forward on (fws, fst) and the next closure's forward (activations saved in the primary
   // buffers; nothing reads its reconstructions of netT / netF -- the pass below takes them from the no-grad
   // forward -- so their last decoder layer is not run), enqueued in lock step
-  int rc = concurrent ? two_forwards(e, params, x, uv, fws, fst, ws, st, true) : three_forward(e, params, x, uv, fws, fst);
+  // concurrent, fp32 storage: the no-grad forward stops in front of the last layer of netT / netF and the pass forms their
+  // reconstructions from that layer's input (recon_kernel<.., FROMA>): one launch, 0.13 GB of writes and 0.2 GB of reads less
+  const AEPlan& aT = e->ae[1];
+  const AEPlan& aF = e->ae[2];
+  const bool from_a = concurrent && !e->bf && aT.dec[5].in_bs == aF.dec[5].in_bs &&
+                      recon_from_a_supported(c.C, c.P, aT.dec[5].Cin, aT.dec[5].Cout, aT.dec[5].Win);
+  int rc = concurrent ? two_forwards(e, params, x, uv, fws, fst, ws, st, true, from_a) : three_forward(e, params, x, uv, fws, fst);
   if (rc) return rc;
   if (concurrent) e->mark(lshm_engine::PH_FWD_CLOSURE_END, st);
   e->mark(lshm_engine::PH_FWD_NOGRAD_END, fst);
   // concurrent: the seven sums of the pass (a 13 us launch the caller's stream would wait for) move to the latent-space
   // stream of the next closure: nothing needs them before the loss terms are assembled there
-  rc = multiplier_update_recon(x, fws + e->ae[0].out, fws + e->ae[1].out, fws + e->ae[2].out, y1, y2, y3, c.rho,
-                               c.B * c.C, c.P, concurrent ? nullptr : reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
-                               ws + e->o_gx2, ws + e->o_gx3c, ws + e->o_recon_part, fst, (float)(1.0 / world), e->bf);
+  if (from_a)
+    rc = multiplier_update_recon_from_a(x, fws + e->ae[0].out, fws + aT.dact[4], fws + aF.dact[4], aT.dec[5].in_bs, params + aT.tw[5],
+                                        params + aT.tb[5], params + aF.tw[5], params + aF.tb[5], c.C, y1, y2, y3, c.rho, c.B * c.C,
+                                        c.P, ws + e->o_gx1p, ws + e->o_gx2, ws + e->o_gx3c, ws + e->o_recon_part, fst,
+                                        (float)(1.0 / world));
+  else
+    rc = multiplier_update_recon(x, fws + e->ae[0].out, fws + e->ae[1].out, fws + e->ae[2].out, y1, y2, y3, c.rho,
+                                 c.B * c.C, c.P, concurrent ? nullptr : reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,
+                                 ws + e->o_gx2, ws + e->o_gx3c, ws + e->o_recon_part, fst, (float)(1.0 / world), e->bf);
   if (rc) return rc;
   e->mark(lshm_engine::PH_RECON_END, fst);
   e->sum7_pending = concurrent;

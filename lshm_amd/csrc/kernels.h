@@ -354,6 +354,11 @@ int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const
 size_t recon_partials_floats(int planes, int P);
 // second stage of the reconstruction pass on its own (multiplier_update_recon with sums7 == nullptr leaves it to the caller)
 int recon_sum7(const float* block_partials, int planes, int P, double* sums7, hipStream_t st);
+bool recon_from_a_supported(int C, int P, int Cin, int Cout, int Ls);
+int multiplier_update_recon_from_a(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT,
+                                   const float* bT, const float* wF, const float* bF, int C, float* y1, float* y2, float* y3,
+                                   float rho, int planes, int P, float* gx1p, float* gx2, float* gx3c, float* block_partials,
+                                   hipStream_t st, float grad_scale);
 int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
                             float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
                             float* gx3c, float* block_partials, hipStream_t st, float grad_scale = 1.f, int bf = 0);
