@@ -127,19 +127,38 @@ __device__ __forceinline__ void up_stage(const float* __restrict__ xs, int xoff,
 // copy-out pass: rows of the LDS image (C x L, logical element p at img[c*P + p + off]) -> global (c-major rows of L),
 // with the optional ELU' multiply written back to the image for the next stage.  `zero_last`: the last logical
 // element has no source (pad-1 up stage) and is written as zero.
+// The ELU' inputs of a data-gradient stage are requested BEFORE the stage's matrix instructions (load_dact) and used in
+// its copy-out: their HBM round trip (~2 us, three times per sample) hides behind the stage instead of following it.
+template <int C, int L>
+struct DactRegs {
+  static constexpr int N = (C * L + kChainThreads - 1) / kChainThreads;
+  float v[N];
+};
+template <int C, int L>
+__device__ __forceinline__ void load_dact(DactRegs<C, L>& r, const float* __restrict__ dact) {
+  if (!dact) return;
+#pragma unroll
+  for (int k = 0; k < DactRegs<C, L>::N; ++k) {
+    const int i = threadIdx.x + k * kChainThreads;
+    r.v[k] = i < C * L ? dact[i] : 0.f;  // the same flat order as copy_out
+  }
+}
 template <int C, int L, int P>
 __device__ __forceinline__ void copy_out(float* __restrict__ img, int off, float* __restrict__ out, const float* __restrict__ dact,
-                                         bool zero_last) {
+                                         bool zero_last, const DactRegs<C, L>& r) {
   // one element per lane: consecutive lanes read consecutive LDS words (no bank conflicts; float4 rows of the
   // odd-pitched images were 4-way conflicts, 57-65 % of the LDS cycles of the first version) and store 256-byte runs
-#pragma unroll 4
-  for (int i = threadIdx.x; i < C * L; i += kChainThreads) {
-    const int c = i / L, q = i - c * L;
-    float* p = img + c * P + q + off;
-    float v = (zero_last && q == L - 1) ? 0.f : *p;
-    if (dact) v *= elu_grad_from_out(dact[(long)c * L + q]);
-    if (dact || (zero_last && q == L - 1)) *p = v;
-    out[(long)c * L + q] = v;
+#pragma unroll
+  for (int k = 0; k < DactRegs<C, L>::N; ++k) {
+    const int i = threadIdx.x + k * kChainThreads;
+    if (i < C * L) {
+      const int c = i / L, q = i - c * L;
+      float* p = img + c * P + q + off;
+      float v = (zero_last && q == L - 1) ? 0.f : *p;
+      if (dact) v *= elu_grad_from_out(r.v[k]);
+      if (dact || (zero_last && q == L - 1)) *p = v;
+      out[(long)c * L + q] = v;
+    }
   }
 }
 
@@ -172,22 +191,28 @@ __global__ __launch_bounds__(kChainThreads) void conv1d_chain_down_kernel(const 
     const int c = i / L0, q = i - c * L0;
     x0[c * P0 + q + 1] = in[(long)c * L0 + q];
   }
+  const float* da0 = a.st[0].dact[pr] ? a.st[0].dact[pr] + (long)b * a.st[0].out_bs : nullptr;
+  const float* da1 = a.st[1].dact[pr] ? a.st[1].dact[pr] + (long)b * a.st[1].out_bs : nullptr;
+  const float* da2 = a.st[2].dact[pr] ? a.st[2].dact[pr] + (long)b * a.st[2].out_bs : nullptr;
+  DactRegs<C1, L0 / 4> r1;
+  DactRegs<C2, L0 / 16> r2;
+  DactRegs<C3, L0 / 64> r3;
+  load_dact(r1, da0);
   __syncthreads();
   down_stage<C0, C1, L0, P0, P1>(x0, y1, a.st[0].w[pr], a.st[0].bias[pr], a.st[0].act, a.pad);
   __syncthreads();
-  copy_out<C1, L0 / 4, P1>(y1, 1, a.st[0].out[pr] + (long)b * a.st[0].out_bs,
-                           a.st[0].dact[pr] ? a.st[0].dact[pr] + (long)b * a.st[0].out_bs : nullptr, false);
+  load_dact(r2, da1);
+  copy_out<C1, L0 / 4, P1>(y1, 1, a.st[0].out[pr] + (long)b * a.st[0].out_bs, da0, false, r1);
   for (int c = t; c < C2; c += kChainThreads) y2[c * P2] = 0.f;  // (x0 is dead: the barrier above followed its last read)
   __syncthreads();
   down_stage<C1, C2, L0 / 4, P1, P2>(y1, y2, a.st[1].w[pr], a.st[1].bias[pr], a.st[1].act, a.pad);
   __syncthreads();
-  copy_out<C2, L0 / 16, P2>(y2, 1, a.st[1].out[pr] + (long)b * a.st[1].out_bs,
-                            a.st[1].dact[pr] ? a.st[1].dact[pr] + (long)b * a.st[1].out_bs : nullptr, false);
+  load_dact(r3, da2);
+  copy_out<C2, L0 / 16, P2>(y2, 1, a.st[1].out[pr] + (long)b * a.st[1].out_bs, da1, false, r2);
   __syncthreads();
   down_stage<C2, C3, L0 / 16, P2, P3>(y2, y3, a.st[2].w[pr], a.st[2].bias[pr], a.st[2].act, a.pad);
   __syncthreads();
-  copy_out<C3, L0 / 64, P3>(y3, 1, a.st[2].out[pr] + (long)b * a.st[2].out_bs,
-                            a.st[2].dact[pr] ? a.st[2].dact[pr] + (long)b * a.st[2].out_bs : nullptr, false);
+  copy_out<C3, L0 / 64, P3>(y3, 1, a.st[2].out[pr] + (long)b * a.st[2].out_bs, da2, false, r3);
 }
 
 // tconv1 -> tconv2 -> tconv3 geometry: C0 x L0 -> C1 x 4 L0 -> C2 x 16 L0 -> C3 x 64 L0
@@ -208,21 +233,27 @@ __global__ __launch_bounds__(kChainThreads) void conv1d_chain_up_kernel(const Ch
     const int c = i / (L0 / 4), c4 = i - c * (L0 / 4);
     *reinterpret_cast<f32x4*>(x0 + c * P0 + 4 * c4) = *reinterpret_cast<const f32x4*>(in + (long)c * L0 + 4 * c4);
   }
+  const float* da0 = a.st[0].dact[pr] ? a.st[0].dact[pr] + (long)b * a.st[0].out_bs : nullptr;
+  const float* da1 = a.st[1].dact[pr] ? a.st[1].dact[pr] + (long)b * a.st[1].out_bs : nullptr;
+  const float* da2 = a.st[2].dact[pr] ? a.st[2].dact[pr] + (long)b * a.st[2].out_bs : nullptr;
+  DactRegs<C1, 4 * L0> r1;
+  DactRegs<C2, 16 * L0> r2;
+  DactRegs<C3, 64 * L0> r3;
+  load_dact(r1, da0);
   __syncthreads();
   up_stage<C0, C1, L0, P0, P1>(x0, 0, y1, a.st[0].w[pr], a.st[0].bias[pr], a.st[0].act);
   __syncthreads();
-  copy_out<C1, 4 * L0, P1>(y1, pad, a.st[0].out[pr] + (long)b * a.st[0].out_bs,
-                           a.st[0].dact[pr] ? a.st[0].dact[pr] + (long)b * a.st[0].out_bs : nullptr, pad != 0);
+  load_dact(r2, da1);
+  copy_out<C1, 4 * L0, P1>(y1, pad, a.st[0].out[pr] + (long)b * a.st[0].out_bs, da0, pad != 0, r1);
   __syncthreads();
   up_stage<C1, C2, 4 * L0, P1, P2>(y1, pad, y2, a.st[1].w[pr], a.st[1].bias[pr], a.st[1].act);
   __syncthreads();
-  copy_out<C2, 16 * L0, P2>(y2, pad, a.st[1].out[pr] + (long)b * a.st[1].out_bs,
-                            a.st[1].dact[pr] ? a.st[1].dact[pr] + (long)b * a.st[1].out_bs : nullptr, pad != 0);
+  load_dact(r3, da2);
+  copy_out<C2, 16 * L0, P2>(y2, pad, a.st[1].out[pr] + (long)b * a.st[1].out_bs, da1, pad != 0, r2);
   __syncthreads();
   up_stage<C2, C3, 16 * L0, P2, P3>(y2, pad, y3, a.st[2].w[pr], a.st[2].bias[pr], a.st[2].act);
   __syncthreads();
-  copy_out<C3, 64 * L0, P3>(y3, pad, a.st[2].out[pr] + (long)b * a.st[2].out_bs,
-                            a.st[2].dact[pr] ? a.st[2].dact[pr] + (long)b * a.st[2].out_bs : nullptr, pad != 0);
+  copy_out<C3, 64 * L0, P3>(y3, pad, a.st[2].out[pr] + (long)b * a.st[2].out_bs, da2, pad != 0, r3);
 }
 
 static size_t lds_down(int c0, int c1, int c2, int c3, int l0) {
