@@ -308,13 +308,14 @@ __global__ __launch_bounds__(256) void recon_kernel(
     const long LA = (long)P * P / 4;
     const int h0 = blockIdx.y * TILE, w0 = blockIdx.x * TILE;
     {  // sT[cs][rr][k] = aT[cs][(h0 + rr) * P / 4 + w0 / 4 + k],  sF[cs][q][k] = aF[cs][(w0 + q) * P / 4 + h0 / 4 + k]
+      // (T = bf16: the layer's input is a bf16 tensor too, and its output would have been rounded to bf16 on its way here)
       const int tid = threadIdx.y * TILE + threadIdx.x, cs = tid >> 5, rr = tid & 31;
-      const float* pT = fa.aT + (long)b * fa.a_bs + cs * LA + (long)(h0 + rr) * (P / 4) + w0 / 4;
-      const float* pF = fa.aF + (long)b * fa.a_bs + cs * LA + (long)(w0 + rr) * (P / 4) + h0 / 4;
+      const T* pT = reinterpret_cast<const T*>(fa.aT) + (long)b * fa.a_bs + cs * LA + (long)(h0 + rr) * (P / 4) + w0 / 4;
+      const T* pF = reinterpret_cast<const T*>(fa.aF) + (long)b * fa.a_bs + cs * LA + (long)(w0 + rr) * (P / 4) + h0 / 4;
       f32x4* dT = reinterpret_cast<f32x4*>(&stage[(cs * TILE + rr) * 8]);
       f32x4* dF = reinterpret_cast<f32x4*>(&stage[8 * TILE * 8 + (cs * TILE + rr) * 8]);
-      dT[0] = *reinterpret_cast<const f32x4*>(pT); dT[1] = *reinterpret_cast<const f32x4*>(pT + 4);
-      dF[0] = *reinterpret_cast<const f32x4*>(pF); dF[1] = *reinterpret_cast<const f32x4*>(pF + 4);
+      dT[0] = Elem<T>::ld4(pT); dT[1] = Elem<T>::ld4(pT + 4);
+      dF[0] = Elem<T>::ld4(pF); dF[1] = Elem<T>::ld4(pF + 4);
     }
 #pragma unroll
     for (int cs = 0; cs < 8; ++cs) {
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(256) void recon_kernel(
       float v = bfv;
 #pragma unroll
       for (int cs = 0; cs < 8; ++cs) v = fmaf(sF[(cs * TILE + threadIdx.y + 8 * i) * 8 + (threadIdx.x >> 2)], wf[cs], v);
+      if constexpr (sizeof(T) == 2) v = (float)(T)v;
       tile[threadIdx.y + 8 * i][threadIdx.x] = v;
     }
   } else {
@@ -349,6 +351,7 @@ __global__ __launch_bounds__(256) void recon_kernel(
       a2 = bt;
 #pragma unroll
       for (int cs = 0; cs < 8; ++cs) a2 = fmaf(stage[(cs * TILE + threadIdx.y + 8 * i) * 8 + (threadIdx.x >> 2)], wt[cs], a2);
+      if constexpr (sizeof(T) == 2) a2 = (float)(T)a2;
     } else {
       a2 = Elem<T>::ld(x2 + o);
     }
@@ -463,7 +466,7 @@ bool recon_from_a_supported(int C, int P, int Cin, int Cout, int Ls) {
 int multiplier_update_recon_from_a(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT,
                                    const float* bT, const float* wF, const float* bF, int C, float* y1, float* y2, float* y3,
                                    float rho, int planes, int P, float* gx1p, float* gx2, float* gx3c, float* block_partials,
-                                   hipStream_t st, float grad_scale) {
+                                   hipStream_t st, float grad_scale, int bf) {
   if (P % TILE || planes % C) { set_last_error("recon_losses: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
   if (!x || !x1 || !aT || !aF || !wT || !bT || !wF || !bF || !gx1p || !gx2 || !gx3c || !block_partials) {
     set_last_error("recon_losses: null pointer");
@@ -471,9 +474,15 @@ int multiplier_update_recon_from_a(const float* x, const float* x1, const float*
   }
   const double n = (double)planes * P * P;
   const ReconFromA fa{aT, aF, wT, bT, wF, bF, a_bs, C};
-  hipLaunchKernelGGL((recon_kernel<true, true, float, true>), dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st, x, x1,
-                     (const float*)nullptr, (const float*)nullptr, y1, y2, y3, rho, (float)(grad_scale / n), P,
-                     reinterpret_cast<double*>(block_partials), gx1p, gx2, gx3c, fa);
+  if (bf)  // x1, the two activation tensors and the three gradient images are bf16 tensors
+    hipLaunchKernelGGL((recon_kernel<true, true, bf16, true>), dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st, x,
+                       reinterpret_cast<const bf16*>(x1), (const bf16*)nullptr, (const bf16*)nullptr, y1, y2, y3, rho,
+                       (float)(grad_scale / n), P, reinterpret_cast<double*>(block_partials), reinterpret_cast<bf16*>(gx1p),
+                       reinterpret_cast<bf16*>(gx2), reinterpret_cast<bf16*>(gx3c), fa);
+  else
+    hipLaunchKernelGGL((recon_kernel<true, true, float, true>), dim3(P / TILE, P / TILE, planes), dim3(TILE, 8), 0, st, x, x1,
+                       (const float*)nullptr, (const float*)nullptr, y1, y2, y3, rho, (float)(grad_scale / n), P,
+                       reinterpret_cast<double*>(block_partials), gx1p, gx2, gx3c, fa);
   return check_launch("recon_losses");
 }
 // y_k += rho r_k, then the reconstruction terms of the next closure with the updated multipliers

@@ -409,11 +409,13 @@ static void three_forward_steps(const lshm_engine* e, const float* prm, const fl
     const AEPlan& aT = e->ae[1];
     const AEPlan& aF = e->ae[2];
     *resid_conv0_step = nullptr;
-    if (!e->bf && e->pair_mode && resid_conv0_supported(c.C, c.P, aT.enc[0].Cin, aT.enc[0].Cout, aT.enc[0].Win) &&
+    // (bf16 storage: the reconstruction, the residual and conv0's outputs are bf16 tensors in both forms)
+    const bool bf_ok = !e->bf || (aT.enc[0].in_bf16 && aT.enc[0].out_bf16 && aF.enc[0].in_bf16 && aF.enc[0].out_bf16);
+    if (bf_ok && e->pair_mode && resid_conv0_supported(c.C, c.P, aT.enc[0].Cin, aT.enc[0].Cout, aT.enc[0].Win) &&
         aT.enc[0].out_bs == aF.enc[0].out_bs)
       *resid_conv0_step = [=](float* ws, hipStream_t st) -> int {
         return resid_conv0(x, ws + e->ae[0].out, prm + aT.cw[0], prm + aT.cb[0], ws + aT.act[0], prm + aF.cw[0], prm + aF.cb[0],
-                           ws + aF.act[0], aT.enc[0].out_bs, c.B, st);
+                           ws + aF.act[0], aT.enc[0].out_bs, c.B, st, e->bf);
       };
   }
   steps.push_back([=](float* ws, hipStream_t st) -> int {
@@ -1475,7 +1477,8 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
   // reconstructions from that layer's input (recon_kernel<.., FROMA>): one launch, 0.13 GB of writes and 0.2 GB of reads less
   const AEPlan& aT = e->ae[1];
   const AEPlan& aF = e->ae[2];
-  const bool from_a = concurrent && !e->bf && aT.dec[5].in_bs == aF.dec[5].in_bs &&
+  const bool bf_ok = !e->bf || (aT.dec[5].in_bf16 && aT.dec[5].out_bf16 && aF.dec[5].in_bf16 && aF.dec[5].out_bf16);
+  const bool from_a = concurrent && bf_ok && aT.dec[5].in_bs == aF.dec[5].in_bs &&
                       recon_from_a_supported(c.C, c.P, aT.dec[5].Cin, aT.dec[5].Cout, aT.dec[5].Win);
   int rc = concurrent ? two_forwards(e, params, x, uv, fws, fst, ws, st, true, from_a) : three_forward(e, params, x, uv, fws, fst);
   if (rc) return rc;
@@ -1487,7 +1490,7 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
     rc = multiplier_update_recon_from_a(x, fws + e->ae[0].out, fws + aT.dact[4], fws + aF.dact[4], aT.dec[5].in_bs, params + aT.tw[5],
                                         params + aT.tb[5], params + aF.tw[5], params + aF.tb[5], c.C, y1, y2, y3, c.rho, c.B * c.C,
                                         c.P, ws + e->o_gx1p, ws + e->o_gx2, ws + e->o_gx3c, ws + e->o_recon_part, fst,
-                                        (float)(1.0 / world));
+                                        (float)(1.0 / world), e->bf);
   else
     rc = multiplier_update_recon(x, fws + e->ae[0].out, fws + e->ae[1].out, fws + e->ae[2].out, y1, y2, y3, c.rho,
                                  c.B * c.C, c.P, concurrent ? nullptr : reinterpret_cast<double*>(ws + e->o_scal), ws + e->o_gx1p,

@@ -202,7 +202,7 @@ int conv2d_bwd_lds(const float* small, long s_bs, const float* big, long big_bs,
 // conv0 of netT and netF from x and the 2-D reconstruction in one launch, no materialised residual (resid_conv0.hip)
 bool resid_conv0_supported(int C, int P, int Cin, int Cout, int L1d);
 int resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,
-                float* yF, long y_bs, int B, hipStream_t st);
+                float* yF, long y_bs, int B, hipStream_t st, int bf = 0);  // bf: x1 and the outputs are bf16 tensors
 
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
@@ -358,7 +358,7 @@ bool recon_from_a_supported(int C, int P, int Cin, int Cout, int Ls);
 int multiplier_update_recon_from_a(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT,
                                    const float* bT, const float* wF, const float* bF, int C, float* y1, float* y2, float* y3,
                                    float rho, int planes, int P, float* gx1p, float* gx2, float* gx3c, float* block_partials,
-                                   hipStream_t st, float grad_scale);
+                                   hipStream_t st, float grad_scale, int bf = 0);
 int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
                             float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
                             float* gx3c, float* block_partials, hipStream_t st, float grad_scale = 1.f, int bf = 0);

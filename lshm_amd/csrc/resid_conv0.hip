@@ -35,8 +35,9 @@ struct ResidConv0Args {
 };
 
 // one output position: taps 0..3 at sequence positions 4j-1 .. 4j+2; xm[ci] = the element before the quad (0 at j == 0)
+template <class T>
 __device__ __forceinline__ void conv0_point(const float (&xm)[CI], const float (&v)[CI][3], const float* __restrict__ w,
-                                            const float* __restrict__ bias, float* __restrict__ y) {
+                                            const float* __restrict__ bias, T* __restrict__ y) {
 #pragma unroll
   for (int co = 0; co < CO; ++co) {
     float acc = uload(bias + co);
@@ -48,11 +49,21 @@ __device__ __forceinline__ void conv0_point(const float (&xm)[CI], const float (
       acc = fmaf(v[ci][1], w4[2], acc);
       acc = fmaf(v[ci][2], w4[3], acc);
     }
-    y[(long)co * LO] = elu(acc);
+    Elem<T>::st(y + (long)co * LO, elu(acc));
   }
 }
 
+// T: element type of x1 and of the outputs (bf16 storage): the residual is then rounded to bf16 as
+// residual_split_kernel<bf16> stores it, before it enters the products
+template <class T>
+__device__ __forceinline__ float resid(float xa, float xb) {
+  const float v = (xa - xb) * 0.5f;
+  if constexpr (sizeof(T) == 2) return (float)(T)v;
+  return v;
+}
+template <class T>
 __global__ __launch_bounds__(256) void resid_conv0_kernel(const ResidConv0Args a) {
+  const T* __restrict__ x1 = reinterpret_cast<const T*>(a.x1);
   __shared__ float res[CI * P * PITCH];  // netF: the residual of a 128 x 32 tile of all four channels
   __shared__ float prev[CI];             // ... and the last element of the column before the tile
   const int t = threadIdx.x;
@@ -66,31 +77,31 @@ __global__ __launch_bounds__(256) void resid_conv0_kernel(const ResidConv0Args a
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci) {
       const f32x4 xa = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.x + base + (long)ci * L));
-      const f32x4 xb = *reinterpret_cast<const f32x4*>(a.x1 + base + (long)ci * L);
+      const f32x4 xb = Elem<T>::ld4(x1 + base + (long)ci * L);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) v[ci][k] = (xa[k] - xb[k]) * 0.5f;
-      xm[ci] = j > 0 ? (a.x[base + (long)ci * L - 1] - a.x1[base + (long)ci * L - 1]) * 0.5f : 0.f;
+      for (int k = 0; k < 3; ++k) v[ci][k] = resid<T>(xa[k], xb[k]);
+      xm[ci] = j > 0 ? resid<T>(a.x[base + (long)ci * L - 1], Elem<T>::ld(x1 + base + (long)ci * L - 1)) : 0.f;
     }
-    conv0_point(xm, v, a.w[0], a.bias[0], a.y[0] + (long)b * a.y_bs + j);
+    conv0_point(xm, v, a.w[0], a.bias[0], reinterpret_cast<T*>(a.y[0]) + (long)b * a.y_bs + j);
     return;
   }
   // ---- netF: sequence position s = 128 c + r (column c, row r); output j = 32 c + g reads rows 4g-1 .. 4g+2 of column c
   // (row -1 = the last row of column c - 1; nothing before j == 0)
   const int b = blockIdx.x / (P / TC), c0 = (blockIdx.x - b * (P / TC)) * TC;
   const float* xb = a.x + (long)b * CI * L;
-  const float* x1b = a.x1 + (long)b * CI * L;
+  const T* x1b = x1 + (long)b * CI * L;
   for (int i = t; i < CI * P * (TC / 4); i += 256) {
     const int c4 = i % (TC / 4), rr = i / (TC / 4);  // rr = ci * 128 + r
     const long g = (long)rr * P + c0 + 4 * c4;
     const f32x4 xa = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xb + g));
-    const f32x4 xc = *reinterpret_cast<const f32x4*>(x1b + g);
+    const f32x4 xc = Elem<T>::ld4(x1b + g);
     float* d = &res[rr * PITCH + 4 * c4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = (xa[k] - xc[k]) * 0.5f;
+    for (int k = 0; k < 4; ++k) d[k] = resid<T>(xa[k], xc[k]);
   }
   if (t < CI) {
     const long g = ((long)t * P + (P - 1)) * P + c0 - 1;
-    prev[t] = c0 > 0 ? (xb[g] - x1b[g]) * 0.5f : 0.f;
+    prev[t] = c0 > 0 ? resid<T>(xb[g], Elem<T>::ld(x1b + g)) : 0.f;
   }
   __syncthreads();
   const int g = t & 31, cg = t >> 5;  // 32 row groups x 8 column phases; a thread walks columns cg, cg + 8, ...
@@ -104,7 +115,7 @@ __global__ __launch_bounds__(256) void resid_conv0_kernel(const ResidConv0Args a
       v[ci][0] = col[0]; v[ci][1] = col[PITCH]; v[ci][2] = col[2 * PITCH];
       xm[ci] = g > 0 ? col[-PITCH] : (c > 0 ? res[(ci * P + P - 1) * PITCH + c - 1] : prev[ci]);
     }
-    conv0_point(xm, v, a.w[1], a.bias[1], a.y[1] + (long)b * a.y_bs + (long)(c0 + c) * (P / 4) + g);
+    conv0_point(xm, v, a.w[1], a.bias[1], reinterpret_cast<T*>(a.y[1]) + (long)b * a.y_bs + (long)(c0 + c) * (P / 4) + g);
   }
 }
 
@@ -113,7 +124,7 @@ bool resid_conv0_supported(int C, int Pp, int Cin, int Cout, int L1d) {
 }
 
 int resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,
-                float* yF, long y_bs, int B, hipStream_t st) {
+                float* yF, long y_bs, int B, hipStream_t st, int bf) {
   if (!x || !x1 || !wT || !bT || !yT || !wF || !bF || !yF || B < 1 || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x1) |
       reinterpret_cast<uintptr_t>(wT) | reinterpret_cast<uintptr_t>(wF)) & 15)) {
     set_last_error("resid_conv0: null or unaligned pointer");
@@ -126,9 +137,11 @@ int resid_conv0(const float* x, const float* x1, const float* wT, const float* b
   a.y_bs = y_bs; a.B = B;
   a.nF = B * (P / TC);
   const long nT = ((long)B * LO + 255) / 256;
-  int rc = kernel_budget_ok(reinterpret_cast<const void*>(&resid_conv0_kernel), 256, 0, "resid_conv0");
+  int rc = kernel_budget_ok(bf ? reinterpret_cast<const void*>(&resid_conv0_kernel<bf16>) : reinterpret_cast<const void*>(&resid_conv0_kernel<float>),
+                            256, 0, "resid_conv0");
   if (rc) return rc;
-  hipLaunchKernelGGL(resid_conv0_kernel, dim3((unsigned)(a.nF + nT)), dim3(256), 0, st, a);
+  if (bf) hipLaunchKernelGGL(resid_conv0_kernel<bf16>, dim3((unsigned)(a.nF + nT)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(resid_conv0_kernel<float>, dim3((unsigned)(a.nF + nT)), dim3(256), 0, st, a);
   return check_launch("resid_conv0");
 }
 

@@ -776,8 +776,9 @@ def test_bf16_storage_step_vs_fp32_oracle():
     assert t["nonfinite"] == 0.0
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
 @pytest.mark.parametrize("batch", [4, 256])
-def test_overlapped_forwards_are_bitwise_the_same_trajectory(batch):
+def test_overlapped_forwards_are_bitwise_the_same_trajectory(batch, storage):
     """TrainConfig.overlap_forwards (default): the no-grad forward that closes iteration k and the closure forward
     that opens iteration k+1 run side by side on two streams with separate activation buffers
     (LSHM_NEXT_CONCURRENT_FORWARD).  Parameters, multipliers, Adam moments and logged terms must be bit for bit
@@ -785,8 +786,9 @@ def test_overlapped_forwards_are_bitwise_the_same_trajectory(batch):
     from lshm_amd import KHarmonicTrainer, TrainConfig, _lib
     out = []
     for overlap in (False, True):
-        tr = KHarmonicTrainer(TrainConfig(Kc=5, overlap_forwards=overlap), batch=batch, batch_per_bline=2,
-                              default_batch=batch // 2, device=DEV)
+        cfg = TrainConfig(Kc=5, overlap_forwards=overlap) if storage == "fp32" else TrainConfig(
+            Kc=5, overlap_forwards=overlap, matrix_precision="bf16", activation_storage="bf16")
+        tr = KHarmonicTrainer(cfg, batch=batch, batch_per_bline=2, default_batch=batch // 2, device=DEV)
         tr.init_parameters(seed=3)
         x, uv = O.closed_form_inputs(4, 4)
         x, uv = x.repeat(batch // 4, 1, 1, 1) * torch.linspace(0.5, 1.5, batch).view(-1, 1, 1, 1), uv.repeat(batch // 4, 1)
