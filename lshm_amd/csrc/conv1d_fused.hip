@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_bwd_fused2_kernel(const FusedBw
 bool conv1d_bwd_lds_supported(int Cs, int Cb, int Ls, int pad);
 int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs, float* ws,
                    float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks, hipStream_t st, int* grid_out,
-                   const FusedDgrad& fd, int big_bf16);
+                   const FusedDgrad& fd, int big_bf16, int small_bf16);
 bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
   // 12 / 8 channels: 96 accumulator registers + the data-gradient working set do not fit two wavefronts per SIMD
   // (the compiler spills 80-330 registers; 67-129 us against 50 us for the two separate kernels, profiles/r03):
@@ -283,9 +283,14 @@ bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
 int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs,
                       float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks,
                       hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd, int small_bf16) {
-  if (((Cs == 12 && !small_bf16 && (big_bf16 || !getenv("LSHM_FUSED2_12_8"))) || (Cs == 8 && !small_bf16 && !big_bf16)) &&
+  // (8 / 4 channels with bf16 storage stay on the register form below: the LDS form is 0.05 ms per iteration SLOWER there --
+  //  half the bytes, the same matrix and LDS work -- while it is 0.03 ms faster in fp32; LSHM_BWD_LDS_8_4_BF16=1 for A/B)
+  static const bool lds84_bf16 = getenv("LSHM_BWD_LDS_8_4_BF16") != nullptr;
+  if (((Cs == 12 && !small_bf16 && (big_bf16 || !getenv("LSHM_FUSED2_12_8"))) ||
+       (Cs == 8 && small_bf16 == big_bf16 && (!big_bf16 || lds84_bf16))) &&
       conv1d_bwd_lds_supported(Cs, Cb, Ls, pad))
-    return conv1d_bwd_lds(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, max_blocks, st, grid_out, fd, big_bf16);
+    return conv1d_bwd_lds(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, max_blocks, st, grid_out, fd, big_bf16,
+                          small_bf16);
   const bool two = small2 != nullptr;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!conv1d_bwd_fused2_supported(Cs, Cb, pad) || Ls % 64 || Lb != 4 * Ls || s_bs % 4 || big_bs % 4 || fd.dx_bs % 4 ||
@@ -356,7 +361,7 @@ struct BwdLds1dArgs {
 };
 
 // TB: element type of the big tensor and (conv layer) of its gradient -- fp32, or bf16 storage
-template <int CS, int CB, int TP, bool CONV, bool DACT, typename TB>
+template <int CS, int CB, int TP, bool CONV, bool DACT, typename TB, typename TS = float>  // TS: element type of the small tensor (and of its gradient)
 __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs a) {
   static_assert(CS <= 16 && CS % 4 == 0 && CB % 4 == 0 && TP % 64 == 0, "one 16-row tile of small channels");
   constexpr int NT = CB / 4, NW = CS * CB * 4, SLAB = NW + 16;
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs 
   float* bimg = smem + 16 * LDS_S;
   float* obuf = bimg + CB * BP;  // CONV: data-gradient image, logical element i of the tile at obuf[cb][1 + i]
   const int pr = blockIdx.y;
-  const float* __restrict__ small = a.small[pr];
+  const TS* __restrict__ small = reinterpret_cast<const TS*>(a.small[pr]);
   const TB* __restrict__ big = reinterpret_cast<const TB*>(a.big[pr]);
   const float* __restrict__ w = a.w[pr];
   float* __restrict__ dout = a.dout[pr];
@@ -403,13 +408,13 @@ __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs 
   float rh = 0.f, rx = 0.f;
   auto fetch = [&](int tile) {
     const int b = tile / tiles_per, j0 = (tile - b * tiles_per) * TP;
-    const float* sb = small + (long)b * a.s_bs + j0;
+    const TS* sb = small + (long)b * a.s_bs + j0;
     const TB* bb = big + (long)b * a.big_bs + 4L * j0;
 #pragma unroll
     for (int q = 0; q < NQS; ++q) {
       const int i = t + 256 * q;
       rs[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (i < CS * (TP / 4)) rs[q] = *reinterpret_cast<const f32x4*>(sb + (long)(i / (TP / 4)) * Ls + 4 * (i % (TP / 4)));
+      if (i < CS * (TP / 4)) rs[q] = Elem<TS>::ld4(sb + (long)(i / (TP / 4)) * Ls + 4 * (i % (TP / 4)));
     }
 #pragma unroll
     for (int q = 0; q < NQB; ++q) {
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs 
       if (i < CB * TP) rb[q] = Elem<TB>::ld4(bb + (long)(i / TP) * Lb + 4 * (i % TP));
     }
     rh = (t < CB && pad && j0 > 0) ? Elem<TB>::ld(bb + (long)t * Lb - 1) : 0.f;                      // the element before the segment
-    if constexpr (CONV) rx = (t >= 64 && t < 64 + CS && j0 + TP < Ls) ? sb[(long)(t - 64) * Ls + TP] : 0.f;  // the position after the tile
+    if constexpr (CONV) rx = (t >= 64 && t < 64 + CS && j0 + TP < Ls) ? Elem<TS>::ld(sb + (long)(t - 64) * Ls + TP) : 0.f;  // the position after the tile
   };
   if ((int)blockIdx.x < a.ntiles) fetch(blockIdx.x);
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -458,7 +463,7 @@ __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs 
     }
     // ---- data gradient: 16-position row tiles, every 4th per wavefront
     if constexpr (!CONV) {
-      float* dsm = dout + (long)b * a.d_bs + j0;
+      TS* dsm = reinterpret_cast<TS*>(dout) + (long)b * a.d_bs + j0;
       for (int mt = wave; mt < TP / 16; mt += 4) {
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -469,7 +474,7 @@ __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs 
 #pragma unroll
             for (int r = 0; r < 4; ++r) d[r] *= elu_grad_from_out(stile[lm * LDS_S + p + r]);
           }
-          *reinterpret_cast<f32x4*>(dsm + (long)lm * Ls + p) = d;
+          Elem<TS>::st4(dsm + (long)lm * Ls + p, d);
         }
       }
     } else {
@@ -561,7 +566,7 @@ bool conv1d_bwd_lds_supported(int Cs, int Cb, int Ls, int pad) {
 
 int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs, float* ws,
                    float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks, hipStream_t st, int* grid_out,
-                   const FusedDgrad& fd, int big_bf16) {
+                   const FusedDgrad& fd, int big_bf16, int small_bf16) {
   const bool two = small2 != nullptr;
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!conv1d_bwd_lds_supported(Cs, Cb, Ls, pad) || Lb != 4 * Ls || s_bs % 4 || big_bs % 4 || fd.dx_bs % 4 || !fd.w || !fd.dx ||
@@ -589,9 +594,18 @@ int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const flo
   const bool dact = fd.dact != 0;
 #define LSHM_BLDS(CONV_, DACT_, TB_) hipLaunchKernelGGL((conv1d_bwd_lds_kernel<12, 8, 128, CONV_, DACT_, TB_>), g, dim3(256), 0, st, a)
   if (Cs == 8) {
-    if (big_bf16) { set_last_error("conv1d_bwd_lds: the 8 / 4 channel form is fp32 only"); return LSHM_ERR_UNSUPPORTED; }
-    if (dact) hipLaunchKernelGGL((conv1d_bwd_lds_kernel<8, 4, 256, true, true, float>), g, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv1d_bwd_lds_kernel<8, 4, 256, true, false, float>), g, dim3(256), 0, st, a);
+    // bf16 storage: the layer's input (big, and its gradient) and its output gradient (small) are both bf16 tensors, or neither
+    if (big_bf16 != small_bf16) { set_last_error("conv1d_bwd_lds: 8 / 4 channels: both tensors bf16 or both fp32"); return LSHM_ERR_UNSUPPORTED; }
+    if (big_bf16) {
+      if (dact) hipLaunchKernelGGL((conv1d_bwd_lds_kernel<8, 4, 256, true, true, bf16, bf16>), g, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv1d_bwd_lds_kernel<8, 4, 256, true, false, bf16, bf16>), g, dim3(256), 0, st, a);
+    } else {
+      if (dact) hipLaunchKernelGGL((conv1d_bwd_lds_kernel<8, 4, 256, true, true, float>), g, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((conv1d_bwd_lds_kernel<8, 4, 256, true, false, float>), g, dim3(256), 0, st, a);
+    }
+  } else if (small_bf16) {
+    set_last_error("conv1d_bwd_lds: 12 / 8 channels: the small tensor is fp32");
+    return LSHM_ERR_UNSUPPORTED;
   } else if (big_bf16) {
     if (pad == 0) { if (dact) LSHM_BLDS(false, true, bf16); else LSHM_BLDS(false, false, bf16); }
     else { if (dact) LSHM_BLDS(true, true, bf16); else LSHM_BLDS(true, false, bf16); }

@@ -43,7 +43,8 @@ struct Bwd2dArgs {
   int Hs, Ws, ntiles;
 };
 
-template <bool CONV, bool DACT>
+// TB: element type of the big tensor and, for the conv layer, of its gradient (bf16 storage: DESIGN 4.6)
+template <bool CONV, bool DACT, class TB = float>
 __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs a) {
   constexpr int SM_FLOATS = CONV ? 16 * SPH * SPW : 16 * LDS_S;  // 16 rows: the MFMA row tile of the weight gradient; rows >= CS stay zero
   constexpr int OT_FLOATS = CONV ? CB * 2 * TH * OW : 0;
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
   float* patch = smem + SM_FLOATS;       // big patch [cb][PH][PW]
   float* otile = patch + CB * PH * PW;   // CONV: data-gradient tile [cb][2 TH][2 TW]
   const float* __restrict__ small = a.small;
-  const float* __restrict__ big = a.big;
+  const TB* __restrict__ big = reinterpret_cast<const TB*>(a.big);
   const float* __restrict__ w = a.w;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lm = lane & 15, lk = lane >> 4;
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
     const int tr_ = tile - b * (tiles_x * tiles_y);
     const int m0 = (tr_ / tiles_x) * TH, n0 = (tr_ % tiles_x) * TW;
     const float* sb = small + (long)b * a.s_bs;
-    const float* bb = big + (long)b * a.big_bs;
+    const TB* bb = big + (long)b * a.big_bs;
 #pragma unroll
     for (int q = 0; q < NQS; ++q) {
       const int i = t + 256 * q;
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
         const int c4 = i % (2 * TW / 4), rr = i / (2 * TW / 4);
         const int prow = rr % PH, cb = rr / PH;
         const int iy = 2 * m0 - 1 + prow;
-        if ((unsigned)iy < (unsigned)Hb) rb[q] = *reinterpret_cast<const f32x4*>(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
+        if ((unsigned)iy < (unsigned)Hb) rb[q] = Elem<TB>::ld4(bb + ((long)cb * Hb + iy) * Wb + 2 * n0 + 4 * c4);
       }
     }
 #pragma unroll
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
         const int side = i & 1, rr = i >> 1;
         const int prow = rr % PH, cb = rr / PH;
         const int iy = 2 * m0 - 1 + prow, ix = side ? 2 * n0 + 2 * TW : 2 * n0 - 1;
-        if ((unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb) rhb[q] = bb[((long)cb * Hb + iy) * Wb + ix];
+        if ((unsigned)iy < (unsigned)Hb && (unsigned)ix < (unsigned)Wb) rhb[q] = Elem<TB>::ld(bb + ((long)cb * Hb + iy) * Wb + ix);
       }
     }
   };
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
         }
       }
       __syncthreads();
-      float* ob = a.dout + (long)b * a.d_bs;
+      TB* ob = reinterpret_cast<TB*>(a.dout) + (long)b * a.d_bs;
       for (int i = t; i < CB * 2 * TH * OW / 4; i += 256) {
         const int e = 4 * i;
         const int co = e / (2 * TH * OW), r = e - co * (2 * TH * OW);
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
 #pragma unroll
           for (int q = 0; q < 4; ++q) v[q] *= elu_grad_from_out(xv[q]);
         }
-        *reinterpret_cast<f32x4*>(ob + ((long)co * Hb + 2 * m0 + oy) * Wb + 2 * n0 + ox) = v;
+        Elem<TB>::st4(ob + ((long)co * Hb + 2 * m0 + oy) * Wb + 2 * n0 + ox, v);
       }
     }
   }
@@ -344,7 +345,7 @@ bool conv2d_bwd_lds_supported(int Cs, int Cb, int Hs, int Ws) {
 // dout = dsmall).  dact != 0: dout is multiplied by ELU' of the saved tensor of its own shape.
 int conv2d_bwd_lds(const float* small, long s_bs, const float* big, long big_bs, const float* w, float* dout, int conv, int dact,
                    float* dw, float* db, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
-                   hipStream_t st, GradJobs* defer) {
+                   hipStream_t st, GradJobs* defer, int big_bf16) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!conv2d_bwd_lds_supported(Cs, Cb, Hs, Ws) || !small || !big || !w || !dout || !dw || s_bs % 4 || big_bs % 4 || !al16(small) ||
       !al16(big) || !al16(dout)) {
@@ -360,11 +361,16 @@ int conv2d_bwd_lds(const float* small, long s_bs, const float* big, long big_bs,
   static const int cap = [] { const char* v = getenv("LSHM_GRID_BWD_LDS2D"); return v && atoi(v) > 0 && atoi(v) <= 1024 ? atoi(v) : 512; }();
   const int grid = a.ntiles < cap ? a.ntiles : cap;
   int rc;
-#define LSHM_B2D(CONV_, DACT_) do { \
-    if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(&conv2d_bwd_lds_kernel<CONV_, DACT_>), 256, 0, "conv2d_bwd_lds"))) return rc; \
-    hipLaunchKernelGGL((conv2d_bwd_lds_kernel<CONV_, DACT_>), dim3(grid), dim3(256), 0, st, a); } while (0)
-  if (conv) { if (dact) LSHM_B2D(true, true); else LSHM_B2D(true, false); }
-  else { if (dact) LSHM_B2D(false, true); else LSHM_B2D(false, false); }
+#define LSHM_B2D(CONV_, DACT_, TB_) do { \
+    if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(&conv2d_bwd_lds_kernel<CONV_, DACT_, TB_>), 256, 0, "conv2d_bwd_lds"))) return rc; \
+    hipLaunchKernelGGL((conv2d_bwd_lds_kernel<CONV_, DACT_, TB_>), dim3(grid), dim3(256), 0, st, a); } while (0)
+  if (big_bf16) {
+    if (conv) { if (dact) LSHM_B2D(true, true, bf16); else LSHM_B2D(true, false, bf16); }
+    else { if (dact) LSHM_B2D(false, true, bf16); else LSHM_B2D(false, false, bf16); }
+  } else {
+    if (conv) { if (dact) LSHM_B2D(true, true, float); else LSHM_B2D(true, false, float); }
+    else { if (dact) LSHM_B2D(false, true, float); else LSHM_B2D(false, false, float); }
+  }
 #undef LSHM_B2D
   if ((rc = check_launch("conv2d_bwd_lds"))) return rc;
   const int nbias = conv ? Cs : Cb;

@@ -197,7 +197,7 @@ int tconv2d_bwd_fused(const float* small, long s_bs, const float* big, long big_
 bool conv2d_bwd_lds_supported(int Cs, int Cb, int Hs, int Ws);
 int conv2d_bwd_lds(const float* small, long s_bs, const float* big, long big_bs, const float* w, float* dout, int conv, int dact,
                    float* dw, float* db, int B, int Cs, int Cb, int Hs, int Ws, float* ws, size_t wsf, int accumulate,
-                   hipStream_t st, GradJobs* defer = nullptr);
+                   hipStream_t st, GradJobs* defer = nullptr, int big_bf16 = 0);
 
 // conv0 of netT and netF from x and the 2-D reconstruction in one launch, no materialised residual (resid_conv0.hip)
 bool resid_conv0_supported(int C, int P, int Cin, int Cout, int L1d);

@@ -237,11 +237,11 @@ bool conv_layer_bwd_fusable(const ConvLayer& L, const ConvWgradIO& io, const Con
   if (L.kind == 0) {  // 2-D conv: conv1 (8 -> 12 channels), fp32 storage
     int Ho2, Wo2;
     conv_out_dims(L, Ho2, Wo2);
-    return !L.in_bf16 && !L.out_bf16 && L.out_bs % 4 == 0 && conv2d_bwd_lds_supported(L.Cout, L.Cin, Ho2, Wo2);
+    return !L.out_bf16 && L.out_bs % 4 == 0 && conv2d_bwd_lds_supported(L.Cout, L.Cin, Ho2, Wo2);  // (its input may be bf16)
   }
   if (L.kind == 1)  // 2-D transposed: the outermost decoder layer (8 -> 4 channels) and, fp32 storage, tconv4 (12 -> 8)
     return (!getenv("LSHM_BWD_FUSED2D_OFF") && tconv2d_bwd_fused_supported(L.Cin, L.Cout, L.Hin, L.Win)) ||
-           (!L.in_bf16 && !L.out_bf16 && L.out_bs % 4 == 0 && conv2d_bwd_lds_supported(L.Cin, L.Cout, L.Hin, L.Win));
+           (!L.in_bf16 && L.out_bs % 4 == 0 && conv2d_bwd_lds_supported(L.Cin, L.Cout, L.Hin, L.Win));  // (its output may be bf16)
   if (L.kind == 3)  // transposed: small = the layer's input, big = dz
     return conv1d_bwd_fused_supported(L.Cin, L.Cout, 0) && (dio.dact_in || conv1d_bwd_fused2_supported(L.Cin, L.Cout, 0)) &&
            conv1d_wgrad_direct_supported(L.Cin, L.Cout, L.Win);
@@ -283,10 +283,10 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
   if (L.kind < 2) {
     const int Hs = tr ? L.Hin : Ho, Ws = tr ? L.Win : Wo;
     if (fuse) {
-      if (!io2 && !big_bf16 && !small_bf16 && conv2d_bwd_lds_supported(Cs, Cb, Hs, Ws) &&
+      if (!io2 && !small_bf16 && conv2d_bwd_lds_supported(Cs, Cb, Hs, Ws) &&
           gemm_wsf >= conv2d_wgrad_direct_workspace_floats(Cs, Cb))  // the 12 <-> 8 channel layers (conv2d_fused.hip)
         return conv2d_bwd_lds(small_of(io), s_bs, big_of(io), big_bs, fuse->w, fuse->dx, tr ? 0 : 1, fuse->dact_in ? 1 : 0, io.dw, io.db,
-                              L.B, Cs, Cb, Hs, Ws, gemm_ws, gemm_wsf, accumulate, st, defer);
+                              L.B, Cs, Cb, Hs, Ws, gemm_ws, gemm_wsf, accumulate, st, defer, big_bf16);
       if (!tr || io2 || !tconv2d_bwd_fused_supported(Cs, Cb, Hs, Ws) || gemm_wsf < conv2d_wgrad_direct_workspace_floats(Cs, Cb)) {
         set_last_error("conv wgrad: fused data gradient not available for this layer");
         return LSHM_ERR_UNSUPPORTED;
