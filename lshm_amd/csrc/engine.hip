@@ -490,8 +490,9 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   };
   // The small layers' weight gradients are released in groups: every release costs a barrier packet
   // on both queues (a few microseconds each), which for 5-10 us kernels is most of their run time.
-  // (groups of 1 / 2 / 3 / 4: 2.224 / 2.220 / 2.240 / 2.255 ms per iteration now that a release costs `st` nothing)
-  static const int group = [] { const char* v = getenv("LSHM_WGRAD_GROUP"); return v ? atoi(v) : 2; }();
+  // (groups of 1 / 2 / 3 / 4: 2.224 / 2.220 / 2.240 / 2.255 ms per iteration once a release cost `st` nothing; at the end of
+  //  round 3, with fewer and fused weight-gradient launches: 1 / 2 / 3 = 2.024 / 2.045 / 2.055 -- every layer on its own)
+  static const int group = [] { const char* v = getenv("LSHM_WGRAD_GROUP"); return v ? atoi(v) : 1; }();
   std::vector<std::function<int()>> pending;
   auto release = [&](bool force) -> int {
     if (pending.empty() || (!force && (int)pending.size() < group)) return LSHM_OK;
