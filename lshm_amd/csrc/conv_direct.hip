@@ -1432,8 +1432,8 @@ int conv1d_wgrad_mid(const float* small, long s_bs, const float* big, long big_b
   const int nw = Cs * Cb * 4, slab = nw + wgrad_bias_pad(Cs, Cb);
   const int TP = Cs == 24 ? 128 : 64;
   const int ntiles = (Ls / TP) * B;
-  static const int capmid = [] { const char* v = getenv("LSHM_GRID_WGRAD_MID"); return v && atoi(v) > 0 && atoi(v) <= 1024 ? atoi(v) : 512; }();
-  // (512 workgroups over the pair instead of 1024: half the partial slabs for the closing sums, -0.004 ms per iteration)
+  static const int capmid = [] { const char* v = getenv("LSHM_GRID_WGRAD_MID"); return v && atoi(v) > 0 && atoi(v) <= 1024 ? atoi(v) : 256; }();
+  // (workgroups over the pair = partial slabs for the closing sums; per iteration 1024 / 512 / 256 / 128: 2.037 / 2.033 / 2.019 / 2.022 ms)
   int grid = ntiles < capmid / G ? ntiles : capmid / G;
   if (grid < 1) grid = 1;
   const dim3 g(grid, G);
