@@ -20,8 +20,12 @@ cp $(ls $RAW/default/*/*kernel_stats.csv | head -1) $OUT/bench_default_kernel_st
 python3 profiles/summarize.py $RAW/default 1 -1 > $OUT/bench_default_kernel_stats.txt
 # 2. un-profiled bench line
 python3 bench.py > $OUT/bench_unprofiled_output.json 2> $RAW/unprofiled.err
-# 3. one ADMM iteration, kernel by kernel
+# 3. one ADMM iteration, kernel by kernel.  LSHM_WGRAD_GROUP=2 (exported: nothing may sit between rocprofv3's "--" and the
+#    program): with the default one-layer-at-a-time releases the HOST becomes the bottleneck under the profiler (3.29 ms of
+#    wall for 2.18 ms of device-busy time), which the unprofiled run is not (profiles/r03/phase_times.txt)
+export LSHM_WGRAD_GROUP=2
 rocprofv3 --kernel-trace -d $RAW/step --output-format csv -- python3 bench.py $STEP > $RAW/step.json 2> $RAW/step.err
+unset LSHM_WGRAD_GROUP
 python3 profiles/step_trace.py $RAW/step > $OUT/step_timeline.txt
 # 4. HBM traffic: FETCH_SIZE / WRITE_SIZE in separate passes, keyed by the profiled command
 for C in FETCH_SIZE WRITE_SIZE; do
