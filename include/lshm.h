@@ -264,6 +264,15 @@ int lshm_recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, 
                               const float* y1, const float* y2, const float* y3, float rho,
                               int planes, int P, double* sums7, float* gx1_partial, float* gx2,
                               float* gx3c, float* workspace, lshm_stream_t stream);
+/* The same terms and gradients with the reconstructions of netT / netF NOT read but formed inside the pass from the inputs
+ * aT, aF (planes / C samples x 8 channels x P*P/4 positions) of their last layer, ConvTranspose1d(8, C, 4, stride=4) without
+ * activation (src/lofar_models.py:142; weights wT / wF (8, C, 4), biases bT / bF (C)): bitwise what lshm_conv_fwd_pair of that
+ * layer followed by lshm_recon_losses_fwd_bwd gives.  The step engine uses the multiplier-updating form of this pass behind
+ * its no-grad forward, which then stops one layer early. */
+int lshm_recon_losses_from_a(const float* x, const float* x1, const float* aT, const float* aF, const float* wT,
+                             const float* bT, const float* wF, const float* bF, const float* y1, const float* y2,
+                             const float* y3, float rho, int planes, int P, int C, double* sums7, float* gx1_partial,
+                             float* gx2, float* gx3c, float* workspace, lshm_stream_t stream);
 int lshm_combine_dx1(const float* gx1_partial, const float* gT, const float* gFc, float* gx1,
                      int planes, int P, lshm_stream_t stream);
 /* y_k += rho * r_k                                                src/kharmonic_lofar.py:200-202 */

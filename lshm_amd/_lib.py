@@ -99,6 +99,7 @@ _SIGNATURES = {
     "lshm_rica_update_dictionary": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_float, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lshm_recon_workspace_floats": (c_size_t, [c_int, c_int]),
     "lshm_recon_losses_fwd_bwd": (c_int, [c_void_p] * 7 + [c_float, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
+    "lshm_recon_losses_from_a": (c_int, [c_void_p] * 11 + [c_float, c_int, c_int, c_int] + [c_void_p] * 5 + [c_void_p]),
     "lshm_combine_dx1": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lshm_multiplier_update": (c_int, [c_void_p] * 7 + [c_float, c_int, c_int, c_void_p]),
     "lshm_adam_step_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_float, c_float, c_float,

@@ -321,6 +321,19 @@ int lshm_recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, 
   REQUIRE((gx1p && gx2 && gx3c) || (!gx1p && !gx2 && !gx3c), "recon_losses: gradient images are all set or all NULL");
   return recon_losses_fwd_bwd(x, x1, x2, x3c, y1, y2, y3, rho, planes, P, sums7, gx1p, gx2, gx3c, ws, ST(s));
 }
+int lshm_recon_losses_from_a(const float* x, const float* x1, const float* aT, const float* aF, const float* wT, const float* bT,
+                             const float* wF, const float* bF, const float* y1, const float* y2, const float* y3, float rho,
+                             int planes, int P, int C, double* sums7, float* gx1p, float* gx2, float* gx3c, float* ws,
+                             lshm_stream_t s) {
+  REQUIRE(x && x1 && aT && aF && wT && bT && wF && bF && y1 && y2 && y3 && sums7 && gx1p && gx2 && gx3c && ws && planes > 0 && C > 0,
+          "recon_losses_from_a: null pointer");
+  if (!recon_from_a_supported(C, P, 8, C, P * P / 4)) {
+    set_last_error("recon_losses_from_a: needs ConvTranspose1d(8, C, 4, stride=4) output layers and a patch size that is a multiple of 32");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  return recon_losses_from_a(x, x1, aT, aF, 8L * (P * P / 4), wT, bT, wF, bF, C, y1, y2, y3, rho, planes, P, sums7, gx1p, gx2, gx3c, ws,
+                             ST(s));
+}
 int lshm_combine_dx1(const float* gx1p, const float* gT, const float* gFc, float* gx1, int planes, int P,
                      lshm_stream_t s) {
   REQUIRE(gx1p && gT && gFc && gx1 && planes > 0 && P % 32 == 0, "combine_dx1: bad argument");

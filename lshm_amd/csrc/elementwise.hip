@@ -485,6 +485,24 @@ int multiplier_update_recon_from_a(const float* x, const float* x1, const float*
                        reinterpret_cast<double*>(block_partials), gx1p, gx2, gx3c, fa);
   return check_launch("recon_losses");
 }
+// the same pass without the multiplier update (the C entry lshm_recon_losses_from_a: per-kernel parity of the FROMA form)
+int recon_losses_from_a(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT, const float* bT,
+                        const float* wF, const float* bF, int C, const float* y1, const float* y2, const float* y3, float rho,
+                        int planes, int P, double* sums7, float* gx1p, float* gx2, float* gx3c, float* block_partials,
+                        hipStream_t st) {
+  if (P % TILE || planes % C) { set_last_error("recon_losses: patch size must be a multiple of 32"); return LSHM_ERR_ARG; }
+  const double n = (double)planes * P * P;
+  const ReconFromA fa{aT, aF, wT, bT, wF, bF, a_bs, C};
+  const dim3 grid(P / TILE, P / TILE, planes);
+  double* part = reinterpret_cast<double*>(block_partials);
+  hipLaunchKernelGGL((recon_kernel<false, true, float, true>), grid, dim3(TILE, 8), 0, st, x, x1, (const float*)nullptr,
+                     (const float*)nullptr, const_cast<float*>(y1), const_cast<float*>(y2), const_cast<float*>(y3), rho,
+                     (float)(1.0 / n), P, part, gx1p, gx2, gx3c, fa);
+  int rc = check_launch("recon_losses");
+  if (rc) return rc;
+  hipLaunchKernelGGL(sum7_kernel, dim3(7), dim3(1024), 0, st, part, (long)grid.x * grid.y * grid.z, sums7);
+  return check_launch("recon_sum7");
+}
 // y_k += rho r_k, then the reconstruction terms of the next closure with the updated multipliers
 int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
                             float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,

@@ -359,6 +359,10 @@ int multiplier_update_recon_from_a(const float* x, const float* x1, const float*
                                    const float* bT, const float* wF, const float* bF, int C, float* y1, float* y2, float* y3,
                                    float rho, int planes, int P, float* gx1p, float* gx2, float* gx3c, float* block_partials,
                                    hipStream_t st, float grad_scale, int bf = 0);
+int recon_losses_from_a(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT, const float* bT,
+                        const float* wF, const float* bF, int C, const float* y1, const float* y2, const float* y3, float rho,
+                        int planes, int P, double* sums7, float* gx1p, float* gx2, float* gx3c, float* block_partials,
+                        hipStream_t st);
 int multiplier_update_recon(const float* x, const float* x1, const float* x2, const float* x3c, float* y1, float* y2,
                             float* y3, float rho, int planes, int P, double* sums7, float* gx1p, float* gx2,
                             float* gx3c, float* block_partials, hipStream_t st, float grad_scale = 1.f, int bf = 0);

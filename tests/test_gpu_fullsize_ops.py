@@ -369,3 +369,42 @@ def test_first_1d_layers_straight_from_the_images_are_bitwise_the_two_launches(n
     refT = TF.elu(TF.conv1d(r.reshape(nb, 4, -1), w[0].double(), b[0].double(), stride=4, padding=1))
     refF = TF.elu(TF.conv1d(r.transpose(2, 3).reshape(nb, 4, -1), w[1].double(), b[1].double(), stride=4, padding=1))
     assert rel_err(y[0], refT) < 1e-5 and rel_err(y[1], refF) < 1e-5
+
+
+@pytest.mark.parametrize("nb", [256, 2])
+def test_reconstruction_pass_from_the_last_layers_input_is_bitwise_the_two_launches(nb):
+    """lshm_recon_losses_from_a (the reconstruction terms and gradients with x2 / x3c formed inside the pass from the input of
+    netT / netF's last layer, src/lofar_models.py:142, src/kharmonic_lofar.py:150-158) against lshm_conv_fwd_pair of that
+    layer followed by lshm_recon_losses_fwd_bwd: the seven sums and the three gradient images, bit for bit."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(11 + nb)
+    C, P = 4, 128
+    planes = nb * C
+    x, x1 = torch.randn(nb, C, P, P, generator=g), torch.randn(nb, C, P, P, generator=g)
+    a = [TF.elu(torch.randn(nb, 8, P * P // 4, generator=g)) for _ in range(2)]
+    w = [torch.randn(8, C, 4, generator=g) * 0.3 for _ in range(2)]
+    b = [torch.randn(C, generator=g) * 0.1 for _ in range(2)]
+    ys = [torch.randn(nb, C, P, P, generator=g) * 0.1 for _ in range(3)]
+    dv = lambda t: t.to(DEV).contiguous()
+    xd, x1d, ad, wd, bd, yd = dv(x), dv(x1), [dv(t) for t in a], [dv(t) for t in w], [dv(t) for t in b], [dv(t) for t in ys]
+    st, Pt = L.stream(), L.ptr
+    nws = lib.lshm_recon_workspace_floats(planes, P)
+    ws = torch.empty(nws, device=DEV)
+    # reference: run the layer, then the pass
+    x2, x3c = torch.empty(nb, C, P * P, device=DEV), torch.empty(nb, C, P * P, device=DEV)
+    L.check(lib.lshm_conv_fwd_pair(3, Pt(ad[0]), Pt(wd[0]), Pt(bd[0]), Pt(x2), Pt(ad[1]), Pt(wd[1]), Pt(bd[1]), Pt(x3c), nb, 8, C, 1,
+                                   P * P // 4, 0, 0, 0, None, 0, st), "tconv5 pair")
+    s_ref = torch.zeros(8, device=DEV, dtype=torch.float64)
+    g_ref = [torch.empty(nb, C, P, P, device=DEV) for _ in range(3)]
+    L.check(lib.lshm_recon_losses_fwd_bwd(Pt(xd), Pt(x1d), Pt(x2), Pt(x3c), Pt(yd[0]), Pt(yd[1]), Pt(yd[2]), 0.7, planes, P, Pt(s_ref),
+                                          *[Pt(t) for t in g_ref], Pt(ws), st), "recon")
+    s_new = torch.zeros(8, device=DEV, dtype=torch.float64)
+    g_new = [torch.full((nb, C, P, P), float("nan"), device=DEV) for _ in range(3)]
+    L.check(lib.lshm_recon_losses_from_a(Pt(xd), Pt(x1d), Pt(ad[0]), Pt(ad[1]), Pt(wd[0]), Pt(bd[0]), Pt(wd[1]), Pt(bd[1]), Pt(yd[0]),
+                                         Pt(yd[1]), Pt(yd[2]), 0.7, planes, P, C, Pt(s_new), *[Pt(t) for t in g_new], Pt(ws), st),
+            "recon from a")
+    torch.cuda.synchronize()
+    assert torch.equal(s_ref[:7], s_new[:7])
+    for p, q in zip(g_ref, g_new):
+        assert torch.equal(p, q)
