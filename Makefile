@@ -14,6 +14,9 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h include/lshm.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# headers of single kernel families (kept out of kernels.h, which rebuilds everything)
+$(OBJDIR)/deep2d.o $(OBJDIR)/capi.o $(OBJDIR)/engine.o: $(CSRC)/deep2d.h
+
 $(LIB): $(OBJS)
 	@mkdir -p lshm_amd/lib
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)

@@ -64,6 +64,9 @@ def parse():
                     help="skip the secondary objects (sequential_forwards_mode, bf16_mode, k64_mode, admm10_loop)")
     ap.add_argument("--sequential-forwards", action="store_true",
                     help="headline with TrainConfig.overlap_forwards=False (the round-2 schedule), for A/B")
+    ap.add_argument("--schedule-off", default="", metavar="NAMES",
+                    help="comma-separated schedule choices of the headline trainer to switch off (TrainConfig.schedule_off, e.g. "
+                         "no_deep2d), for A/B")
     return ap.parse_args()
 
 
@@ -627,7 +630,8 @@ def main():
     B = args.batch
     cfg = TrainConfig(Kc=args.K, matrix_precision="bf16" if args.bf16 else "fp32",
                       activation_storage="bf16" if (args.bf16 and not args.bf16_operands_only) else "fp32",
-                      overlap_forwards=not args.sequential_forwards)
+                      overlap_forwards=not args.sequential_forwards,
+                      schedule_off=tuple(n for n in args.schedule_off.split(",") if n))
     tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=args.bpb, default_batch=B // args.bpb, device=dev,
                           process_group=pg)
     tr.init_parameters(seed=0)  # identical replicas on every rank

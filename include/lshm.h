@@ -162,6 +162,21 @@ int lshm_dense2d_fwd(int L, const float* cat1, const float* const* wb, float* z1
 int lshm_dense2d_bwd(int L, const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
                      const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
                      lshm_stream_t stream);
+/* The deep section of AutoEncoderCNN2(latent_dim=224, rica=True)'s forward as ONE launch (src/lofar_models.py:36-41,43-51,
+ * 52-55 and the forward :66-69,73-98): conv3 -> conv4 -> conv5 -> fc1 -> fc2in -> fc2out -> fc3 -> tconv0 -> tconv1 -> tconv2 ->
+ * tconv3, a workgroup per patch (or two), activations resident in LDS, every layer's output also written once to out[]:
+ *   x2 (B,24,16,16) = conv2's output; w[11] / bias[11] = {conv3, conv4, conv5, fc1, fc2in, fc2out, fc3, tconv0, tconv1, tconv2,
+ *   tconv3} in the layers' own torch layouts; out[11] = {conv3 (B,48,8,8), conv4 (B,96,4,4), cat1 (B,784: columns 0..767
+ *   written, 768..783 = elu(fcuv1(uvh)) must be there), z1 (B,224), mu (B,224 inside a (B,ldmu) matrix), cat3 (B,240: columns
+ *   0..223 written, 224..239 = elu(fcuv3(uvh)) must be there), d0 (B,768), tconv0 (B,96,4,4), tconv1 (B,48,8,8), tconv2
+ *   (B,24,16,16), tconv3 (B,12,32,32)}.
+ * The weights are first re-ordered into `packed` (lshm_deep2d_packed_floats() floats, 16-byte aligned) in the order the
+ * kernel's matrix instructions consume them (one launch).  variant 0: one patch per 1024-thread workgroup, 1: two patches,
+ * 2: one patch per 512-thread workgroup.  Results do not depend on the variant bit for bit.  stamps (diagnostics, may be
+ * NULL): 32 device int64 that receive workgroup 0's shader-clock readings at the stage boundaries. */
+size_t lshm_deep2d_packed_floats(void);
+int lshm_deep2d_fwd(const float* x2, const float* const* w, const float* const* bias, float* const* out, long ldmu, float* packed,
+                    int B, int variant, long long* stamps, lshm_stream_t stream);
 /* dz = gy * ELU'(y) from the saved output y                      (autograd of F.elu) */
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t stream);
 
@@ -375,7 +390,12 @@ typedef struct lshm_step_config {
   float scales[8];
   int world;            /* data-parallel world size (gradients are averaged over it) */
   int precision;        /* LSHM_PRECISION_*: operand precision of this engine's GEMM-shaped layers */
+  unsigned schedule;    /* LSHM_SCHED_*: 0 = the shipped schedule; each bit switches ONE of its choices off (per engine: two
+                           engines of a process may differ).  Every alternative is the launch sequence the choice replaced;
+                           results agree to rounding (bit for bit where noted). */
 } lshm_step_config;
+/* conv3 .. tconv3 of the 2-D autoencoder's forward as eleven launches instead of one (lshm_deep2d_fwd) */
+#define LSHM_SCHED_NO_DEEP2D (1u << 0)
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);
 void lshm_engine_destroy(lshm_engine* e);

@@ -33,10 +33,12 @@ class StepConfig(C.Structure):
                 ("p", c_float), ("alpha", c_float), ("beta", c_float), ("gamma", c_float),
                 ("rho", c_float), ("rica_lambda", c_float), ("rica", c_int), ("bpb", c_int),
                 ("batch_size", c_int), ("H", c_int), ("scales", c_float * 8), ("world", c_int),
-                ("precision", c_int)]
+                ("precision", c_int), ("schedule", C.c_uint)]
 
 
 PRECISION_F32, PRECISION_BF16_OPERANDS, PRECISION_BF16_STORAGE = 0, 1, 2
+SCHED_NO_DEEP2D = 1 << 0
+SCHEDULE_BITS = {"no_deep2d": SCHED_NO_DEEP2D}
 STEP_RECON_READY = 1
 NEXT_CONCURRENT_FORWARD = 1
 ENGINE_USED_EARLY_BUCKET, ENGINE_USED_CONCURRENT_FORWARD = 1, 2
@@ -68,6 +70,8 @@ _SIGNATURES = {
     "lshm_dense2d_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p]),
     "lshm_dense2d_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lshm_deep2d_packed_floats": (c_size_t, []),
+    "lshm_deep2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lshm_elu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "lshm_linear_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "lshm_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,

@@ -3,6 +3,7 @@
 // allocation, no synchronisation.
 #include "../../include/lshm.h"
 #include "kernels.h"
+#include "deep2d.h"
 
 #include <string.h>
 
@@ -183,6 +184,23 @@ int lshm_conv1d_chain3(int up, const float* x, const float* const* w, const floa
     st[k].act = act;
   }
   return conv1d_chain(up != 0, st, x, nullptr, up ? 96L * 16 : 12L * 1024, pad, B, ST(s));
+}
+size_t lshm_deep2d_packed_floats(void) { return deep2d_packed_floats(); }
+int lshm_deep2d_fwd(const float* x2, const float* const* w, const float* const* bias, float* const* out, long ldmu, float* packed,
+                    int B, int variant, long long* stamps, lshm_stream_t s) {
+  REQUIRE(x2 && w && bias && out && packed && B > 0 && ldmu >= 224, "deep2d_fwd: bad argument");
+  for (int i = 0; i < 11; ++i) REQUIRE(w[i] && bias[i] && out[i], "deep2d_fwd: null layer pointer");
+  const Deep2dWeights dw{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
+  int rc = deep2d_pack(dw, packed, ST(s));
+  if (rc) return rc;
+  Deep2dIO io;
+  io.x2 = x2;
+  io.b3 = bias[0]; io.b4 = bias[1]; io.b5 = bias[2]; io.bfc1 = bias[3]; io.bfc2in = bias[4]; io.bfc2out = bias[5]; io.bfc3 = bias[6];
+  io.bt0 = bias[7]; io.bt1 = bias[8]; io.bt2 = bias[9]; io.bt3 = bias[10];
+  io.a3 = out[0]; io.a4 = out[1]; io.cat1 = out[2]; io.z1 = out[3]; io.mu = out[4]; io.mu_ld = ldmu; io.cat3 = out[5]; io.d0 = out[6];
+  io.t0 = out[7]; io.t1 = out[8]; io.t2 = out[9]; io.t3 = out[10];
+  io.stamps = stamps;
+  return deep2d_fwd(io, packed, B, variant, ST(s));
 }
 static int dense_mid_fwd(int L, const float* cat1, const float* const* wb, float* z1, float* mu, long ldmu, float* cat3, float* d0,
                          int B, lshm_stream_t s) {

@@ -16,6 +16,7 @@
 //                    column-vectorised residuals, gradient ping-pong buffers, split-K partials.
 #include "../../include/lshm.h"
 #include "kernels.h"
+#include "deep2d.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -82,6 +83,9 @@ struct lshm_engine {
   // forwards that do not depend on each other -- the no-grad forward that closes iteration k and the closure
   // forward that opens iteration k+1 -- run side by side on two streams, each with `ws` or `ws + alt_base` as base.
   size_t o_fpart, fwd_floats, alt_base;
+  size_t o_pack2d = 0;  // fragment-ordered copy of the 2-D autoencoder's deep weights (deep2d.hip), inside the forward prefix
+  bool deep2d = false;  // conv3 .. tconv3 of the 2-D autoencoder's forward as one launch
+  int deep_variant = 0; // 0: one patch per workgroup (a forward alone), 1: two (two forwards side by side: each fills half of the CUs)
   size_t o_recon_part;  // per-block partial sums of the reconstruction pass (its own buffer: their seven sums may be made later, beside the backward)
   hipStream_t fstream = nullptr;  // the no-grad forward + shared reconstruction pass, beside the next closure forward
   // Two "lanes" of backward scratch: netT and netF (independent given AE1's output, identical
@@ -253,7 +257,33 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   const int chu[4] = {a0.dec[1].Cin, a0.dec[1].Cout, a0.dec[2].Cout, a0.dec[3].Cout};
   const bool chain_dn = a0.ndim == 1 && conv1d_chain_supported(false, chd, a0.enc[2].Win);
   const bool chain_up = a0.ndim == 1 && conv1d_chain_supported(true, chu, a0.dec[1].Win);
+  // 2-D autoencoder: conv3 .. tconv3 (eleven layers) as one launch over a fragment-ordered copy of their weights (deep2d.hip);
+  // the copy is made at the head of the forward (the parameters may have changed since the last one)
+  const bool deep = G == 1 && a0.ndim == 2 && e->deep2d;
+  if (deep) {
+    steps.push_back([=](float* ws, hipStream_t st) -> int {
+      const AEPlan& a = A(0);
+      const Deep2dWeights w{prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw, prm + a.fc3w,
+                            prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
+      return deep2d_pack(w, ws + e->o_pack2d, st);
+    });
+  }
   for (int i = 0; i < 6; ++i) {
+    if (deep && i == 3) {
+      steps.push_back([=](float* ws, hipStream_t st) -> int {
+        const AEPlan& a = A(0);
+        Deep2dIO io;
+        io.x2 = ws + a.act[2];
+        io.b3 = prm + a.cb[3]; io.b4 = prm + a.cb[4]; io.b5 = prm + a.cb[5];
+        io.bfc1 = prm + a.fc1b; io.bfc2in = prm + a.fc2inb; io.bfc2out = prm + a.fc2outb; io.bfc3 = prm + a.fc3b;
+        io.bt0 = prm + a.tb[0]; io.bt1 = prm + a.tb[1]; io.bt2 = prm + a.tb[2]; io.bt3 = prm + a.tb[3];
+        io.a3 = ws + a.act[3]; io.a4 = ws + a.act[4]; io.cat1 = ws + a.cat1; io.z1 = ws + a.z1;
+        io.mu = ws + e->o_Mu + a.mu_col; io.mu_ld = D; io.cat3 = ws + a.cat3; io.d0 = ws + a.d0;
+        io.t0 = ws + a.dact[0]; io.t1 = ws + a.dact[1]; io.t2 = ws + a.dact[2]; io.t3 = ws + a.dact[3];
+        return deep2d_fwd(io, ws + e->o_pack2d, B, e->deep_variant, st);
+      });
+      break;
+    }
     if (chain_dn && i == 2) {
       steps.push_back([=](float* ws, hipStream_t st) -> int {
         Chain1dStage cs[3];
@@ -293,7 +323,9 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   auto both = [&](auto f) { Lin q{}; for (int g = 0; g < 2; ++g) f(q, g, A(g)); return q; };
   // (elu(fcuv1(uvh)) and elu(fcuv3(uvh)) are already in cat1 / cat3: the uv_features step)
   const bool dense_chain = dense1d_supported(L, hd, c.rica);  // latent width 16 (netT / netF) or 256 (the 2-D autoencoder)
-  if (dense_chain) {
+  if (deep) {
+    if (latent_mark) *latent_mark = steps.size();
+  } else if (dense_chain) {
     // fc1 -> fc2in -> fc2out -> fc3 of an autoencoder as one launch (dense1d.hip); the latents are complete inside it,
     // so the latent-space terms start right after it
     steps.push_back([=](float* ws, hipStream_t st) -> int {
@@ -326,13 +358,13 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
       steps.push_back([=](float* ws, hipStream_t st) -> int { return copy2d(ws + src, D, ws + dst, L + hd, B, L, st); });
     }
   }
-  if (!dense_chain) {
+  if (!dense_chain && !deep) {
     if (latent_mark) *latent_mark = steps.size();
     Lin q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = a.cat3; q.w[g] = a.fc3w; q.b[g] = a.fc3b; q.y[g] = a.d0; });
     q.ldx = L + hd; q.ldy = 768; q.K = L + hd; q.N = 768; q.act = 0;
     lin(q);
   }
-  for (int i = 0; i < 6; ++i) {
+  for (int i = deep ? 4 : 0; i < 6; ++i) {
     if (i == 5 && output_mark) *output_mark = steps.size();
     if (chain_up && i == 1) {
       steps.push_back([=](float* ws, hipStream_t st) -> int {
@@ -808,6 +840,13 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
   const int n = (int)P.steps.size();
   const int lead = stagger_env < 0 ? 0 : stagger_env > n ? n : stagger_env;
   int rc;
+  // two chains side by side: the deep sections take two patches per workgroup, so that each chain's launch fills half of
+  // the CUs and every weight fetched from L2 serves two patches (bit for bit the one-patch results)
+  struct VariantScope {
+    lshm_engine* e;
+    explicit VariantScope(lshm_engine* en) : e(en) { e->deep_variant = 1; }
+    ~VariantScope() { e->deep_variant = 0; }
+  } variant_scope(e);
   // chain a is the forward whose activations are not kept (the no-grad forward): its residual split + conv0 pair is one launch
   const bool fused_a = skip_b_1d_output && P.resid_conv0 && P.resid_mark + 1 < (size_t)n;
   for (int i = 0; i < n + lead; ++i) {
@@ -1213,6 +1252,12 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->o_row = take(cur, (size_t)B * img);
   e->o_col = take(cur, (size_t)B * img);
   e->o_fpart = take(cur, 4 * pf);  // split-K scratch of the forward launches (two pair-sized slots)
+  {
+    const int ech[5] = {e->ae[0].enc[1].Cout, e->ae[0].enc[2].Cout, e->ae[0].enc[3].Cout, e->ae[0].enc[4].Cout, e->ae[0].enc[5].Cout};
+    e->deep2d = !(cfg->schedule & LSHM_SCHED_NO_DEEP2D) && cfg->precision == LSHM_PRECISION_F32 /* fp32 weights and products */ &&
+                deep2d_supported(cfg->L, e->hdim, cfg->rica, ech, e->ae[0].enc[3].Hin);
+    if (e->deep2d) e->o_pack2d = take(cur, deep2d_packed_floats());
+  }
   e->fwd_floats = cur;
   // ---- backward / loss side
   e->o_gMu = take(cur, (size_t)B * e->D);

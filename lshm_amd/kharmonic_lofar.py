@@ -84,6 +84,10 @@ class TrainConfig:
     # (lshm_engine_multiplier_update_next_ex, LSHM_NEXT_CONCURRENT_FORWARD); both are computed, as upstream
     # computes both -- neither waits for the other.  Same trajectory bit for bit.  False: one after the other.
     overlap_forwards: bool = True
+    # Schedule choices of the engine to switch OFF (names of lshm_amd._lib.SCHEDULE_BITS, e.g. ("no_deep2d",)): each
+    # restores the launch sequence the choice replaced -- for A/B measurements and the tests that hold a fused kernel's
+    # trajectory to the launches it replaced.  Per trainer (lshm_step_config.schedule), not per process.
+    schedule_off: Tuple[str, ...] = ()
 
 
 class KHarmonicTrainer:
@@ -123,6 +127,9 @@ class KHarmonicTrainer:
         sc.world = self.world
         sc.precision = (L.PRECISION_BF16_STORAGE if cfg.activation_storage == "bf16" else
                         L.PRECISION_BF16_OPERANDS if cfg.matrix_precision == "bf16" else L.PRECISION_F32)
+        sc.schedule = 0
+        for name in cfg.schedule_off:
+            sc.schedule |= L.SCHEDULE_BITS[name]
         self._sc = sc
         h = C.c_void_p()
         # the engine's side stream and events are created on the device that is current now, and every

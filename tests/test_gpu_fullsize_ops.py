@@ -408,3 +408,137 @@ def test_reconstruction_pass_from_the_last_layers_input_is_bitwise_the_two_launc
     assert torch.equal(s_ref[:7], s_new[:7])
     for p, q in zip(g_ref, g_new):
         assert torch.equal(p, q)
+
+
+def _deep2d_problem(nb, seed):
+    """Random weights (torch layouts) and inputs of the deep section of AutoEncoderCNN2(latent_dim=224, rica=True)."""
+    g = torch.Generator().manual_seed(seed)
+    L, hd = 224, 16
+    rn = lambda *s, scale=1.0: torch.randn(*s, generator=g) * scale
+    w = [rn(48, 24, 4, 4, scale=(3.0 / (24 * 16)) ** 0.5), rn(96, 48, 4, 4, scale=(3.0 / (48 * 16)) ** 0.5),
+         rn(192, 96, 4, 4, scale=(3.0 / (96 * 16)) ** 0.5), rn(L, 768 + hd, scale=(3.0 / 784) ** 0.5),
+         rn(L, L, scale=(3.0 / L) ** 0.5), rn(L, L, scale=(3.0 / L) ** 0.5), rn(768, L + hd, scale=(3.0 / 240) ** 0.5),
+         rn(192, 96, 4, 4, scale=(3.0 / (192 * 4)) ** 0.5), rn(96, 48, 4, 4, scale=(3.0 / (96 * 4)) ** 0.5),
+         rn(48, 24, 4, 4, scale=(3.0 / (48 * 4)) ** 0.5), rn(24, 12, 4, 4, scale=(3.0 / (24 * 4)) ** 0.5)]
+    b = [rn(n, scale=0.1) for n in (48, 96, 192, L, L, L, 768, 96, 48, 24, 12)]
+    x2 = TF.elu(rn(nb, 24, 16, 16))
+    uv1 = TF.elu(rn(nb, hd))  # elu(fcuv1(uvh)), elu(fcuv3(uvh)): produced by another launch in the engine
+    uv3 = TF.elu(rn(nb, hd))
+    return w, b, x2, uv1, uv3
+
+
+def _deep2d_reference(w, b, x2, uv1, uv3, dt):
+    c = lambda t: t.to(dt)
+    a3 = TF.elu(TF.conv2d(c(x2), c(w[0]), c(b[0]), stride=2, padding=1))
+    a4 = TF.elu(TF.conv2d(a3, c(w[1]), c(b[1]), stride=2, padding=1))
+    a5 = TF.elu(TF.conv2d(a4, c(w[2]), c(b[2]), stride=2, padding=1))
+    cat1 = torch.cat([a5.flatten(1), c(uv1)], 1)
+    z1 = TF.elu(TF.linear(cat1, c(w[3]), c(b[3])))
+    mu = TF.elu(TF.linear(z1, c(w[4]), c(b[4])))
+    h = TF.elu(TF.linear(mu, c(w[5]), c(b[5])))
+    cat3 = torch.cat([h, c(uv3)], 1)
+    d0 = TF.linear(cat3, c(w[6]), c(b[6]))
+    t0 = TF.elu(TF.conv_transpose2d(d0.view(-1, 192, 2, 2), c(w[7]), c(b[7]), stride=2, padding=1))
+    t1 = TF.elu(TF.conv_transpose2d(t0, c(w[8]), c(b[8]), stride=2, padding=1))
+    t2 = TF.elu(TF.conv_transpose2d(t1, c(w[9]), c(b[9]), stride=2, padding=1))
+    t3 = TF.elu(TF.conv_transpose2d(t2, c(w[10]), c(b[10]), stride=2, padding=1))
+    return [a3, a4, cat1, z1, mu, cat3, d0, t0, t1, t2, t3]
+
+
+@pytest.mark.parametrize("variant,nb", [(0, 256), (1, 256), (2, 256), (0, 5), (1, 5)],
+                         ids=["one-patch", "two-patches", "512-threads", "one-patch-ragged", "two-patches-ragged"])
+def test_deep_section_of_the_2d_autoencoder_as_one_launch(variant, nb):
+    """lshm_deep2d_fwd (conv3 -> conv4 -> conv5 -> fc1 -> fc2in -> fc2out -> fc3 -> tconv0 -> tconv1 -> tconv2 -> tconv3 of
+    AutoEncoderCNN2, src/lofar_models.py:36-55,66-98, one workgroup per patch (or two), activations resident in LDS,
+    weights streamed in fragment order) against the eleven separate launches it replaces and against fp64: every layer's
+    output, B = 256 and a batch that does not fill the last workgroup."""
+    import ctypes as C
+    from lshm_amd import _lib as L
+    lib = L.load()
+    Ld, hd = 224, 16
+    w, b, x2, uv1, uv3 = _deep2d_problem(nb, 7 + variant)
+    wd, bd = [t.to(DEV) for t in w], [t.to(DEV) for t in b]
+    x2d = x2.to(DEV)
+    shapes = [(nb, 48, 8, 8), (nb, 96, 4, 4), (nb, 768 + hd), (nb, Ld), (nb, 256), (nb, Ld + hd), (nb, 768), (nb, 96, 4, 4),
+              (nb, 48, 8, 8), (nb, 24, 16, 16), (nb, 12, 32, 32)]
+    outs = [torch.full(s, float("nan"), device=DEV) for s in shapes]
+    outs[2][:, 768:] = uv1.to(DEV)
+    outs[5][:, Ld:] = uv3.to(DEV)
+    packed = torch.empty(lib.lshm_deep2d_packed_floats(), device=DEV)
+    arr = lambda ts: (C.c_void_p * 11)(*[t.data_ptr() for t in ts])
+    L.check(lib.lshm_deep2d_fwd(L.ptr(x2d), arr(wd), arr(bd), arr(outs), 256, L.ptr(packed), nb, variant, None, L.stream()), "deep2d_fwd")
+    torch.cuda.synchronize()
+    got = list(outs)
+    got[4] = outs[4][:, :Ld]
+    for k, o in enumerate(got):
+        assert torch.isfinite(o).all(), k
+    # fp64 on whole samples (first / last patch, both patches of a two-patch workgroup)
+    idx = [i for i in SAMPLES if i < nb] if nb > 5 else list(range(nb))
+    ref = _deep2d_reference(w, b, x2[idx], uv1[idx], uv3[idx], torch.float64)
+    for k, (o, r) in enumerate(zip(got, ref)):
+        assert rel_err(o[idx].cpu().double().reshape(r.shape), r) < 2e-5, (variant, k)
+    # the separate launches of the library (implicit GEMMs with their own summation order)
+    st = L.stream()
+    cur = x2d
+    sep = []
+    for li, (kind, cin, cout, hin) in enumerate([(0, 24, 48, 16), (0, 48, 96, 8), (0, 96, 192, 4)]):
+        y = torch.empty(nb, cout, hin // 2, hin // 2, device=DEV)
+        nws = lib.lshm_conv_workspace_floats(kind, nb, cin, cout, hin, hin)
+        ws = torch.empty(max(nws, 1), device=DEV)
+        L.check(lib.lshm_conv_fwd(kind, L.ptr(cur), L.ptr(wd[li]), L.ptr(bd[li]), L.ptr(y), nb, cin, cout, hin, hin, 0, 0, 1,
+                                  L.ptr(ws), nws, st), "conv_fwd")
+        sep.append(y)
+        cur = y
+    cat1 = torch.cat([cur.flatten(1), uv1.to(DEV)], 1).contiguous()
+    sep[2] = cat1
+
+    def lin(x, wi, act):
+        K, N = x.shape[1], wd[wi].shape[0]
+        y = torch.empty(nb, N, device=DEV)
+        nws = lib.lshm_linear_workspace_floats(nb, K, N)
+        ws = torch.empty(max(nws, 1), device=DEV)
+        L.check(lib.lshm_linear_fwd(L.ptr(x), K, L.ptr(wd[wi]), L.ptr(bd[wi]), L.ptr(y), N, nb, K, N, act, L.ptr(ws), nws, st), "linear_fwd")
+        return y
+
+    z1 = lin(cat1, 3, 1)
+    mu = lin(z1, 4, 1)
+    cat3 = torch.cat([lin(mu, 5, 1), uv3.to(DEV)], 1).contiguous()
+    d0 = lin(cat3, 6, 0)
+    sep += [z1, mu, cat3, d0]
+    cur = d0.view(nb, 192, 2, 2)
+    for li, (cin, cout, hin) in zip((7, 8, 9, 10), [(192, 96, 2), (96, 48, 4), (48, 24, 8), (24, 12, 16)]):
+        y = torch.empty(nb, cout, 2 * hin, 2 * hin, device=DEV)
+        nws = lib.lshm_conv_workspace_floats(1, nb, cin, cout, hin, hin)
+        ws = torch.empty(max(nws, 1), device=DEV)
+        L.check(lib.lshm_conv_fwd(1, L.ptr(cur), L.ptr(wd[li]), L.ptr(bd[li]), L.ptr(y), nb, cin, cout, hin, hin, 0, 0, 1,
+                                  L.ptr(ws), nws, st), "tconv_fwd")
+        sep.append(y)
+        cur = y
+    torch.cuda.synchronize()
+    for k, (o, r) in enumerate(zip(got, sep)):
+        assert rel_err(o, r.reshape(o.shape)) < 1e-5, (variant, k)
+
+
+def test_deep_section_variants_agree_bit_for_bit():
+    """One, two patches per workgroup and the 512-thread form of lshm_deep2d_fwd take the same products in the same order."""
+    import ctypes as C
+    from lshm_amd import _lib as L
+    lib = L.load()
+    nb, Ld, hd = 37, 224, 16
+    w, b, x2, uv1, uv3 = _deep2d_problem(nb, 99)
+    wd, bd = [t.to(DEV) for t in w], [t.to(DEV) for t in b]
+    x2d = x2.to(DEV)
+    shapes = [(nb, 48, 8, 8), (nb, 96, 4, 4), (nb, 768 + hd), (nb, Ld), (nb, 256), (nb, Ld + hd), (nb, 768), (nb, 96, 4, 4),
+              (nb, 48, 8, 8), (nb, 24, 16, 16), (nb, 12, 32, 32)]
+    arr = lambda ts: (C.c_void_p * 11)(*[t.data_ptr() for t in ts])
+    res = []
+    for variant in (0, 1, 2):
+        outs = [torch.zeros(s, device=DEV) for s in shapes]
+        outs[2][:, 768:] = uv1.to(DEV)
+        outs[5][:, Ld:] = uv3.to(DEV)
+        packed = torch.empty(lib.lshm_deep2d_packed_floats(), device=DEV)
+        L.check(lib.lshm_deep2d_fwd(L.ptr(x2d), arr(wd), arr(bd), arr(outs), 256, L.ptr(packed), nb, variant, None, L.stream()), "deep2d_fwd")
+        torch.cuda.synchronize()
+        res.append([o.clone() for o in outs])
+    for k in range(11):
+        assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
