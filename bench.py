@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--schedule-off", default="", metavar="NAMES",
                     help="comma-separated schedule choices of the headline trainer to switch off (TrainConfig.schedule_off, e.g. "
                          "no_deep2d), for A/B")
+    ap.add_argument("--tune", type=int, default=0, help="TrainConfig.tune of the headline trainer (experimental placement word)")
     return ap.parse_args()
 
 
@@ -631,7 +632,7 @@ def main():
     cfg = TrainConfig(Kc=args.K, matrix_precision="bf16" if args.bf16 else "fp32",
                       activation_storage="bf16" if (args.bf16 and not args.bf16_operands_only) else "fp32",
                       overlap_forwards=not args.sequential_forwards,
-                      schedule_off=tuple(n for n in args.schedule_off.split(",") if n))
+                      schedule_off=tuple(n for n in args.schedule_off.split(",") if n), tune=args.tune)
     tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=args.bpb, default_batch=B // args.bpb, device=dev,
                           process_group=pg)
     tr.init_parameters(seed=0)  # identical replicas on every rank

@@ -162,6 +162,18 @@ int lshm_dense2d_fwd(int L, const float* cat1, const float* const* wb, float* z1
 int lshm_dense2d_bwd(int L, const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
                      const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
                      lshm_stream_t stream);
+/* ---- diagnostics: a per-launch trace of the calling thread WITHOUT a profiler.  Between lshm_trace_begin and lshm_trace_end
+ * every kernel this thread launches through the library carries a start and a stop event of the trace's own
+ * (hipExtLaunchKernel: the kernel's dispatch and completion timestamps, no marker packets), so the timeline of the
+ * SHIPPED schedule can be read where rocprofv3 makes the host the bottleneck.  lshm_trace_end returns the number of
+ * launches recorded; after the caller has synchronised the device, lshm_trace_read returns launch `index`: demangled
+ * kernel name, start (us after the first recorded launch), duration (us), stream (numbered in order of first use) and
+ * grid size in threads.  lshm_trace_free releases the events.  Cost: ~25 launches per iteration that signal a dependency
+ * through their stop event record a marker instead. */
+int lshm_trace_begin(int capacity);
+int lshm_trace_end(void);
+int lshm_trace_read(int index, char* name, int name_cap, float* start_us, float* dur_us, int* stream_index, unsigned* grid_threads);
+int lshm_trace_free(void);
 /* The deep section of AutoEncoderCNN2(latent_dim=224, rica=True)'s forward as ONE launch (src/lofar_models.py:36-41,43-51,
  * 52-55 and the forward :66-69,73-98): conv3 -> conv4 -> conv5 -> fc1 -> fc2in -> fc2out -> fc3 -> tconv0 -> tconv1 -> tconv2 ->
  * tconv3, a workgroup per patch (or two), activations resident in LDS, every layer's output also written once to out[]:
@@ -177,6 +189,18 @@ int lshm_dense2d_bwd(int L, const float* dd0, const float* cat3, const float* mu
 size_t lshm_deep2d_packed_floats(void);
 int lshm_deep2d_fwd(const float* x2, const float* const* w, const float* const* bias, float* const* out, long ldmu, float* packed,
                     int B, int variant, long long* stamps, lshm_stream_t stream);
+/* The data-gradient pass back through the same layers (+ conv2's) as ONE launch: the same eleven-stage pipeline on the
+ * layers' own weight tensors (the data gradient of a k4 s2 p1 transposed conv is the conv with the same tensor, and vice
+ * versa; the dense layers are read transposed).  g_t2 (B,24,16,16) = gradient w.r.t. tconv2's pre-activation output;
+ * w[12] = {conv2, conv3, conv4, conv5, fc1, fc2in, fc2out, fc3, tconv0, tconv1, tconv2, tconv3}.weight;
+ * saved[10] = the forward tensors whose ELU' multiplies each stage's result: {tconv1 out, tconv0 out, cat3 (B,240), mu
+ * (B,224, row pitch ldmu), z1, cat1 (B,784), conv4 out, conv3 out, conv2 out, conv1 out (B,12,32,32)}; gmu (row pitch ldgmu,
+ * may be NULL) = gradient of the latent-space terms w.r.t. the code, added in front of fc2out's ELU';
+ * out[11] = the pre-activation gradients the weight gradients read as dz: {tconv1 (B,48,8,8), tconv0 (B,96,4,4), fc3's
+ * output (B,768), [fc2out | fcuv3] (B,240), fc2in (B,224), fc1 (B,224), [conv5 | fcuv1] (B,784), conv4 (B,96,4,4), conv3
+ * (B,48,8,8), conv2 (B,24,16,16), conv1 (B,12,32,32)}.  variant 0: one patch per workgroup, 1: two. */
+int lshm_deep2d_bwd(const float* g_t2, const float* const* w, const float* const* saved, long ldmu, const float* gmu, long ldgmu,
+                    float* const* out, float* packed, int B, int variant, lshm_stream_t stream);
 /* dz = gy * ELU'(y) from the saved output y                      (autograd of F.elu) */
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t stream);
 
@@ -393,9 +417,14 @@ typedef struct lshm_step_config {
   unsigned schedule;    /* LSHM_SCHED_*: 0 = the shipped schedule; each bit switches ONE of its choices off (per engine: two
                            engines of a process may differ).  Every alternative is the launch sequence the choice replaced;
                            results agree to rounding (bit for bit where noted). */
+  unsigned tune;        /* experimental placement word of the round's A/B measurements; 0 = the shipped schedule */
 } lshm_step_config;
 /* conv3 .. tconv3 of the 2-D autoencoder's forward as eleven launches instead of one (lshm_deep2d_fwd) */
 #define LSHM_SCHED_NO_DEEP2D (1u << 0)
+/* ... and the data gradients of tconv2 .. conv2 of the 2-D autoencoder as eleven launches instead of one (lshm_deep2d_bwd) */
+#define LSHM_SCHED_NO_DEEP2D_BWD (1u << 1)
+/* the implicit-GEMM weight gradients of the 2-D autoencoder's deep layers as six launches instead of one batched launch */
+#define LSHM_SCHED_NO_WGRAD_BATCH (1u << 2)
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);
 void lshm_engine_destroy(lshm_engine* e);

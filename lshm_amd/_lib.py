@@ -33,12 +33,12 @@ class StepConfig(C.Structure):
                 ("p", c_float), ("alpha", c_float), ("beta", c_float), ("gamma", c_float),
                 ("rho", c_float), ("rica_lambda", c_float), ("rica", c_int), ("bpb", c_int),
                 ("batch_size", c_int), ("H", c_int), ("scales", c_float * 8), ("world", c_int),
-                ("precision", c_int), ("schedule", C.c_uint)]
+                ("precision", c_int), ("schedule", C.c_uint), ("tune", C.c_uint)]
 
 
 PRECISION_F32, PRECISION_BF16_OPERANDS, PRECISION_BF16_STORAGE = 0, 1, 2
-SCHED_NO_DEEP2D = 1 << 0
-SCHEDULE_BITS = {"no_deep2d": SCHED_NO_DEEP2D}
+SCHED_NO_DEEP2D, SCHED_NO_DEEP2D_BWD, SCHED_NO_WGRAD_BATCH = 1 << 0, 1 << 1, 1 << 2
+SCHEDULE_BITS = {"no_deep2d": SCHED_NO_DEEP2D, "no_deep2d_bwd": SCHED_NO_DEEP2D_BWD, "no_wgrad_batch": SCHED_NO_WGRAD_BATCH}
 STEP_RECON_READY = 1
 NEXT_CONCURRENT_FORWARD = 1
 ENGINE_USED_EARLY_BUCKET, ENGINE_USED_CONCURRENT_FORWARD = 1, 2
@@ -72,6 +72,11 @@ _SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lshm_deep2d_packed_floats": (c_size_t, []),
     "lshm_deep2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "lshm_deep2d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "lshm_trace_begin": (c_int, [c_int]),
+    "lshm_trace_end": (c_int, []),
+    "lshm_trace_read": (c_int, [c_int, C.c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lshm_trace_free": (c_int, []),
     "lshm_elu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "lshm_linear_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "lshm_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,

@@ -10,10 +10,32 @@
 #include <map>
 #include <mutex>
 #include <utility>
+#include <vector>
+#include <cxxabi.h>
+#include <stdlib.h>
 
 namespace lshm {
 thread_local hipEvent_t launch_stop_event = nullptr;
 thread_local unsigned launch_stop_count = 0;
+
+// ---- per-launch trace (diagnostics; see common.h)
+thread_local bool launch_trace_on = false;
+namespace {
+struct TraceRec { const void* kernel; hipStream_t st; unsigned grid, block; hipEvent_t start, stop; };
+struct Trace {
+  std::vector<TraceRec> recs;
+  std::vector<LaunchTraceSlot> pool;
+  size_t used = 0;
+};
+thread_local Trace* g_trace = nullptr;
+}  // namespace
+bool launch_trace_take(const void* kernel, dim3 g, dim3 b, hipStream_t st, LaunchTraceSlot* slot) {
+  Trace* t = g_trace;
+  if (!t || t->used >= t->pool.size()) return false;
+  *slot = t->pool[t->used++];
+  t->recs.push_back(TraceRec{kernel, st, g.x * g.y * g.z, b.x * b.y * b.z, slot->start, slot->stop});
+  return true;
+}
 
 static thread_local char g_err[256] = "";
 void set_last_error(const char* msg) {
@@ -59,6 +81,22 @@ int kernel_budget_ok(const void* kernel, int threads, size_t dyn_lds, const char
     snprintf(g_err, sizeof(g_err), "%s: register budget allows %d threads per workgroup, the launch needs %d", what, kv.second, threads);
     return LSHM_ERR_UNSUPPORTED;
   }
+  return LSHM_OK;
+}
+int raise_dynamic_lds(const void* kernel, size_t dyn_lds, const char* what) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, size_t> raised;  // (kernel, device) -> limit already set
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return LSHM_OK; }
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = raised.find({kernel, dev});
+  if (it != raised.end() && it->second >= dyn_lds) return LSHM_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) != hipSuccess) {
+    (void)hipGetLastError();
+    snprintf(g_err, sizeof(g_err), "%s: cannot raise the dynamic LDS limit to %zu bytes", what, dyn_lds);
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  raised[{kernel, dev}] = dyn_lds;
   return LSHM_OK;
 }
 }  // namespace lshm
@@ -185,13 +223,78 @@ int lshm_conv1d_chain3(int up, const float* x, const float* const* w, const floa
   }
   return conv1d_chain(up != 0, st, x, nullptr, up ? 96L * 16 : 12L * 1024, pad, B, ST(s));
 }
+int lshm_trace_begin(int capacity) {
+  if (capacity < 1 || capacity > 65536) { set_last_error("trace_begin: capacity must be 1..65536"); return LSHM_ERR_ARG; }
+  if (g_trace) { set_last_error("trace_begin: this thread is already recording"); return LSHM_ERR_ARG; }
+  Trace* t = new Trace();
+  t->pool.resize(capacity);
+  for (auto& sl : t->pool) {
+    if (hipEventCreate(&sl.start) != hipSuccess || hipEventCreate(&sl.stop) != hipSuccess) {
+      (void)hipGetLastError();
+      set_last_error("trace_begin: cannot create events");
+      delete t;  // (events created so far are leaked: a diagnostic path on a device that is out of events)
+      return LSHM_ERR_ARG;
+    }
+  }
+  g_trace = t;
+  launch_trace_on = true;
+  return LSHM_OK;
+}
+int lshm_trace_end(void) {
+  if (!g_trace) { set_last_error("trace_end: this thread is not recording"); return LSHM_ERR_ARG; }
+  launch_trace_on = false;
+  return (int)g_trace->recs.size();
+}
+int lshm_trace_read(int index, char* name, int name_cap, float* start_us, float* dur_us, int* stream_index, unsigned* grid_threads) {
+  Trace* t = g_trace;
+  if (!t || launch_trace_on) { set_last_error("trace_read: call lshm_trace_end first"); return LSHM_ERR_ARG; }
+  if (index < 0 || index >= (int)t->recs.size()) { set_last_error("trace_read: index past the end"); return LSHM_ERR_ARG; }
+  const TraceRec& r = t->recs[index];
+  float a = 0.f, d = 0.f;
+  if (hipEventElapsedTime(&a, t->recs[0].start, r.start) != hipSuccess || hipEventElapsedTime(&d, r.start, r.stop) != hipSuccess) {
+    (void)hipGetLastError();
+    set_last_error("trace_read: an event has not completed (synchronise the device first)");
+    return LSHM_ERR_ARG;
+  }
+  if (start_us) *start_us = a * 1000.f;
+  if (dur_us) *dur_us = d * 1000.f;
+  if (stream_index) {
+    int k = 0;
+    std::vector<hipStream_t> seen;
+    for (int i = 0; i <= index; ++i) {
+      bool f = false;
+      for (size_t j = 0; j < seen.size(); ++j) if (seen[j] == t->recs[i].st) { f = true; if (i == index) k = (int)j; }
+      if (!f) { if (i == index) k = (int)seen.size(); seen.push_back(t->recs[i].st); }
+    }
+    *stream_index = k;
+  }
+  if (grid_threads) *grid_threads = r.grid * r.block;
+  if (name && name_cap > 0) {
+    const char* mangled = hipKernelNameRefByPtr(r.kernel, r.st);
+    int status = 1;
+    char* dem = mangled ? abi::__cxa_demangle(mangled, nullptr, nullptr, &status) : nullptr;
+    strncpy(name, (status == 0 && dem) ? dem : (mangled ? mangled : "?"), name_cap - 1);
+    name[name_cap - 1] = 0;
+    free(dem);
+  }
+  return LSHM_OK;
+}
+int lshm_trace_free(void) {
+  Trace* t = g_trace;
+  if (!t) return LSHM_OK;
+  launch_trace_on = false;
+  for (auto& sl : t->pool) { (void)hipEventDestroy(sl.start); (void)hipEventDestroy(sl.stop); }
+  delete t;
+  g_trace = nullptr;
+  return LSHM_OK;
+}
 size_t lshm_deep2d_packed_floats(void) { return deep2d_packed_floats(); }
 int lshm_deep2d_fwd(const float* x2, const float* const* w, const float* const* bias, float* const* out, long ldmu, float* packed,
                     int B, int variant, long long* stamps, lshm_stream_t s) {
   REQUIRE(x2 && w && bias && out && packed && B > 0 && ldmu >= 224, "deep2d_fwd: bad argument");
   for (int i = 0; i < 11; ++i) REQUIRE(w[i] && bias[i] && out[i], "deep2d_fwd: null layer pointer");
-  const Deep2dWeights dw{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
-  int rc = deep2d_pack(dw, packed, ST(s));
+  const Deep2dWeights dw{nullptr, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
+  int rc = deep2d_pack(dw, packed, 0, ST(s));
   if (rc) return rc;
   Deep2dIO io;
   io.x2 = x2;
@@ -201,6 +304,24 @@ int lshm_deep2d_fwd(const float* x2, const float* const* w, const float* const* 
   io.t0 = out[7]; io.t1 = out[8]; io.t2 = out[9]; io.t3 = out[10];
   io.stamps = stamps;
   return deep2d_fwd(io, packed, B, variant, ST(s));
+}
+int lshm_deep2d_bwd(const float* g_t2, const float* const* w, const float* const* saved, long ldmu, const float* gmu, long ldgmu,
+                    float* const* out, float* packed, int B, int variant, lshm_stream_t s) {
+  REQUIRE(g_t2 && w && saved && out && packed && B > 0 && ldmu >= 224, "deep2d_bwd: bad argument");
+  for (int i = 0; i < 12; ++i) REQUIRE(w[i], "deep2d_bwd: null weight pointer");
+  for (int i = 0; i < 10; ++i) REQUIRE(saved[i], "deep2d_bwd: null saved-activation pointer");
+  for (int i = 0; i < 11; ++i) REQUIRE(out[i], "deep2d_bwd: null output pointer");
+  const Deep2dWeights dw{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11]};
+  int rc = deep2d_pack(dw, packed, 1, ST(s));
+  if (rc) return rc;
+  Deep2dBwdIO io;
+  io.g_t2 = g_t2;
+  io.s_t1 = saved[0]; io.s_t0 = saved[1]; io.s_cat3 = saved[2]; io.s_mu = saved[3]; io.s_mu_ld = ldmu; io.s_z1 = saved[4]; io.s_cat1 = saved[5];
+  io.s_c4 = saved[6]; io.s_c3 = saved[7]; io.s_c2 = saved[8]; io.s_c1 = saved[9];
+  io.gmu = gmu; io.gmu_ld = ldgmu;
+  io.g_t1 = out[0]; io.g_t0 = out[1]; io.g_d0 = out[2]; io.g_cat3 = out[3]; io.g_mu = out[4]; io.g_mu_ld = 224; io.g_z1 = out[5];
+  io.g_cat1 = out[6]; io.g_c4 = out[7]; io.g_c3 = out[8]; io.g_c2 = out[9]; io.g_c1 = out[10];
+  return deep2d_bwd(io, packed, B, variant, ST(s));
 }
 static int dense_mid_fwd(int L, const float* cat1, const float* const* wb, float* z1, float* mu, long ldmu, float* cat3, float* d0,
                          int B, lshm_stream_t s) {

@@ -268,8 +268,9 @@ static size_t lds_up(int c0, int c1, int c2, int c3, int l0) {
 bool conv1d_chain_supported(bool up, const int* ch, int L0) {
   static const bool off = getenv("LSHM_CHAIN_OFF") != nullptr;
   if (off) return false;
-  if (!up) return ch[0] == 12 && ch[1] == 24 && ch[2] == 48 && ch[3] == 96 && L0 == 1024;
-  return ch[0] == 96 && ch[1] == 48 && ch[2] == 24 && ch[3] == 12 && L0 == 16;
+  // (the LDS a chain needs is part of the answer: on a device that cannot hold it the plan keeps the three launches)
+  if (!up) return ch[0] == 12 && ch[1] == 24 && ch[2] == 48 && ch[3] == 96 && L0 == 1024 && device_lds_fits(lds_down(12, 24, 48, 96, 1024));
+  return ch[0] == 96 && ch[1] == 48 && ch[2] == 24 && ch[3] == 12 && L0 == 16 && device_lds_fits(lds_up(96, 48, 24, 12, 16));
 }
 
 int conv1d_chain(bool up, const Chain1dStage* st, const float* in0, const float* in1, long in_bs, int pad, int B, hipStream_t s) {
@@ -297,21 +298,13 @@ int conv1d_chain(bool up, const Chain1dStage* st, const float* in0, const float*
     const size_t lds = lds_down(12, 24, 48, 96, 1024);
     auto kern = conv1d_chain_down_kernel<12, 24, 48, 96, 1024>;
     if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(kern), kChainThreads, lds, "conv1d chain (down)"))) return rc;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      (void)hipGetLastError();
-      set_last_error("conv1d_chain: cannot raise the dynamic LDS limit");
-      return LSHM_ERR_UNSUPPORTED;
-    }
+    if ((rc = raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "conv1d chain (down)"))) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(kChainThreads), lds, s, a);
   } else {
     const size_t lds = lds_up(96, 48, 24, 12, 16);
     auto kern = conv1d_chain_up_kernel<96, 48, 24, 12, 16>;
     if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(kern), kChainThreads, lds, "conv1d chain (up)"))) return rc;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      (void)hipGetLastError();
-      set_last_error("conv1d_chain: cannot raise the dynamic LDS limit");
-      return LSHM_ERR_UNSUPPORTED;
-    }
+    if ((rc = raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "conv1d chain (up)"))) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(kChainThreads), lds, s, a);
   }
   return check_launch("conv1d_chain");

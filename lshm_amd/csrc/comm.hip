@@ -11,6 +11,7 @@
 #include "kernels.h"
 
 #include <dlfcn.h>
+#include <stdio.h>
 #include <rccl/rccl.h>
 #include <stdlib.h>
 #include <string.h>
@@ -36,6 +37,8 @@ Rccl& rccl() {
     // stand-in that sums through host shared memory, so two ranks on ONE GPU can drive the engine-attached path)
     const char* override_path = getenv("LSHM_RCCL_LIB");
     if (override_path && *override_path) {
+      // (said aloud: the collectives of this process then come from a library the environment named, not from RCCL)
+      fprintf(stderr, "lshm: RCCL entry points bound from LSHM_RCCL_LIB=%s\n", override_path);
       q.handle = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
     } else {
       const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};

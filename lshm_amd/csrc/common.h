@@ -22,6 +22,11 @@ int check_launch(const char* what);  // hipGetLastError -> code + message
 // kernel variant that cannot launch is thus a return code at the call site, never a failed or aborted dispatch.
 int kernel_budget_ok(const void* kernel, int threads, size_t dyn_lds, const char* what);
 int device_lds_bytes();  // LDS a workgroup may use on the current device (0: unknown)
+// Raises the dynamic-LDS limit of `kernel` to `dyn_lds` bytes on the current device -- once per (kernel, device), remembered:
+// hipFuncSetAttribute on every launch is host time on the enqueue path.  LSHM_ERR_UNSUPPORTED (with a message) if refused.
+int raise_dynamic_lds(const void* kernel, size_t dyn_lds, const char* what);
+// true if a workgroup of the current device may hold `bytes` of LDS (unknown device: true, the launch reports it)
+inline bool device_lds_fits(size_t bytes) { const int v = device_lds_bytes(); return v <= 0 || bytes <= (size_t)v; }
 
 // A kernel's own completion signal as an event.  hipEventRecord puts a marker packet behind the last kernel of a stream,
 // and the NEXT kernel of that stream waits for the marker to retire: ~6 us of idle queue per record on the stream that
@@ -39,13 +44,27 @@ struct StopEventScope {
 };
 template <typename... KArgs, typename Tuple, size_t... I>
 inline void launch_with_stop_event(void (*kernel)(KArgs...), dim3 g, dim3 b, unsigned lds, hipStream_t st, hipEvent_t ev,
-                                   Tuple& t, std::index_sequence<I...>) {
+                                   Tuple& t, std::index_sequence<I...>, hipEvent_t start = nullptr) {
   void* ptrs[sizeof...(KArgs) ? sizeof...(KArgs) : 1] = {static_cast<void*>(&std::get<I>(t))...};
-  (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, ptrs, lds, st, nullptr, ev, 0);
+  (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), g, b, ptrs, lds, st, start, ev, 0);
 }
+// Diagnostic per-launch trace WITHOUT a profiler (lshm_trace_begin / _end / _read, include/lshm.h): while a thread records,
+// every launch it makes goes through hipExtLaunchKernel with a start and a stop event of the trace's own -- the kernel's
+// dispatch and completion timestamps, no marker packets in the queue.  A launch inside a StopEventScope additionally records
+// the scope's event behind the kernel (a marker: ~5 us of idle queue on that stream, ~25 times per iteration).
+struct LaunchTraceSlot { hipEvent_t start, stop; };
+extern thread_local bool launch_trace_on;
+bool launch_trace_take(const void* kernel, dim3 g, dim3 b, hipStream_t st, LaunchTraceSlot* slot);  // false: trace full
 template <typename... KArgs, typename... Args>
 inline void launch(void (*kernel)(KArgs...), dim3 g, dim3 b, unsigned lds, hipStream_t st, Args&&... args) {
   static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+  LaunchTraceSlot slot;
+  if (launch_trace_on && launch_trace_take(reinterpret_cast<const void*>(kernel), g, b, st, &slot)) {
+    std::tuple<KArgs...> t{static_cast<KArgs>(args)...};
+    launch_with_stop_event(kernel, g, b, lds, st, slot.stop, t, std::index_sequence_for<KArgs...>{}, slot.start);
+    if (hipEvent_t ev = launch_stop_event) { (void)hipEventRecord(ev, st); ++launch_stop_count; }
+    return;
+  }
   if (hipEvent_t ev = launch_stop_event) {
     std::tuple<KArgs...> t{static_cast<KArgs>(args)...};  // the kernel's own parameter types, as <<<>>> would convert
     launch_with_stop_event(kernel, g, b, lds, st, ev, t, std::index_sequence_for<KArgs...>{});

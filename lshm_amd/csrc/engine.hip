@@ -85,6 +85,9 @@ struct lshm_engine {
   size_t o_fpart, fwd_floats, alt_base;
   size_t o_pack2d = 0;  // fragment-ordered copy of the 2-D autoencoder's deep weights (deep2d.hip), inside the forward prefix
   bool deep2d = false;  // conv3 .. tconv3 of the 2-D autoencoder's forward as one launch
+  bool deep2d_bwd = false;  // ... and the data gradients of tconv2 .. conv2 as one launch
+  size_t o_pack2d_bwd = 0;  // the backward's fragment-ordered weight copy
+  unsigned wgrad_on_main = 0;  // which of the deep layers' weight gradients follow the data-gradient chain on ITS stream (ae_backward)
   int deep_variant = 0; // 0: one patch per workgroup (a forward alone), 1: two (two forwards side by side: each fills half of the CUs)
   size_t o_recon_part;  // per-block partial sums of the reconstruction pass (its own buffer: their seven sums may be made later, beside the backward)
   hipStream_t fstream = nullptr;  // the no-grad forward + shared reconstruction pass, beside the next closure forward
@@ -128,7 +131,7 @@ struct lshm_engine {
   bool early_ok = true;           // ranks agree on the early bucket (lshm_engine_set_early_bucket); else one group at the end
   bool in_capture = false;        // the stream of the current call is being captured (set by ENGINE_ENTER)
   unsigned last_flags = 0;        // LSHM_ENGINE_USED_*: what the last call actually did (tests)
-  const void* seen_ptr[12] = {};  // device pointers already checked to live on this engine's device
+  const void* seen_ptr[16] = {};  // device pointers already checked to live on this engine's device (ring: old entries are re-checked)
   int nseen = 0;
   unsigned seen_total = 0;
 };
@@ -263,9 +266,9 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   if (deep) {
     steps.push_back([=](float* ws, hipStream_t st) -> int {
       const AEPlan& a = A(0);
-      const Deep2dWeights w{prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw, prm + a.fc3w,
-                            prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
-      return deep2d_pack(w, ws + e->o_pack2d, st);
+      const Deep2dWeights w{prm + a.cw[2], prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw,
+                            prm + a.fc3w, prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
+      return deep2d_pack(w, ws + e->o_pack2d, 0, st);
     });
   }
   for (int i = 0; i < 6; ++i) {
@@ -541,8 +544,18 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   static const bool chain_bwd = getenv("LSHM_CHAIN_BWD_OFF") == nullptr;
   const bool chain_dec = chain_bwd && a0.ndim == 1 && conv1d_chain_supported(false, chd, a0.dec[3].Win * 4);
   const bool chain_enc = chain_bwd && a0.ndim == 1 && conv1d_chain_supported(true, chu, a0.enc[4].Win / 4);
+  // 2-D autoencoder: the data gradients of tconv2 .. conv2 (eleven layers) as one launch (deep2d.hip); their weight
+  // gradients follow behind it
+  const bool deepb = G == 1 && a0.ndim == 2 && e->deep2d_bwd && dinput[0] == nullptr;
+  if (deepb) {  // the fragment-ordered weight copy of the data-gradient pipeline (the parameters changed since the last backward)
+    const AEPlan& a = A(0);
+    const Deep2dWeights w{prm + a.cw[2], prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw,
+                          prm + a.fc3w, prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
+    if ((rc = deep2d_pack(w, ws + e->o_pack2d_bwd, 1, st))) return rc;
+  }
   // ---- decoder, last layer first
   for (int i = 5; i >= 0; --i) {
+    if (deepb && i == 2) break;
     if (chain_dec && i == 3) {
       // dz of tconv3 (12 channels) -> gradients w.r.t. the inputs of tconv3, tconv2, tconv1, each multiplied by ELU' of
       // that (saved) input; the three weight gradients follow on the other stream once the chain has written their dz
@@ -599,6 +612,8 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   }
   LinWgradIO lw[2];
   LinDgradIO ld[2];
+  int enc_from = 5;  // first encoder layer the loop below still has to differentiate
+  std::vector<std::function<int()>> main_wgrads;  // weight gradients that follow the last data-gradient kernel on `st`
   auto wgrad = [&](long ldx, long lddz, int K, int N) {
     if (jobs.batch_dense)  // only parked here (no launch, no event): grad_jobs_launch_dense runs them all
       return linear_wgrad(lw[0], ldx, lddz, B, K, N, nullptr, 0, wst, G > 1 ? &lw[1] : nullptr, &jobs);
@@ -610,14 +625,52 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // 1-D autoencoders: the four data gradients of the dense layers are one launch (dense1d.hip); the weight gradients
   // below still read the buffers it fills
   static const bool dense_bwd_on = getenv("LSHM_DENSE1D_BWD_OFF") == nullptr;
-  const bool dense_chain = dense_bwd_on && dense1d_supported(L, hd, c.rica);
+  const bool dense_chain = deepb || (dense_bwd_on && dense1d_supported(L, hd, c.rica));  // (deepb: the chain below has every dense data gradient)
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     if (dense_chain) return (int)LSHM_OK;
     return on_st([&] { return linear_dgrad(ld[0], lddz, lddx, ldxs, ldadd, add_n, B, K, N, part, pf, st, G > 1 ? &ld[1] : nullptr); });
   };
   // the latent-space gradient enters at fc3: whoever produced it beside the decoders is joined here, not earlier
   if (before_dense) { last_ev = nullptr; if ((rc = (*before_dense)())) return rc; }
-  if (dense_chain) {
+  if (deepb) {
+    const AEPlan& a = A(0);
+    const lshm_engine::Lane& la = LA(0);
+    Deep2dBwdIO io;
+    io.g_t2 = dz[0];  // = o_gdec[3]: tconv3's data gradient, the last separate launch of the decoder
+    io.s_t1 = ws + a.dact[1]; io.s_t0 = ws + a.dact[0]; io.s_cat3 = ws + a.cat3; io.s_mu = ws + e->o_Mu + a.mu_col; io.s_mu_ld = D;
+    io.gmu = ws + e->o_gMu + a.mu_col; io.gmu_ld = D; io.s_z1 = ws + a.z1; io.s_cat1 = ws + a.cat1;
+    io.s_c4 = ws + a.act[4]; io.s_c3 = ws + a.act[3]; io.s_c2 = ws + a.act[2]; io.s_c1 = ws + a.act[1];
+    io.g_t1 = ws + la.o_gdec[2]; io.g_t0 = ws + la.o_gdec[1]; io.g_d0 = ws + la.o_dd0; io.g_cat3 = ws + la.o_dcat3;
+    io.g_mu = ws + la.o_dzmu; io.g_mu_ld = L; io.g_z1 = ws + la.o_dz1; io.g_cat1 = ws + la.o_dcat1;
+    io.g_c4 = ws + la.o_genc[5]; io.g_c3 = ws + la.o_genc[4]; io.g_c2 = ws + la.o_genc[3]; io.g_c1 = ws + la.o_genc[2];
+    if ((rc = on_st([&] { return deep2d_bwd(io, ws + e->o_pack2d_bwd, B, 0, st); }))) return rc;
+    // every dz of the eleven layers exists now: their weight gradients, released together
+    // ... between the two streams: the data-gradient stream has only conv1's one-pass backward left, so a share of the
+    // weight gradients follows that kernel there (bit k of the placement word: item k on the data-gradient stream)
+    const bool batch_conv = !(c.schedule & LSHM_SCHED_NO_WGRAD_BATCH);
+    const unsigned on_main = (side && !batch_conv) ? e->wgrad_on_main : 0u;
+    int item = 0;
+    auto conv_w = [&](const ConvLayer& Lr, const float* xin, const float* dzp, long wo, long bo) {
+      const ConvWgradIO w0{xin, dzp, grd + wo, grd + bo};
+      if ((on_main >> item++) & 1u) main_wgrads.push_back([&jobs, &Lr, w0, st]() { return conv_layer_wgrad(Lr, w0, nullptr, 0, 0, st, nullptr, &jobs); });
+      else pending.push_back([&jobs, &Lr, w0, wst]() { return conv_layer_wgrad(Lr, w0, nullptr, 0, 0, wst, nullptr, &jobs); });
+    };
+    conv_w(a0.dec[2], ws + a.dact[1], dz[0], a.tw[2], a.tb[2]);
+    conv_w(a0.dec[1], ws + a.dact[0], ws + la.o_gdec[2], a.tw[1], a.tb[1]);
+    conv_w(a0.dec[0], ws + a.d0, ws + la.o_gdec[1], a.tw[0], a.tb[0]);
+    conv_w(a0.enc[5], ws + a.act[4], ws + la.o_dcat1, a.cw[5], a.cb[5]);
+    conv_w(a0.enc[4], ws + a.act[3], ws + la.o_genc[5], a.cw[4], a.cb[4]);
+    conv_w(a0.enc[3], ws + a.act[2], ws + la.o_genc[4], a.cw[3], a.cb[3]);
+    conv_w(a0.enc[2], ws + a.act[1], ws + la.o_genc[3], a.cw[2], a.cb[2]);
+    // the six implicit-GEMM ones park their problems; one launch runs them all
+    jobs.batch_conv = batch_conv;
+    // ... on the DATA-gradient stream, behind conv1's one-pass backward (the only kernel that stream has left): the
+    // weight-gradient stream meanwhile runs conv2's and conv0's direct kernels and the dense batch, and one round of closing
+    // sums ends the pass (the two streams finish ~100 us after the chain instead of ~250)
+    if (jobs.batch_conv) main_wgrads.push_back([&jobs, st, wst, side]() { return grad_jobs_launch_conv(jobs, side ? st : wst); });
+    enc_from = 1;
+  }
+  if (dense_chain && !deepb) {
     Dense1dBwdIO io[2];
     for (int g = 0; g < G; ++g)
       io[g] = Dense1dBwdIO{ws + LA(g).o_dd0, ws + A(g).cat3, ws + e->o_Mu + A(g).mu_col, ws + e->o_gMu + A(g).mu_col, ws + A(g).z1,
@@ -664,11 +717,11 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // tail after the last weight gradient then only has the encoder's
   pending.push_back([&]() { return grad_jobs_launch_dense(jobs, wst); });
   if ((rc = release(true))) return rc;
-  if (side && (rc = grad_jobs_finish(jobs, wst))) return rc;
+  if (side && !deepb && (rc = grad_jobs_finish(jobs, wst))) return rc;  // (deepb: everything that is left is short; one round at the end)
   // ---- encoder
   bool fused_tail = false;  // a fused kernel on `st` wrote partials that the closing sums on `wst` have not been ordered behind yet
-  for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_dcat1;
-  for (int i = 5; i >= 0; --i) {
+  for (int g = 0; g < G; ++g) dz[g] = enc_from == 5 ? ws + LA(g).o_dcat1 : ws + LA(g).o_genc[enc_from + 1];
+  for (int i = enc_from; i >= 0; --i) {
     if (chain_enc && i == 4) {
       // dz of conv4 (96 channels) -> gradients w.r.t. the inputs of conv4, conv3, conv2 (x ELU' of the saved inputs)
       Chain1dStage cs[3];
@@ -724,6 +777,11 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     if (i == 0 && !dinput[0]) break;
     if ((rc = on_st([&] { return conv_layer_dgrad(a0.enc[i], dg[0], part, pf, st, G > 1 ? &dg[1] : nullptr); }))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = dx[g];
+  }
+  if (!main_wgrads.empty()) {
+    for (auto& f : main_wgrads) if ((rc = f())) return rc;
+    fused_tail = true;  // their partials are on `st`: the closing sums on `wst` wait for an event recorded behind them
+    last_ev = nullptr;
   }
   if (fused_tail && (rc = dz_ready())) return rc;
   return grad_jobs_finish(jobs, wst);
@@ -1141,8 +1199,8 @@ static int device_fence(lshm_engine* e, hipStream_t st, std::initializer_list<co
                                                     : "engine: an argument lives on another device than the engine");
       return LSHM_ERR_ARG;
     }
-    e->seen_ptr[e->seen_total++ % 12] = q;
-    if (e->nseen < 12) ++e->nseen;
+    e->seen_ptr[e->seen_total++ % 16] = q;
+    if (e->nseen < 16) ++e->nseen;
   }
   return LSHM_OK;
 }
@@ -1295,6 +1353,9 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     la.o_dd0 = take(cur, (size_t)B * 768);
   }
   e->o_dMscratch = take(cur, (size_t)cfg->K * e->D);
+  e->deep2d_bwd = e->deep2d && !(cfg->schedule & LSHM_SCHED_NO_DEEP2D_BWD);
+  e->wgrad_on_main = cfg->tune ? cfg->tune - 1 : 0u;  // (experimental placement word: lshm_step_config.tune, 0 = shipped)
+  if (e->deep2d_bwd) e->o_pack2d_bwd = take(cur, deep2d_packed_floats());
   e->o_recon_part = take(cur, recon_partials_floats(B * cfg->C, cfg->P));
   e->latent_ws_floats = khm_workspace_floats(B, e->D, cfg->K);
   e->o_latent_ws = take(cur, e->latent_ws_floats);
@@ -1418,6 +1479,8 @@ int lshm_engine_device(const lshm_engine* e) { return e ? e->device : -1; }
 int lshm_engine_phase_times(const lshm_engine* e, float* ms, int n) {
   if (!e || !ms || n < 1) { set_last_error("engine_phase_times: bad argument"); return LSHM_ERR_ARG; }
   if (e->phase.empty()) { set_last_error("engine_phase_times: the engine was created without LSHM_PHASE_EVENTS=1"); return LSHM_ERR_UNSUPPORTED; }
+  EngineCall scope(e);  // the events live on the engine's device, whatever device is current in the caller
+  if (!scope.ok) { set_last_error("engine: cannot make the engine's device current"); return LSHM_ERR_ARG; }
   if (hipDeviceSynchronize() != hipSuccess) { set_last_error("engine_phase_times: device synchronisation failed"); return LSHM_ERR_ARG; }
   for (int i = 0; i < n; ++i) {
     ms[i] = -1.f;  // an event that was never recorded (a phase this schedule does not have)
@@ -1452,14 +1515,18 @@ int lshm_engine_forward_backward_ex(lshm_engine* e, const float* params, float* 
   ENGINE_CHECK(e && params && grads && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_backward: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st, params, grads, x, uv, y1, ws, terms);
+  ENGINE_ENTER(e, st, params, grads, x, uv, y1, y2, y3, ws, terms);
   e->next_event = 0;
   // the forward below is recomputed either way; only the reconstruction pass can be the one the preceding
   // lshm_engine_multiplier_update_next already made with the same inputs
   const bool recon_done = (flags & LSHM_STEP_RECON_READY) && e->recon_ready;
+  int rc;
+  // (after lshm_engine_multiplier_update_next_ex(LSHM_NEXT_CONCURRENT_FORWARD) the seven sums of that pass exist only as
+  //  per-block partials; the forward below forgets them, so they are closed first)
+  if (recon_done && (rc = pending_sum7(e, ws, st))) return rc;
   // ... and with it done, nothing reads the reconstructions of netT / netF (the workspace keeps the identical
   // ones of the preceding no-grad forward)
-  int rc = forward_with_latent_losses(e, params, grads, x, uv, ws, st, recon_done);
+  rc = forward_with_latent_losses(e, params, grads, x, uv, ws, st, recon_done);
   if (rc) return rc;
   return losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st, recon_done);
 }
@@ -1476,7 +1543,7 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
   ENGINE_CHECK(e && params && grads && x && y1 && y2 && y3 && terms && ws, "engine_backward_saved: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st, params, grads, x, y1, ws, terms);
+  ENGINE_ENTER(e, st, params, grads, x, y1, y2, y3, ws, terms);
   e->next_event = 0;
   const bool recon_done = e->recon_ready;
   e->recon_ready = false;
@@ -1494,7 +1561,7 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update_next: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st, params, x, uv, y1, ws);
+  ENGINE_ENTER(e, st, params, x, uv, y1, y2, y3, ws);
   e->next_event = 0;
   e->recon_ready = false;
   const lshm_step_config& c = e->cfg;
@@ -1568,7 +1635,7 @@ int lshm_engine_forward_loss(lshm_engine* e, const float* params, const float* x
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && terms && ws, "engine_forward_loss: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st, params, x, uv, y1, ws, terms);
+  ENGINE_ENTER(e, st, params, x, uv, y1, y2, y3, ws, terms);
   e->next_event = 0;
   int rc = forward_with_latent_losses(e, params, nullptr, x, uv, ws, st);
   if (rc) return rc;
@@ -1581,7 +1648,7 @@ int lshm_engine_multiplier_update(lshm_engine* e, const float* params, const flo
   ENGINE_CHECK(e && params && x && uv && y1 && y2 && y3 && ws, "engine_multiplier_update: null pointer");
   if (wsf < e->ws_floats) { set_last_error("engine: workspace too small"); return LSHM_ERR_WORKSPACE; }
   hipStream_t st = reinterpret_cast<hipStream_t>(s);
-  ENGINE_ENTER(e, st, params, x, uv, y1, ws);
+  ENGINE_ENTER(e, st, params, x, uv, y1, y2, y3, ws);
   e->next_event = 0;
   int rc = three_forward(e, params, x, uv, ws, st);
   if (rc) return rc;

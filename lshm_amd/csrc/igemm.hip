@@ -1100,6 +1100,66 @@ int strided_gemm_batch_mm(const StridedGemmParams* probs, int n, hipStream_t st)
   return LSHM_OK;
 }
 
+// The weight gradients of the deep 2-D layers (tconv2..0, conv5..3: 15-30 us launches each, a few workgroup waves of
+// latency-bound K loops, one after the other on the weight-gradient stream) as ONE launch: 64 x 64 tiles, K split so that
+// every problem brings a few hundred workgroups, slabs summed by the backward's job list like any other split.
+int grad_jobs_launch_conv(GradJobs& jobs, hipStream_t st) {
+  using P = Conv2dWgrad;
+  constexpr int BM = 64, BN = 64, BK = 16;
+  const int n = (int)jobs.conv2d.size();
+  if (n == 0) return LSHM_OK;
+  const long target = 2304 / n > 192 ? 2304 / n : 192;  // workgroups per problem (~9 per CU in all)
+  for (int base = 0; base < n; base += kMaxBatch) {
+    const int cnt = n - base < kMaxBatch ? n - base : kMaxBatch;
+    Batch<P> bp;
+    int tiles = 0;
+    for (int g = 0; g < kMaxBatch; ++g) {
+      const GradJobs::ParkedConv2d& q = jobs.conv2d[base + (g < cnt ? g : 0)];
+      bp.p[g] = q.p;
+      const int M = q.p.M, N = q.p.N;
+      bp.mt[g] = cdiv(M, BM);
+      bp.nt[g] = cdiv(N, BN);
+      const long tmn = (long)bp.mt[g] * bp.nt[g];
+      SplitPlan sp{1, (q.p.K + BK - 1) / BK * BK};
+      if (g < cnt && q.ws && q.wsf) {
+        long want = (target + tmn - 1) / tmn;
+        const long maxs = q.p.K / 64;
+        if (want > maxs) want = maxs;
+        const long per = (long)((M + 3) & ~3) * N;
+        if (per * want > (long)q.wsf) want = (long)q.wsf / per;
+        if (want > 1) {
+          int kc = (int)((q.p.K + want - 1) / want);
+          kc = (kc + BK - 1) / BK * BK;
+          const int splits = (q.p.K + kc - 1) / kc;
+          if (splits > 1) sp = SplitPlan{splits, kc};
+        }
+      }
+      bp.p[g].sk.partial = sp.splits > 1 ? q.ws : nullptr;
+      bp.p[g].sk.splits = sp.splits;
+      bp.p[g].sk.kchunk = sp.kchunk;
+      bp.first[g] = tiles;
+      if (g < cnt) {
+        tiles += (int)tmn * sp.splits;
+        if (sp.splits > 1) {
+          const long Mp = (M + 3) & ~3;
+          SumJob J{q.ws, nullptr, (long)N * Mp, (int)(N * Mp), sp.splits, (int)Mp, M, 0, 0, 0, 0};
+          describe_output(bp.p[g], J);
+          jobs.sums.push_back(J);
+        }
+      }
+    }
+    bp.first[kMaxBatch] = tiles;
+    for (int g = cnt; g < kMaxBatch; ++g) bp.first[g] = tiles;
+    bp.n = cnt;
+    int rc = kernel_budget_ok(reinterpret_cast<const void*>(&igemm_batch_kernel<P, BM, BN, BK, 0, false>), 256, 0, "igemm batch (conv2d wgrad)");
+    if (rc) return rc;
+    hipLaunchKernelGGL((igemm_batch_kernel<P, BM, BN, BK, 0, false>), dim3(tiles), dim3(256), 0, st, bp);
+    if ((rc = check_launch("igemm_batch_conv"))) return rc;
+  }
+  jobs.conv2d.clear();
+  return LSHM_OK;
+}
+
 size_t igemm_workspace_floats(int M, int N, int K, int zgroups) {
   // enough for the largest split the planner may choose (768 tiles' worth of slabs)
   const long Mp = (M + 3) & ~3;
@@ -1134,6 +1194,10 @@ int conv2d_wgrad(const Conv2dWgradParams& p, float* ws, size_t wsf, hipStream_t 
                  GradJobs* defer) {
   if (!fits32(span(p.s_bs, p.B, (long)p.Cs * p.Hs * p.Ws), span(p.big_bs, p.B, (long)p.Cb * p.Hs * p.Ws * 4)))
     return LSHM_ERR_UNSUPPORTED;
+  if (defer && defer->batch_conv && !p1 && !p.accumulate && !t_matrix_bf16 && g_tune_force < 0) {
+    defer->conv2d.push_back(GradJobs::ParkedConv2d{p, ws, wsf});  // launched with the others: grad_jobs_launch_conv
+    return LSHM_OK;
+  }
   return launch_auto<Conv2dWgrad>(p, p1, p.M, p.N, 1, ws, wsf, st, defer);
 }
 int conv1d_fwd(const Conv1dFwdParams& p, float* ws, size_t wsf, hipStream_t st, const Conv1dFwdParams* p1) {

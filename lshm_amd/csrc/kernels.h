@@ -102,6 +102,9 @@ struct GradJobs {
   std::vector<SumJob> sums;
   std::vector<StridedGemmParams> dense;  // dense-layer weight gradients waiting for their one shared launch
   bool batch_dense = false;              // linear_wgrad parks its GEMM here instead of launching it
+  struct ParkedConv2d { Conv2dWgradParams p; float* ws; size_t wsf; };
+  std::vector<ParkedConv2d> conv2d;      // implicit-GEMM weight gradients of 2-D layers waiting for their one shared launch
+  bool batch_conv = false;               // conv2d_wgrad parks its problem here instead of launching it (grad_jobs_launch_conv)
   float* scratch = nullptr;
   size_t cap = 0, used = 0;
   float* take(size_t n) {
@@ -116,6 +119,7 @@ struct GradJobs {
 };
 int grad_jobs_finish(GradJobs& jobs, hipStream_t st);
 int grad_jobs_launch_dense(GradJobs& jobs, hipStream_t st);  // the parked dense weight gradients, one launch
+int grad_jobs_launch_conv(GradJobs& jobs, hipStream_t st);   // the parked 2-D conv weight gradients, one launch (split-K slabs join the job list)
 
 // ws / wsf: optional split-K scratch (null: never split)
 // p1 (optional): a second problem of identical shape run in the same launch (ws is split in two)

@@ -67,6 +67,19 @@ class Communicator:
         if rc0:
             raise RuntimeError(f"lshm_amd: comm_unique_id failed on rank 0 (code {rc0}): {msg0}")
         self.device = torch.device(device if device is not None else ("cuda", torch.cuda.current_device()))
+        # ncclCommInitRank is itself a collective: a rank that cannot even ENTER it (library or symbols missing, device
+        # not usable) would leave the others blocked inside it, so everything that can fail locally is agreed on first.
+        # (A failure INSIDE the collective bring-up is bounded only by the process group's timeout.)
+        local_ok = bool(self.lib.lshm_comm_available())
+        if local_ok:
+            try:
+                with L.on_device(self.device):
+                    torch.empty(1, device=self.device)
+            except Exception:
+                local_ok = False
+        if not agree(local_ok, group if self.world > 1 else None, self.world):
+            self.handle = None
+            raise RuntimeError("lshm_amd: RCCL (or the device) is not usable on " + ("this rank" if not local_ok else "another rank"))
         h = C.c_void_p()
         with L.on_device(self.device):
             rc = self.lib.lshm_comm_init(raw, self.rank, self.world, C.byref(h))

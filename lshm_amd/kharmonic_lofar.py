@@ -88,6 +88,7 @@ class TrainConfig:
     # restores the launch sequence the choice replaced -- for A/B measurements and the tests that hold a fused kernel's
     # trajectory to the launches it replaced.  Per trainer (lshm_step_config.schedule), not per process.
     schedule_off: Tuple[str, ...] = ()
+    tune: int = 0  # lshm_step_config.tune (experimental placement word of A/B measurements; 0 = shipped)
 
 
 class KHarmonicTrainer:
@@ -130,6 +131,7 @@ class KHarmonicTrainer:
         sc.schedule = 0
         for name in cfg.schedule_off:
             sc.schedule |= L.SCHEDULE_BITS[name]
+        sc.tune = int(cfg.tune)
         self._sc = sc
         h = C.c_void_p()
         # the engine's side stream and events are created on the device that is current now, and every
@@ -352,7 +354,14 @@ class KHarmonicTrainer:
         with L.on_device(self.device):
             torch.cuda.current_stream(self.device).wait_event(self._staged)
             self._staged = None
-            (self.x, self.uv), self._stage = self._stage, (self.x, self.uv)
+            if self._graph is not None:
+                # a captured iteration has the ADDRESSES of x and uv baked into its kernel arguments: trading the
+                # tensors would replay it on the old pair, which the next prefetch overwrites.  Copy into the fixed
+                # pair instead (device to device, behind the wait above; the staging pair is free again afterwards).
+                self.x.copy_(self._stage[0])
+                self.uv.copy_(self._stage[1])
+            else:
+                (self.x, self.uv), self._stage = self._stage, (self.x, self.uv)
             for t in self.y:
                 t.zero_()
         self.invalidate_forward()

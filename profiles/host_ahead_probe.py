@@ -28,3 +28,15 @@ for rep in range(3):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print(f"host enqueue {1e3 * (t1 - t0) / N:.3f} ms/iteration, with device {1e3 * (t2 - t0) / N:.3f} ms/iteration")
+# per phase: host time of the three calls of an iteration (closure backward | Adam | forwards + reconstruction pass)
+acc = [0.0, 0.0, 0.0]
+torch.cuda.synchronize()
+for _ in range(N):
+    t0 = time.perf_counter(); tr._closure_fwd_bwd()
+    t1 = time.perf_counter(); tr._adam()
+    t2 = time.perf_counter(); tr._multipliers()
+    t3 = time.perf_counter()
+    acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2
+torch.cuda.synchronize()
+print("host time per call: closure (backward of the saved forward) %.3f ms, Adam %.3f ms, multiplier update + next forwards %.3f ms"
+      % tuple(1e3 * a / N for a in acc))

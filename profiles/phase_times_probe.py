@@ -10,7 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lshm_amd import KHarmonicTrainer, TrainConfig, _lib as L
 
 B, dev = 256, torch.device("cuda:0")
-cfg = TrainConfig(Kc=10)
+cfg = TrainConfig(Kc=10, schedule_off=tuple(n for n in os.environ.get("PROBE_SCHEDULE_OFF", "").split(",") if n),
+                  tune=int(os.environ.get("PROBE_TUNE", 0)))
 tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=8, default_batch=B // 8, device=dev)
 tr.init_parameters(seed=0)
 gen = torch.Generator(device="cpu").manual_seed(1234)

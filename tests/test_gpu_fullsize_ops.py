@@ -542,3 +542,127 @@ def test_deep_section_variants_agree_bit_for_bit():
         res.append([o.clone() for o in outs])
     for k in range(11):
         assert torch.equal(res[0][k], res[1][k]) and torch.equal(res[0][k], res[2][k]), k
+
+
+def _eg(y):
+    """ELU'(x) from the saved output y = ELU(x)."""
+    return torch.where(y > 0, torch.ones_like(y), y + 1.0)
+
+
+def _deep2d_bwd_reference(w, saved, g_t2, gmu, dt):
+    """The data-gradient pass through tconv2 .. conv2 of AutoEncoderCNN2 written out: the data gradient of a k4 s2 p1
+    transposed conv is the conv with the same tensor and vice versa (autograd of src/lofar_models.py:73-98)."""
+    c = lambda t: t.to(dt)
+    c2, c3, c4, c5, fc1, fc2in, fc2out, fc3, t0, t1, t2, _t3 = [c(t) for t in w]
+    s_t1, s_t0, s_cat3, s_mu, s_z1, s_cat1, s_c4, s_c3, s_c2, s_c1 = [c(t) for t in saved]
+    g_t1 = TF.conv2d(c(g_t2), t2, None, stride=2, padding=1) * _eg(s_t1)
+    g_t0 = TF.conv2d(g_t1, t1, None, stride=2, padding=1) * _eg(s_t0)
+    g_d0 = TF.conv2d(g_t0, t0, None, stride=2, padding=1).flatten(1)
+    g_cat3 = (g_d0 @ fc3) * _eg(s_cat3)
+    g_mu = g_cat3[:, :224] @ fc2out
+    if gmu is not None:
+        g_mu = g_mu + c(gmu)
+    g_mu = g_mu * _eg(s_mu)
+    g_z1 = (g_mu @ fc2in) * _eg(s_z1)
+    g_cat1 = (g_z1 @ fc1) * _eg(s_cat1)
+    g_c4 = TF.conv_transpose2d(g_cat1[:, :768].reshape(-1, 192, 2, 2), c5, None, stride=2, padding=1) * _eg(s_c4)
+    g_c3 = TF.conv_transpose2d(g_c4, c4, None, stride=2, padding=1) * _eg(s_c3)
+    g_c2 = TF.conv_transpose2d(g_c3, c3, None, stride=2, padding=1) * _eg(s_c2)
+    g_c1 = TF.conv_transpose2d(g_c2, c2, None, stride=2, padding=1) * _eg(s_c1)
+    return [g_t1, g_t0, g_d0, g_cat3, g_mu, g_z1, g_cat1, g_c4, g_c3, g_c2, g_c1]
+
+
+def _deep2d_bwd_problem(nb, seed):
+    g = torch.Generator().manual_seed(seed)
+    L, hd = 224, 16
+    rn = lambda *s, scale=1.0: torch.randn(*s, generator=g) * scale
+    w = [rn(24, 12, 4, 4, scale=(3.0 / (24 * 4)) ** 0.5), rn(48, 24, 4, 4, scale=(3.0 / (48 * 4)) ** 0.5),
+         rn(96, 48, 4, 4, scale=(3.0 / (96 * 4)) ** 0.5), rn(192, 96, 4, 4, scale=(3.0 / (192 * 4)) ** 0.5),
+         rn(L, 768 + hd, scale=(3.0 / L) ** 0.5), rn(L, L, scale=(3.0 / L) ** 0.5), rn(L, L, scale=(3.0 / L) ** 0.5),
+         rn(768, L + hd, scale=(3.0 / 768) ** 0.5), rn(192, 96, 4, 4, scale=(3.0 / (96 * 16)) ** 0.5),
+         rn(96, 48, 4, 4, scale=(3.0 / (48 * 16)) ** 0.5), rn(48, 24, 4, 4, scale=(3.0 / (24 * 16)) ** 0.5), rn(24, 12, 4, 4)]
+    shapes = [(nb, 48, 8, 8), (nb, 96, 4, 4), (nb, L + hd), (nb, L), (nb, L), (nb, 768 + hd), (nb, 96, 4, 4), (nb, 48, 8, 8),
+              (nb, 24, 16, 16), (nb, 12, 32, 32)]
+    saved = [TF.elu(rn(*s)) for s in shapes]
+    g_t2 = rn(nb, 24, 16, 16)
+    gmu = rn(nb, L)
+    return w, saved, g_t2, gmu
+
+
+@pytest.mark.parametrize("variant,nb", [(0, 256), (1, 256), (0, 5), (1, 5)], ids=["one-patch", "two-patches", "one-patch-ragged", "two-patches-ragged"])
+def test_deep_section_backward_as_one_launch(variant, nb):
+    """lshm_deep2d_bwd: the data gradients of tconv2, tconv1, tconv0, fc3, fc2out (+ the latent-term gradient), fc2in, fc1,
+    conv5, conv4, conv3, conv2 of AutoEncoderCNN2 (autograd of src/lofar_models.py:73-98) from ONE launch -- the forward's
+    eleven-stage pipeline on the layers' own weight tensors -- against fp64 and against the separate data-gradient launches
+    of the library, every stage's output."""
+    import ctypes as C
+    from lshm_amd import _lib as L
+    lib = L.load()
+    Ld, hd = 224, 16
+    w, saved, g_t2, gmu = _deep2d_bwd_problem(nb, 31 + variant)
+    wd, sd = [t.to(DEV) for t in w], [t.to(DEV) for t in saved]
+    mu_buf = torch.zeros(nb, 256, device=DEV)  # the code lives inside the shared latent matrix (row pitch 256)
+    mu_buf[:, :Ld] = sd[3]
+    sd_call = list(sd)
+    sd_call[3] = mu_buf
+    gd, gmud = g_t2.to(DEV), gmu.to(DEV)
+    oshapes = [(nb, 48, 8, 8), (nb, 96, 4, 4), (nb, 768), (nb, Ld + hd), (nb, Ld), (nb, Ld), (nb, 768 + hd), (nb, 96, 4, 4), (nb, 48, 8, 8),
+               (nb, 24, 16, 16), (nb, 12, 32, 32)]
+    packed = torch.empty(lib.lshm_deep2d_packed_floats(), device=DEV)
+    arr = lambda ts: (C.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+
+    def run(with_gmu):
+        outs = [torch.full(s, float("nan"), device=DEV) for s in oshapes]
+        L.check(lib.lshm_deep2d_bwd(L.ptr(gd), arr(wd), arr(sd_call), 256, L.ptr(gmud) if with_gmu else None, Ld, arr(outs), L.ptr(packed),
+                                    nb, variant, L.stream()), "deep2d_bwd")
+        torch.cuda.synchronize()
+        return outs
+
+    got = run(True)
+    for k, o in enumerate(got):
+        assert torch.isfinite(o).all(), k
+    idx = [i for i in SAMPLES if i < nb] if nb > 5 else list(range(nb))
+    ref = _deep2d_bwd_reference(w, [t[idx] for t in saved], g_t2[idx], gmu[idx], torch.float64)
+    for k, (o, r) in enumerate(zip(got, ref)):
+        assert rel_err(o[idx].cpu().double().reshape(r.shape), r) < 3e-5, (variant, k)
+    # the separate launches of the library (no latent-term gradient: the C entry of the dense data gradient has no addend)
+    got0 = run(False)
+    st = L.stream()
+    sep = []
+    cur = gd
+    for wi, si, (cin, cout, hin) in [(10, 0, (48, 24, 8)), (9, 1, (96, 48, 4)), (8, None, (192, 96, 2))]:  # data gradients of tconv2, tconv1, tconv0
+        dx = torch.empty(nb, cin, hin, hin, device=DEV)
+        nws = lib.lshm_conv_workspace_floats(1, nb, cin, cout, hin, hin)
+        ws = torch.empty(max(nws, 1), device=DEV)
+        L.check(lib.lshm_conv_dgrad(1, L.ptr(cur), L.ptr(wd[wi]), L.ptr(dx), L.ptr(sd[si]) if si is not None else None, nb, cin, cout, hin, hin,
+                                    0, 0, L.ptr(ws), nws, st), "tconv_dgrad")
+        sep.append(dx)
+        cur = dx
+    sep[2] = sep[2].reshape(nb, 768)
+
+    def lin_dgrad(dz, lddz, wi, K, N, xs, ldxs):
+        dx = torch.empty(nb, K, device=DEV)
+        nws = lib.lshm_linear_workspace_floats(nb, K, N)
+        ws = torch.empty(max(nws, 1), device=DEV)
+        L.check(lib.lshm_linear_dgrad(L.ptr(dz), lddz, L.ptr(wd[wi]), L.ptr(dx), K, L.ptr(xs), ldxs, nb, K, N, L.ptr(ws), nws, st), "linear_dgrad")
+        return dx
+
+    g_cat3 = lin_dgrad(sep[2], 768, 7, Ld + hd, 768, sd[2], Ld + hd)
+    g_mu = lin_dgrad(g_cat3, Ld + hd, 6, Ld, Ld, mu_buf, 256)
+    g_z1 = lin_dgrad(g_mu, Ld, 5, Ld, Ld, sd[4], Ld)
+    g_cat1 = lin_dgrad(g_z1, Ld, 4, 768 + hd, Ld, sd[5], 768 + hd)
+    sep += [g_cat3, g_mu, g_z1, g_cat1]
+    cur = g_cat1  # (B, 784): the conv5 gradient is its first 768 columns, batch stride 784
+    in_bs = 768 + hd
+    for wi, si, (cin, cout, hin) in [(3, 6, (96, 192, 4)), (2, 7, (48, 96, 8)), (1, 8, (24, 48, 16)), (0, 9, (12, 24, 32))]:  # conv5 .. conv2
+        dx = torch.empty(nb, cin, hin, hin, device=DEV)
+        nws = lib.lshm_conv_workspace_floats(0, nb, cin, cout, hin, hin)
+        ws = torch.empty(max(nws, 1), device=DEV)
+        L.check(lib.lshm_conv_dgrad(0, L.ptr(cur), L.ptr(wd[wi]), L.ptr(dx), L.ptr(sd[si]), nb, cin, cout, hin, hin, 0, in_bs, L.ptr(ws),
+                                    nws, st), "conv_dgrad")
+        sep.append(dx)
+        cur = dx
+        in_bs = 0
+    torch.cuda.synchronize()
+    for k, (o, r) in enumerate(zip(got0, sep)):
+        assert rel_err(o, r.reshape(o.shape)) < 2e-5, (variant, k)

@@ -129,6 +129,31 @@ def test_graph_replay_matches_eager():
     assert torch.equal(tr.y[2], tr2.y[2])
 
 
+def test_graph_replay_across_a_swapped_in_minibatch_matches_eager():
+    """A captured iteration has the addresses of x and uv in its kernel arguments: swap_in_minibatch() must not trade
+    the tensors under it (the replay would then read the staging pair the next prefetch overwrites) -- with a graph it
+    copies into the fixed pair.  Eager trainer with blocking copies vs graph trainer with prefetch + swap, bit for bit,
+    while a third minibatch is already being uploaded."""
+    tr, ocfg, params, M, x, uv = _trainer(4, 4, 2, 2)
+    tr2, *_ = _trainer(4, 4, 2, 2)
+    tr2.capture_graph()
+    x_ptr, uv_ptr = tr2.x.data_ptr(), tr2.uv.data_ptr()
+    batches = [(0.5 * x.flip(0), uv.flip(0)), (1.25 * x, 0.5 * uv), (x.roll(1, 0), uv.roll(1, 0))]
+    tr2.prefetch_minibatch(batches[0][0].pin_memory(), batches[0][1].pin_memory())
+    for mb, (xb, uvb) in enumerate(batches):
+        tr.new_minibatch(xb.to(DEV), uvb.to(DEV))
+        tr2.swap_in_minibatch()
+        assert (tr2.x.data_ptr(), tr2.uv.data_ptr()) == (x_ptr, uv_ptr)
+        if mb + 1 < len(batches):  # the next upload overwrites the staging pair while the replays below run
+            tr2.prefetch_minibatch(batches[mb + 1][0].pin_memory(), batches[mb + 1][1].pin_memory())
+        for _ in range(2):
+            tr.step()
+            tr2.step()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.params, tr2.params)
+    assert all(torch.equal(a, b) for a, b in zip(tr.y, tr2.y))
+
+
 def test_state_dict_roundtrip_with_modules():
     from lshm_amd.lofar_models import AutoEncoder1DCNN, AutoEncoderCNN2, Kmeans
     tr, *_ = _trainer(4, 4, 2, 2)
