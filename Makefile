@@ -16,6 +16,8 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/kernels.h include/lshm.h
 
 # headers of single kernel families (kept out of kernels.h, which rebuilds everything)
 $(OBJDIR)/deep2d.o $(OBJDIR)/capi.o $(OBJDIR)/engine.o: $(CSRC)/deep2d.h
+$(OBJDIR)/chain1d_full.o $(OBJDIR)/capi.o $(OBJDIR)/engine.o: $(CSRC)/chain1d_full.h
+$(OBJDIR)/chain1d.o $(OBJDIR)/chain1d_full.o: $(CSRC)/chain1d_dev.h
 
 $(LIB): $(OBJS)
 	@mkdir -p lshm_amd/lib

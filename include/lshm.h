@@ -162,6 +162,15 @@ int lshm_dense2d_fwd(int L, const float* cat1, const float* const* wb, float* z1
 int lshm_dense2d_bwd(int L, const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
                      const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
                      lshm_stream_t stream);
+/* The whole mid + deep section of AutoEncoder1DCNN(latent_dim=16, rica=True)'s forward as ONE launch (src/lofar_models.py:
+ * 119-135,137-140 and the forward :158-183): conv2 -> conv3 -> conv4 -> conv5 -> fc1 -> fc2in -> fc2out -> fc3 -> tconv0 -> tconv1 ->
+ * tconv2 -> tconv3, one workgroup per patch, activations resident in LDS.  x1 (B,12,1024) = conv1's output; w[12] / bias[12] in
+ * that order, torch layouts; out[12] = {conv2 (B,24,256), conv3 (B,48,64), conv4 (B,96,16), cat1 (B,784: columns 0..767 written,
+ * 768..783 = elu(fcuv1(uvh)) must be there), z1 (B,16), mu (B,16 inside a (B,ldmu) matrix), cat3 (B,32: columns 0..15 written,
+ * 16..31 = elu(fcuv3(uvh)) must be there), d0 (B,768), tconv0 (B,96,16), tconv1 (B,48,64), tconv2 (B,24,256), tconv3 (B,12,1024)}.
+ * stamps: diagnostics, may be NULL (64 device int64). */
+int lshm_chain1d_full_fwd(const float* x1, const float* const* w, const float* const* bias, float* const* out, long ldmu, int B,
+                          long long* stamps, lshm_stream_t stream);
 /* ---- diagnostics: a per-launch trace of the calling thread WITHOUT a profiler.  Between lshm_trace_begin and lshm_trace_end
  * every kernel this thread launches through the library carries a start and a stop event of the trace's own
  * (hipExtLaunchKernel: the kernel's dispatch and completion timestamps, no marker packets), so the timeline of the
@@ -425,6 +434,11 @@ typedef struct lshm_step_config {
 #define LSHM_SCHED_NO_DEEP2D_BWD (1u << 1)
 /* the implicit-GEMM weight gradients of the 2-D autoencoder's deep layers as six launches instead of one batched launch */
 #define LSHM_SCHED_NO_WGRAD_BATCH (1u << 2)
+/* EXPERIMENT, off unless set: conv2 .. tconv3 of the 1-D autoencoders' forward as ONE launch per pair (chain1d_full.hip) instead of
+ * five (two three-layer chains, conv5, the dense middle, tconv0).  Measured slower in the step (profiles/r04/README.md): a
+ * workgroup per (patch, network) re-reads conv5's and tconv0's weights from L2 for every patch and runs them on 6-12 of its
+ * 16 wavefronts, 55 us per workgroup wave where the five launches overlap with the other forward. */
+#define LSHM_SCHED_TRY_FULL1D (1u << 3)
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);
 void lshm_engine_destroy(lshm_engine* e);

@@ -37,8 +37,8 @@ class StepConfig(C.Structure):
 
 
 PRECISION_F32, PRECISION_BF16_OPERANDS, PRECISION_BF16_STORAGE = 0, 1, 2
-SCHED_NO_DEEP2D, SCHED_NO_DEEP2D_BWD, SCHED_NO_WGRAD_BATCH = 1 << 0, 1 << 1, 1 << 2
-SCHEDULE_BITS = {"no_deep2d": SCHED_NO_DEEP2D, "no_deep2d_bwd": SCHED_NO_DEEP2D_BWD, "no_wgrad_batch": SCHED_NO_WGRAD_BATCH}
+SCHED_NO_DEEP2D, SCHED_NO_DEEP2D_BWD, SCHED_NO_WGRAD_BATCH, SCHED_TRY_FULL1D = 1 << 0, 1 << 1, 1 << 2, 1 << 3
+SCHEDULE_BITS = {"no_deep2d": SCHED_NO_DEEP2D, "no_deep2d_bwd": SCHED_NO_DEEP2D_BWD, "no_wgrad_batch": SCHED_NO_WGRAD_BATCH, "try_full1d": SCHED_TRY_FULL1D}
 STEP_RECON_READY = 1
 NEXT_CONCURRENT_FORWARD = 1
 ENGINE_USED_EARLY_BUCKET, ENGINE_USED_CONCURRENT_FORWARD = 1, 2
@@ -77,6 +77,7 @@ _SIGNATURES = {
     "lshm_trace_end": (c_int, []),
     "lshm_trace_read": (c_int, [c_int, C.c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lshm_trace_free": (c_int, []),
+    "lshm_chain1d_full_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_void_p]),
     "lshm_elu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p]),
     "lshm_linear_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "lshm_linear_fwd": (c_int, [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int,

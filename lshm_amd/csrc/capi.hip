@@ -4,6 +4,7 @@
 #include "../../include/lshm.h"
 #include "kernels.h"
 #include "deep2d.h"
+#include "chain1d_full.h"
 
 #include <string.h>
 
@@ -287,6 +288,32 @@ int lshm_trace_free(void) {
   delete t;
   g_trace = nullptr;
   return LSHM_OK;
+}
+int lshm_chain1d_full_fwd(const float* x1, const float* const* w, const float* const* bias, float* const* out, long ldmu, int B,
+                          long long* stamps, lshm_stream_t s) {
+  REQUIRE(x1 && w && bias && out && B > 0 && ldmu >= 16, "chain1d_full_fwd: bad argument");
+  for (int i = 0; i < 12; ++i) REQUIRE(w[i] && bias[i] && out[i], "chain1d_full_fwd: null layer pointer");
+  const int ch[5] = {12, 24, 48, 96, 192};
+  if (!chain1d_full_supported(16, 16, 1, ch, 1024)) { set_last_error("chain1d_full_fwd: not available on this device"); return LSHM_ERR_UNSUPPORTED; }
+  Chain1dFullArgs q{};
+  const long obs[3] = {24L * 256, 48L * 64, 96L * 16}, ubs[3] = {48L * 64, 24L * 256, 12L * 1024};
+  for (int g = 0; g < 2; ++g) {
+    q.in[g] = x1;
+    for (int k = 0; k < 3; ++k) {
+      q.dn[k].w[g] = w[k]; q.dn[k].bias[g] = bias[k]; q.dn[k].out[g] = out[k]; q.dn[k].dact[g] = nullptr;
+      q.up[k].w[g] = w[9 + k]; q.up[k].bias[g] = bias[9 + k]; q.up[k].out[g] = out[9 + k]; q.up[k].dact[g] = nullptr;
+    }
+    q.w5[g] = w[3]; q.b5[g] = bias[3]; q.cat1[g] = out[3];
+    q.fc1w[g] = w[4]; q.fc1b[g] = bias[4]; q.fc2inw[g] = w[5]; q.fc2inb[g] = bias[5]; q.fc2outw[g] = w[6]; q.fc2outb[g] = bias[6];
+    q.fc3w[g] = w[7]; q.fc3b[g] = bias[7];
+    q.z1[g] = out[4]; q.mu[g] = out[5]; q.cat3[g] = out[6]; q.d0[g] = out[7];
+    q.wt0[g] = w[8]; q.bt0[g] = bias[8]; q.t0[g] = out[8];
+  }
+  q.in_bs = 12L * 1024;
+  q.mu_ld = ldmu;
+  for (int k = 0; k < 3; ++k) { q.dn[k].out_bs = obs[k]; q.dn[k].act = 1; q.up[k].out_bs = ubs[k]; q.up[k].act = 1; }
+  q.stamps = stamps;
+  return chain1d_full_fwd(q, B, 1, ST(s));
 }
 size_t lshm_deep2d_packed_floats(void) { return deep2d_packed_floats(); }
 int lshm_deep2d_fwd(const float* x2, const float* const* w, const float* const* bias, float* const* out, long ldmu, float* packed,

@@ -262,6 +262,7 @@ template <int G, int THREADS, bool BWD>
 __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   using Y = Lay<BWD>;
   constexpr int NW = THREADS / 64;
+  static_assert(G == 1 || G == 2, "the reductions tell the patches apart with one compare");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* const RA = smem;
   float* const RS = RA + G * RA_F;
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   // ---- the stage-0 input of the G patches into the padded image; forward: the harmonic-feature tails of cat1 / cat3
   prefetch<4>(pf, wq_conv3(wave), wave < 12);
   for (int i = t; i < G * RA_F / 4; i += THREADS) reinterpret_cast<f32x4*>(RA)[i] = zero4;
+  for (int i = t; i < G * RX_F / 4; i += THREADS) reinterpret_cast<f32x4*>(RX)[i] = zero4;  // (RX only ever holds the two 48 x 10 x 10 images: their border is written once)
   __syncthreads();
   stamp();
   for (int i = t; i < G * 1536; i += THREADS) {
@@ -352,16 +354,15 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   prefetch<8>(pf, wq_conv4(wave), wave < 12);
   __syncthreads();
   stamp();
-  for (int i = t; i < G * RX_F; i += THREADS) {  // the padded 10 x 10 images, border included
-    const int g = i / RX_F, j = i - g * RX_F, n = j / X3_CP, r = j - n * X3_CP, pr = r / X3_RP, pc = r - pr * X3_RP;
+  for (int i = t; i < G * 3072; i += THREADS) {  // interior of the padded 10 x 10 images (the border was cleared at the start)
+    const int g = i >= 3072 ? 1 : 0, o = i - g * 3072, n = o >> 6, m = o & 63;
     float v = 0.f;
-    if (pr >= 1 && pr <= 8 && pc >= 1 && pc <= 8 && b0 + g < a.B) {
-      const int o = n * 64 + (pr - 1) * 8 + pc - 1;
+    if (b0 + g < a.B) {
       const float* sp = RS + g * RS_F + o;
       v = epi(sp[0] + sp[3072], a.s3, (long)(b0 + g) * 3072 + o);
       a.a3[(long)(b0 + g) * 3072 + o] = v;
     }
-    RX[i] = v;
+    RX[g * RX_F + n * X3_CP + ((m >> 3) + 1) * X3_RP + (m & 7) + 1] = v;
   }
   __syncthreads();
   stamp();
@@ -394,17 +395,22 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   stamp();
   // stage 1's output as rows of two 4-wide windows: record (channel, padded row) = [cols -1..2 | cols 1..4], so that the
   // 4 x 4 window of stage 2's output position (oy, ox) is four aligned ds_read_b128 at column 4 ox
-  for (int i = t; i < G * 96 * X4_CP; i += THREADS) {
-    const int g = i / (96 * X4_CP), j = i - g * (96 * X4_CP), n = j / X4_CP, r = j - n * X4_CP, pr = r >> 3, k = r & 7;
-    const int pc = k < 4 ? k : k - 2;  // padded column of this slot
+  for (int i = t; i < G * 96 * 24; i += THREADS) {  // the 24 border slots of a channel: rows 0 and 5, slots 0 and 7 of rows 1..4
+    const int g = i >= 96 * 24 ? 1 : 0, j = i - g * 96 * 24, n = j / 24, k = j - n * 24;
+    const int o = k < 8 ? k : k < 16 ? 40 + k - 8 : 8 * (1 + ((k - 16) >> 1)) + ((k & 1) ? 7 : 0);
+    RS[g * RS_F + n * X4_CP + o] = 0.f;
+  }
+  for (int i = t; i < G * 1536; i += THREADS) {
+    const int g = i >= 1536 ? 1 : 0, o = i - g * 1536, n = o >> 4, y = (o >> 2) & 3, pc = (o & 3) + 1;
     float v = 0.f;
-    if (pr >= 1 && pr <= 4 && pc >= 1 && pc <= 4 && b0 + g < a.B) {
-      const int o = n * 16 + (pr - 1) * 4 + pc - 1;
+    if (b0 + g < a.B) {
       const float* sp = RA + g * RA_F + o;
       v = epi(sp[0] + sp[1536], a.s4, (long)(b0 + g) * 1536 + o);
-      if (k <= 3 || k == 6) a.a4[(long)(b0 + g) * 1536 + o] = v;  // (columns 2, 3 have two slots)
+      a.a4[(long)(b0 + g) * 1536 + o] = v;
     }
-    RS[g * RS_F + j] = v;
+    float* rec = RS + g * RS_F + n * X4_CP + (y + 1) * 8;
+    if (pc <= 3) rec[pc] = v;       // window of ox = 0: columns -1..2
+    if (pc >= 2) rec[2 + pc] = v;   // window of ox = 1: columns 1..4
   }
   __syncthreads();
   stamp();
@@ -500,17 +506,22 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   // dense 4's first 768 outputs (192 x 2 x 2; forward: fc3 has no activation, src/lofar_models.py:91) as padded rows of
   // column PAIRS: record (channel, padded row) = [cols (0,1) | (1,2) | (2,3) | unused]: the two column taps of a
   // transposed-conv lane are one ds_read_b64
-  for (int i = t; i < G * 192 * D0_CP; i += THREADS) {
-    const int g = i / (192 * D0_CP), j = i - g * (192 * D0_CP), ci = j >> 5, r = j & 31, pr = r >> 3, k = r & 7;
-    const int pc = (k + 1) >> 1;  // padded column of this slot (k < 6)
+  for (int i = t; i < G * 192 * 16; i += THREADS) {  // the 16 border slots of a channel that are read: rows 0 and 3 (slots 0..5), slots 0 and 5 of rows 1, 2
+    const int g = i >= 192 * 16 ? 1 : 0, j = i - g * 192 * 16, ci = j >> 4, k = j & 15;
+    const int o = k < 6 ? k : k < 12 ? 24 + k - 6 : 8 * (1 + ((k - 12) >> 1)) + ((k & 1) ? 5 : 0);
+    RS[g * RS_F + ci * D0_CP + o] = 0.f;
+  }
+  for (int i = t; i < G * 768; i += THREADS) {
+    const int g = i >= 768 ? 1 : 0, n = i - g * 768, ci = n >> 2, pr = ((n >> 1) & 1) + 1, pc = (n & 1) + 1;
     float v = 0.f;
-    if (k < 6 && (pr == 1 || pr == 2) && (pc == 1 || pc == 2) && b0 + g < a.B) {
-      const int n = ci * 4 + (pr - 1) * 2 + pc - 1;
+    if (b0 + g < a.B) {
       v = dense_sum<Y::NG4>(RA, g, n);
       if (BWD) v = epi(v, a.sd4, (long)(b0 + g) * a.d0_ld + n);
-      if (k & 1) a.d0[(long)(b0 + g) * a.d0_ld + n] = v;  // (slots 1 and 3 are the first of each column)
+      a.d0[(long)(b0 + g) * a.d0_ld + n] = v;
     }
-    RS[g * RS_F + j] = v;
+    float* rec = RS + g * RS_F + ci * D0_CP + pr * 8;  // column pc sits in the pairs (pc - 1, pc) and (pc, pc + 1): slots 2 pc - 1, 2 pc
+    rec[2 * pc - 1] = v;
+    rec[2 * pc] = v;
   }
   if (BWD) {  // fc1' has 16 more outputs: the gradient w.r.t. elu(fcuv1) (the weight gradient of fcuv1 reads it)
     for (int i = t; i < G * kHd; i += THREADS) {
@@ -553,16 +564,20 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   prefetch<8>(pf, wq_tconv1(wave), wave < 12);
   __syncthreads();
   stamp();
-  for (int i = t; i < G * 96 * T0_CP; i += THREADS) {  // padded 6 x 8 (+4) images, border included
-    const int g = i / (96 * T0_CP), j = i - g * (96 * T0_CP), co = j / T0_CP, r = j - co * T0_CP, pr = r >> 3, pc = r & 7;
+  for (int i = t; i < G * 96 * 20; i += THREADS) {  // the 20 border cells of a channel that are read (6 x 6 around the 4 x 4 interior)
+    const int g = i >= 96 * 20 ? 1 : 0, j = i - g * 96 * 20, co = j / 20, k = j - co * 20;
+    const int o = k < 6 ? k : k < 12 ? 5 * T0_RP + k - 6 : (1 + ((k - 12) >> 1)) * T0_RP + ((k & 1) ? 5 : 0);
+    RS[g * RS_F + co * T0_CP + o] = 0.f;
+  }
+  for (int i = t; i < G * 1536; i += THREADS) {
+    const int g = i >= 1536 ? 1 : 0, o = i - g * 1536, co = o >> 4, pos = o & 15;
     float v = 0.f;
-    if (r < 48 && pr >= 1 && pr <= 4 && pc >= 1 && pc <= 4 && b0 + g < a.B) {
-      const int o = co * 16 + (pr - 1) * 4 + pc - 1;
+    if (b0 + g < a.B) {
       const float* sp = RA + g * RA_F + o;
       v = epi(sp[0] + sp[1536], a.st0, (long)(b0 + g) * 1536 + o);
       a.t0[(long)(b0 + g) * 1536 + o] = v;
     }
-    RS[g * RS_F + j] = v;
+    RS[g * RS_F + co * T0_CP + ((pos >> 2) + 1) * T0_RP + (pos & 3) + 1] = v;
   }
   __syncthreads();
   stamp();
@@ -600,16 +615,15 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   prefetch<4>(pf, wq_tconv2(wave), wave < 16);
   __syncthreads();
   stamp();
-  for (int i = t; i < G * RX_F; i += THREADS) {
-    const int g = i / RX_F, j = i - g * RX_F, co = j / T1_CP, r = j - co * T1_CP, pr = r / T1_RP, pc = r - pr * T1_RP;
+  for (int i = t; i < G * 3072; i += THREADS) {
+    const int g = i >= 3072 ? 1 : 0, o = i - g * 3072, co = o >> 6, pos = o & 63;
     float v = 0.f;
-    if (pr >= 1 && pr <= 8 && pc >= 1 && pc <= 8 && b0 + g < a.B) {
-      const int o = co * 64 + (pr - 1) * 8 + pc - 1;
+    if (b0 + g < a.B) {
       const float* sp = RA + g * RA_F + o;
       v = epi(sp[0] + sp[3072], a.st1, (long)(b0 + g) * 3072 + o);
       a.t1[(long)(b0 + g) * 3072 + o] = v;
     }
-    RX[i] = v;
+    RX[g * RX_F + co * T1_CP + ((pos >> 3) + 1) * T1_RP + (pos & 7) + 1] = v;
   }
   __syncthreads();
   stamp();

@@ -17,6 +17,7 @@
 #include "../../include/lshm.h"
 #include "kernels.h"
 #include "deep2d.h"
+#include "chain1d_full.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -86,6 +87,7 @@ struct lshm_engine {
   size_t o_pack2d = 0;  // fragment-ordered copy of the 2-D autoencoder's deep weights (deep2d.hip), inside the forward prefix
   bool deep2d = false;  // conv3 .. tconv3 of the 2-D autoencoder's forward as one launch
   bool deep2d_bwd = false;  // ... and the data gradients of tconv2 .. conv2 as one launch
+  bool full1d = false;  // conv2 .. tconv3 of the 1-D autoencoders' forward as one launch (chain1d_full.hip)
   size_t o_pack2d_bwd = 0;  // the backward's fragment-ordered weight copy
   unsigned wgrad_on_main = 0;  // which of the deep layers' weight gradients follow the data-gradient chain on ITS stream (ae_backward)
   int deep_variant = 0; // 0: one patch per workgroup (a forward alone), 1: two (two forwards side by side: each fills half of the CUs)
@@ -271,7 +273,35 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
       return deep2d_pack(w, ws + e->o_pack2d, 0, st);
     });
   }
+  // 1-D autoencoders: conv2 .. tconv3 (twelve layers) as one launch (chain1d_full.hip)
+  const bool full1d = a0.ndim == 1 && e->full1d;
   for (int i = 0; i < 6; ++i) {
+    if (full1d && i == 2) {
+      steps.push_back([=](float* ws, hipStream_t st) -> int {
+        Chain1dFullArgs q{};
+        for (int g = 0; g < 2; ++g) {
+          const AEPlan& a = A(g < G ? g : 0);
+          q.in[g] = ws + a.act[1];
+          for (int k = 0; k < 3; ++k) {
+            q.dn[k].w[g] = prm + a.cw[2 + k]; q.dn[k].bias[g] = prm + a.cb[2 + k]; q.dn[k].out[g] = ws + a.act[2 + k]; q.dn[k].dact[g] = nullptr;
+            q.up[k].w[g] = prm + a.tw[1 + k]; q.up[k].bias[g] = prm + a.tb[1 + k]; q.up[k].out[g] = ws + a.dact[1 + k]; q.up[k].dact[g] = nullptr;
+          }
+          q.w5[g] = prm + a.cw[5]; q.b5[g] = prm + a.cb[5]; q.cat1[g] = ws + a.cat1;
+          q.fc1w[g] = prm + a.fc1w; q.fc1b[g] = prm + a.fc1b; q.fc2inw[g] = prm + a.fc2inw; q.fc2inb[g] = prm + a.fc2inb;
+          q.fc2outw[g] = prm + a.fc2outw; q.fc2outb[g] = prm + a.fc2outb; q.fc3w[g] = prm + a.fc3w; q.fc3b[g] = prm + a.fc3b;
+          q.z1[g] = ws + a.z1; q.mu[g] = ws + e->o_Mu + a.mu_col; q.cat3[g] = ws + a.cat3; q.d0[g] = ws + a.d0;
+          q.wt0[g] = prm + a.tw[0]; q.bt0[g] = prm + a.tb[0]; q.t0[g] = ws + a.dact[0];
+        }
+        q.in_bs = A(0).enc[2].in_bs;
+        q.mu_ld = D;
+        for (int k = 0; k < 3; ++k) {
+          q.dn[k].out_bs = A(0).enc[2 + k].out_bs; q.dn[k].act = 1;
+          q.up[k].out_bs = A(0).dec[1 + k].out_bs; q.up[k].act = 1;
+        }
+        return chain1d_full_fwd(q, B, G, st);
+      });
+      break;
+    }
     if (deep && i == 3) {
       steps.push_back([=](float* ws, hipStream_t st) -> int {
         const AEPlan& a = A(0);
@@ -326,7 +356,7 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
   auto both = [&](auto f) { Lin q{}; for (int g = 0; g < 2; ++g) f(q, g, A(g)); return q; };
   // (elu(fcuv1(uvh)) and elu(fcuv3(uvh)) are already in cat1 / cat3: the uv_features step)
   const bool dense_chain = dense1d_supported(L, hd, c.rica);  // latent width 16 (netT / netF) or 256 (the 2-D autoencoder)
-  if (deep) {
+  if (deep || full1d) {
     if (latent_mark) *latent_mark = steps.size();
   } else if (dense_chain) {
     // fc1 -> fc2in -> fc2out -> fc3 of an autoencoder as one launch (dense1d.hip); the latents are complete inside it,
@@ -361,13 +391,13 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
       steps.push_back([=](float* ws, hipStream_t st) -> int { return copy2d(ws + src, D, ws + dst, L + hd, B, L, st); });
     }
   }
-  if (!dense_chain && !deep) {
+  if (!dense_chain && !deep && !full1d) {
     if (latent_mark) *latent_mark = steps.size();
     Lin q = both([&](Lin& q, int g, const AEPlan& a) { q.x[g] = a.cat3; q.w[g] = a.fc3w; q.b[g] = a.fc3b; q.y[g] = a.d0; });
     q.ldx = L + hd; q.ldy = 768; q.K = L + hd; q.N = 768; q.act = 0;
     lin(q);
   }
-  for (int i = deep ? 4 : 0; i < 6; ++i) {
+  for (int i = (deep || full1d) ? 4 : 0; i < 6; ++i) {
     if (i == 5 && output_mark) *output_mark = steps.size();
     if (chain_up && i == 1) {
       steps.push_back([=](float* ws, hipStream_t st) -> int {
@@ -1354,6 +1384,11 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   }
   e->o_dMscratch = take(cur, (size_t)cfg->K * e->D);
   e->deep2d_bwd = e->deep2d && !(cfg->schedule & LSHM_SCHED_NO_DEEP2D_BWD);
+  {
+    const int ech[5] = {e->ae[1].enc[1].Cout, e->ae[1].enc[2].Cout, e->ae[1].enc[3].Cout, e->ae[1].enc[4].Cout, e->ae[1].enc[5].Cout};
+    e->full1d = (cfg->schedule & LSHM_SCHED_TRY_FULL1D) && cfg->precision == LSHM_PRECISION_F32 &&
+                chain1d_full_supported(cfg->Lt, e->hdim, cfg->rica, ech, e->ae[1].enc[2].Win);
+  }
   e->wgrad_on_main = cfg->tune ? cfg->tune - 1 : 0u;  // (experimental placement word: lshm_step_config.tune, 0 = shipped)
   if (e->deep2d_bwd) e->o_pack2d_bwd = take(cur, deep2d_packed_floats());
   e->o_recon_part = take(cur, recon_partials_floats(B * cfg->C, cfg->P));

@@ -666,3 +666,52 @@ def test_deep_section_backward_as_one_launch(variant, nb):
     torch.cuda.synchronize()
     for k, (o, r) in enumerate(zip(got0, sep)):
         assert rel_err(o, r.reshape(o.shape)) < 2e-5, (variant, k)
+
+
+def test_whole_1d_mid_and_deep_section_as_one_launch():
+    """lshm_chain1d_full_fwd (conv2 .. tconv3 of AutoEncoder1DCNN, src/lofar_models.py:119-140,158-183, one workgroup per
+    patch; an opt-in experiment of the engine, LSHM_SCHED_TRY_FULL1D) against fp64, every layer's output, B = 37."""
+    import ctypes as C
+    from lshm_amd import _lib as L
+    lib = L.load()
+    nb = 37
+    g = torch.Generator().manual_seed(5)
+    ch = [12, 24, 48, 96, 192]
+    w = [torch.randn(ch[i + 1], ch[i], 4, generator=g) * (3.0 / (4 * ch[i])) ** 0.5 for i in range(4)]
+    w += [torch.randn(16, 784, generator=g) * 0.05, torch.randn(16, 16, generator=g) * 0.3, torch.randn(16, 16, generator=g) * 0.3,
+          torch.randn(768, 32, generator=g) * 0.2]
+    w += [torch.randn(ch[4 - i], ch[3 - i], 4, generator=g) * (3.0 / ch[4 - i]) ** 0.5 for i in range(4)]
+    bs = [torch.randn(n, generator=g) * 0.1 for n in (24, 48, 96, 192, 16, 16, 16, 768, 96, 48, 24, 12)]
+    x1 = TF.elu(torch.randn(nb, 12, 1024, generator=g))
+    uv1, uv3 = TF.elu(torch.randn(nb, 16, generator=g)), TF.elu(torch.randn(nb, 16, generator=g))
+    shapes = [(nb, 24, 256), (nb, 48, 64), (nb, 96, 16), (nb, 784), (nb, 16), (nb, 256), (nb, 32), (nb, 768), (nb, 96, 16), (nb, 48, 64),
+              (nb, 24, 256), (nb, 12, 1024)]
+    outs = [torch.full(s, float("nan"), device=DEV) for s in shapes]
+    outs[3][:, 768:] = uv1.to(DEV)
+    outs[6][:, 16:] = uv3.to(DEV)
+    wd, bd = [t.to(DEV) for t in w], [t.to(DEV) for t in bs]
+    arr = lambda ts: (C.c_void_p * 12)(*[t.data_ptr() for t in ts])
+    L.check(lib.lshm_chain1d_full_fwd(L.ptr(x1.to(DEV)), arr(wd), arr(bd), arr(outs), 256, nb, None, L.stream()), "chain1d_full_fwd")
+    torch.cuda.synchronize()
+    d = lambda t: t.double()
+    cur = d(x1)
+    ref = []
+    for i in range(3):
+        cur = TF.elu(TF.conv1d(cur, d(w[i]), d(bs[i]), stride=4, padding=1))
+        ref.append(cur)
+    a5 = TF.elu(TF.conv1d(cur, d(w[3]), d(bs[3]), stride=4, padding=1))
+    cat1 = torch.cat([a5.flatten(1), d(uv1)], 1)
+    z1 = TF.elu(TF.linear(cat1, d(w[4]), d(bs[4])))
+    mu = TF.elu(TF.linear(z1, d(w[5]), d(bs[5])))
+    cat3 = torch.cat([TF.elu(TF.linear(mu, d(w[6]), d(bs[6]))), d(uv3)], 1)
+    d0 = TF.linear(cat3, d(w[7]), d(bs[7]))
+    ref += [cat1, z1, mu, cat3, d0]
+    cur = d0.view(nb, 192, 4)
+    for i in range(4):
+        cur = TF.elu(TF.conv_transpose1d(cur, d(w[8 + i]), d(bs[8 + i]), stride=4))
+        ref.append(cur)
+    got = list(outs)
+    got[5] = outs[5][:, :16]
+    for k, (o, r) in enumerate(zip(got, ref)):
+        assert torch.isfinite(o).all(), k
+        assert rel_err(o.cpu().double().reshape(r.shape), r) < 2e-5, k
