@@ -31,6 +31,13 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 # algorithmic bytes per patch per training step: layer-wise in+out, no recompute
 STEP_BYTES_PER_PATCH = 15.04e6
+
+
+def _elided_bytes_per_patch(cfg, use_graph):
+    """Algorithmic bytes (SURVEY 8d accounting) of the layers the schedule does not run: with the shared reconstruction
+    pass the closure forward leaves out ConvTranspose1d(8, 4, 4, stride=4) of netT and netF."""
+    shared = (cfg.share_recon_pass or cfg.reuse_forward) and not use_graph
+    return 2 * 4.0 * (8 * 4096 + 4 * 16384) if shared else 0.0
 STEP_FLOP_PER_PATCH = 205.6e6
 
 
@@ -674,7 +681,9 @@ def main():
 
     # Not the headline: the same iterations with TrainConfig.reuse_forward (iteration k+1 starts from the
     # activations of iteration k's no-grad forward; bit-for-bit the same trajectory, tests/test_gpu_step.py::
-    # test_reuse_forward_is_bitwise_the_same_trajectory).  Reported next to `value`, which always recomputes.
+    # test_reuse_forward_is_bitwise_the_same_trajectory).  Reported next to `value`, whose two forwards per iteration are
+    # both run -- up to the common subexpressions config.schedule names (the last 1-D layer pair and the reconstruction
+    # terms of the closure forward: roofline.bytes_executed); literal_upstream_order_mode shares nothing.
     reuse = None
     if not use_graph and not args.no_reuse_mode:
         tr.cfg.reuse_forward = True
@@ -705,8 +714,14 @@ def main():
                                   f"fwd+bwd + Adam (all 4 groups) + no-grad fwd + multiplier update",
                       "global_batch": world * B, "per_gpu_batch": B, "K": args.K, "bpb": args.bpb,
                       "parallelism": f"dp{world}", "launch": "hipgraph" if use_graph else "eager",
-                      "schedule": "no-grad forward of iteration k and closure forward of iteration k+1 on two streams "
-                                  "(TrainConfig.overlap_forwards)" if cfg.overlap_forwards and not use_graph else
+                      "schedule": ("no-grad forward of iteration k and closure forward of iteration k+1 side by side on two streams "
+                                   "(TrainConfig.overlap_forwards); common subexpressions of the two are computed once: the closure "
+                                   "forward does not run the last layer of netT / netF (nothing reads its copy of their reconstructions) "
+                                   "and takes its seven reconstruction terms and three gradient images from the pass that follows the "
+                                   "no-grad forward (TrainConfig.share_recon_pass) -- bit for bit the trajectory of the schedule that "
+                                   "runs both (tests/test_gpu_step.py::test_overlapped_forwards_are_bitwise_the_same_trajectory, "
+                                   "::test_shared_reconstruction_pass_is_bitwise_the_same_trajectory); literal_upstream_order_mode "
+                                   "runs everything") if cfg.overlap_forwards and not use_graph else
                                   "forwards one after the other",
                       "feature_stage": "v2 path (row/column 1D AEs); FFT op benchmarked separately"},
            "loss_total": terms["total"], "nonfinite_terms": terms["nonfinite"],
@@ -721,6 +736,10 @@ def main():
                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(STEP_BYTES_PER_PATCH * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "ms": round(ms, 4), "bytes_per_launch": STEP_BYTES_PER_PATCH * B,
+                        # the layers this schedule actually runs: the closure forward's last 1-D layer pair (read 8 x 4096,
+                        # write 4 x 16384 floats per patch and network) is elided when the reconstruction pass is shared
+                        "bytes_executed": (STEP_BYTES_PER_PATCH - _elided_bytes_per_patch(cfg, use_graph)) * B,
+                        "frac_executed": round((STEP_BYTES_PER_PATCH - _elided_bytes_per_patch(cfg, use_graph)) * B / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "flop_frac_of_f32_matrix_peak": round(STEP_FLOP_PER_PATCH * B / (ms * 1e-3) / 1e12 / 157.3, 4),
                         "traffic": _pmc_step_traffic() if B == 256 and args.K == 10 and not args.bf16 else None,
                         "traffic_source": _pmc_file_id(),
@@ -778,6 +797,10 @@ def main():
         #  k64_mode                  configs[4]'s K = 64 centroids, Adam iteration
         #  admm10_loop               the loop upstream runs: new host minibatch every 10 iterations, terms read back
         out["sequential_forwards_mode"] = _variant(args, dev, pg, rank, world, barrier, x, uv, overlap_forwards=False)
+        # the literal order of src/kharmonic_lofar.py:131-202: closure forward (whole), backward, Adam, no-grad forward (whole),
+        # multiplier update as a pass of its own -- nothing shared between the two forwards: what the sharing is worth
+        out["literal_upstream_order_mode"] = _variant(args, dev, pg, rank, world, barrier, x, uv, overlap_forwards=False,
+                                                       share_recon_pass=False)
         out["bf16_mode"] = _variant(args, dev, pg, rank, world, barrier, x, uv, matrix_precision="bf16",
                                     activation_storage="bf16")
         out["bf16_mode"]["dtype"] = "bf16 operands (v_mfma_f32_16x16x16_bf16) + bf16 storage of the image-sized tensors, f32 accumulate"

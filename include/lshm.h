@@ -130,6 +130,12 @@ int lshm_conv_wgrad_bf16(int kind, const float* x, const float* dz, float* dw, f
 int lshm_conv_bwd_fused(int kind, const float* x, const float* dz, const float* w, float* dw, float* db, float* dx,
                         int elu_grad, int B, int Cin, int Cout, int Hin, int Win, float* workspace,
                         size_t workspace_floats, lshm_stream_t stream);
+/* The same under a schedule word (LSHM_SCHED_*, below): LSHM_SCHED_NO_BWD_LDS_8_4 selects the register form of 1-D conv0's
+ * kernel (the one bf16 storage runs), LSHM_SCHED_NO_BWD_LDS / _NO_BWD_LDS2D / _NO_BWD_FUSED2D make the call refuse the layers
+ * those kernels serve -- what an engine with that word in lshm_step_config.schedule runs. */
+int lshm_conv_bwd_fused_ex(int kind, const float* x, const float* dz, const float* w, float* dw, float* db, float* dx,
+                           int elu_grad, int B, int Cin, int Cout, int Hin, int Win, float* workspace,
+                           size_t workspace_floats, unsigned schedule, lshm_stream_t stream);
 /* Three consecutive k4 s4 1-D layers of AutoEncoder1DCNN's middle as ONE launch, the patch's activations resident in
  * LDS from layer to layer (every layer's output is still written to out[k], once, coalesced):
  *   up == 0: stride-4 conv direction, 12 -> 24 -> 48 -> 96 channels from 1024 positions: conv2 -> conv3 -> conv4
@@ -439,6 +445,24 @@ typedef struct lshm_step_config {
  * workgroup per (patch, network) re-reads conv5's and tconv0's weights from L2 for every patch and runs them on 6-12 of its
  * 16 wavefronts, 55 us per workgroup wave where the five launches overlap with the other forward. */
 #define LSHM_SCHED_TRY_FULL1D (1u << 3)
+/* The remaining choices, one bit each (what runs instead is the launch sequence the choice replaced): */
+#define LSHM_SCHED_NO_CHAIN1D (1u << 4)       /* conv2-4 / tconv1-3 of the 1-D pair's FORWARD as three launches each (lshm_conv1d_chain3) */
+#define LSHM_SCHED_NO_CHAIN1D_BWD (1u << 5)   /* ... their data gradients as three launches each */
+#define LSHM_SCHED_NO_DENSE1D (1u << 6)       /* the dense middle of the 1-D pair's forward as five launches (lshm_dense1d_fwd) */
+#define LSHM_SCHED_NO_DENSE1D_BWD (1u << 7)   /* ... of its backward (lshm_dense1d_bwd) */
+#define LSHM_SCHED_NO_RESID_CONV0 (1u << 8)   /* no-grad forward: residual split + conv0 of netT / netF as two launches (lshm_resid_conv0) */
+#define LSHM_SCHED_NO_RECON_FROM_A (1u << 9)  /* no-grad forward runs the last 1-D layer; the reconstruction pass reads its output */
+#define LSHM_SCHED_NO_ONE_PASS_BWD (1u << 10) /* every one-pass (data + weight + bias gradient) kernel off: separate launches (lshm_conv_bwd_fused) */
+#define LSHM_SCHED_NO_BWD_LDS (1u << 11)      /* the LDS-staged one-pass kernels of the 1-D 12/8 layers and of 1-D conv0 off */
+#define LSHM_SCHED_NO_BWD_LDS_8_4 (1u << 12)  /* 1-D conv0's one-pass backward on the register form (what bf16 storage uses) */
+#define LSHM_SCHED_NO_BWD_LDS2D (1u << 13)    /* the one-pass backward of the 2-D 12/8 layers (tconv4, conv1) off */
+#define LSHM_SCHED_NO_BWD_FUSED2D (1u << 14)  /* the one-pass backward of the outermost 2-D decoder layer off */
+#define LSHM_SCHED_NO_WGRAD_MID (1u << 15)    /* weight gradients of the mid 1-D layers as implicit GEMMs */
+#define LSHM_SCHED_NO_STOP_EVENTS (1u << 16)  /* "dz ready" as recorded events (marker packets) instead of kernel completion signals */
+#define LSHM_SCHED_WGRAD_INLINE (1u << 17)    /* weight gradients on the data-gradient stream (no second stream) */
+#define LSHM_SCHED_FORK (1u << 18)            /* netT and netF on two streams instead of paired launches */
+#define LSHM_SCHED_PHASE_EVENTS (1u << 19)    /* diagnostic: record the phase-boundary events lshm_engine_phase_times reads */
+#define LSHM_SCHED_NO_KHM_MFMA (1u << 20)     /* K-harmonic pass for 16 < K <= 64 on the row-split kernel instead of the matrix cores */
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);
 void lshm_engine_destroy(lshm_engine* e);
@@ -466,6 +490,11 @@ int lshm_engine_set_early_bucket(lshm_engine* e, int on);
 /* HIP device the engine was created on (-1: no device): every engine call makes it current, refuses a stream of
  * another device and refuses arena / workspace / input pointers that are not device memory of that device. */
 int lshm_engine_device(const lshm_engine* e);
+/* Replace the per-call bits of the engine's schedule word (lshm_step_config.schedule; for A/B measurements and the tests
+ * that hold a fused kernel to the launches it replaced on ONE set of parameters).  The bits that shape the engine at
+ * creation -- LSHM_SCHED_NO_DEEP2D, _NO_DEEP2D_BWD, _TRY_FULL1D (workspace), _WGRAD_INLINE, _FORK, _PHASE_EVENTS (streams,
+ * events) -- keep their creation-time value.  Returns the word in effect. */
+unsigned lshm_engine_set_schedule(lshm_engine* e, unsigned schedule);
 /* Diagnostic (an engine created with LSHM_PHASE_EVENTS=1 in the environment; LSHM_ERR_UNSUPPORTED otherwise): device
  * timestamps at the phase boundaries of the last iteration (lshm_engine_backward_saved, the optimiser, then
  * lshm_engine_multiplier_update_next_ex), in milliseconds after the closure's first launch; synchronises the device.

@@ -37,8 +37,14 @@ class StepConfig(C.Structure):
 
 
 PRECISION_F32, PRECISION_BF16_OPERANDS, PRECISION_BF16_STORAGE = 0, 1, 2
-SCHED_NO_DEEP2D, SCHED_NO_DEEP2D_BWD, SCHED_NO_WGRAD_BATCH, SCHED_TRY_FULL1D = 1 << 0, 1 << 1, 1 << 2, 1 << 3
-SCHEDULE_BITS = {"no_deep2d": SCHED_NO_DEEP2D, "no_deep2d_bwd": SCHED_NO_DEEP2D_BWD, "no_wgrad_batch": SCHED_NO_WGRAD_BATCH, "try_full1d": SCHED_TRY_FULL1D}
+# lshm_step_config.schedule (LSHM_SCHED_* of include/lshm.h): name -> bit
+SCHEDULE_BITS = {"no_deep2d": 1 << 0, "no_deep2d_bwd": 1 << 1, "no_wgrad_batch": 1 << 2, "try_full1d": 1 << 3,
+                 "no_chain1d": 1 << 4, "no_chain1d_bwd": 1 << 5, "no_dense1d": 1 << 6, "no_dense1d_bwd": 1 << 7,
+                 "no_resid_conv0": 1 << 8, "no_recon_from_a": 1 << 9, "no_one_pass_bwd": 1 << 10, "no_bwd_lds": 1 << 11,
+                 "no_bwd_lds_8_4": 1 << 12, "no_bwd_lds2d": 1 << 13, "no_bwd_fused2d": 1 << 14, "no_wgrad_mid": 1 << 15,
+                 "no_stop_events": 1 << 16, "wgrad_inline": 1 << 17, "fork": 1 << 18, "phase_events": 1 << 19,
+                 "no_khm_mfma": 1 << 20}
+SCHED_NO_DEEP2D, SCHED_NO_DEEP2D_BWD = SCHEDULE_BITS["no_deep2d"], SCHEDULE_BITS["no_deep2d_bwd"]
 STEP_RECON_READY = 1
 NEXT_CONCURRENT_FORWARD = 1
 ENGINE_USED_EARLY_BUCKET, ENGINE_USED_CONCURRENT_FORWARD = 1, 2
@@ -63,6 +69,8 @@ _SIGNATURES = {
                                 c_int, c_long, c_long, c_void_p, c_size_t, c_int, c_void_p]),
     "lshm_conv_bwd_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                     c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "lshm_conv_bwd_fused_ex": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_int, c_int, c_int, c_void_p, c_size_t, C.c_uint, c_void_p]),
     "lshm_conv1d_chain3": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lshm_dense1d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p]),
     "lshm_dense1d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -155,6 +163,7 @@ _SIGNATURES = {
     "lshm_engine_multiplier_update_next": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, c_void_p]),
     "lshm_engine_multiplier_update_next_ex": (c_int, [c_void_p] * 7 + [c_void_p, c_size_t, C.c_uint, c_void_p]),
     "lshm_engine_device": (c_int, [c_void_p]),
+    "lshm_engine_set_schedule": (C.c_uint, [c_void_p, C.c_uint]),
     "lshm_engine_phase_times": (c_int, [c_void_p, c_void_p, c_int]),
     "lshm_engine_last_flags": (C.c_uint, [c_void_p]),
     "lshm_engine_comm_early_bucket": (c_int, [c_void_p]),

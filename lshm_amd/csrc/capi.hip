@@ -19,6 +19,11 @@ namespace lshm {
 thread_local hipEvent_t launch_stop_event = nullptr;
 thread_local unsigned launch_stop_count = 0;
 
+static thread_local unsigned t_schedule = 0;
+ScheduleScope::ScheduleScope(unsigned word) : prev(t_schedule) { t_schedule = word; }
+ScheduleScope::~ScheduleScope() { t_schedule = prev; }
+unsigned schedule_word() { return t_schedule; }
+
 // ---- per-launch trace (diagnostics; see common.h)
 thread_local bool launch_trace_on = false;
 namespace {
@@ -186,6 +191,12 @@ int lshm_conv_wgrad(int kind, const float* x, const float* dz, float* dw, float*
   if (rc) return rc;
   return conv_layer_wgrad(L, ConvWgradIO{x, dz, dw, db}, ws, wsf, accumulate, ST(s));
 }
+int lshm_conv_bwd_fused_ex(int kind, const float* x, const float* dz, const float* w, float* dw, float* db, float* dx,
+                           int elu_grad, int B, int Cin, int Cout, int Hin, int Win, float* ws, size_t wsf, unsigned schedule,
+                           lshm_stream_t s) {
+  ScheduleScope scope(schedule);
+  return lshm_conv_bwd_fused(kind, x, dz, w, dw, db, dx, elu_grad, B, Cin, Cout, Hin, Win, ws, wsf, s);
+}
 int lshm_conv_bwd_fused(int kind, const float* x, const float* dz, const float* w, float* dw, float* db, float* dx,
                         int elu_grad, int B, int Cin, int Cout, int Hin, int Win, float* ws, size_t wsf,
                         lshm_stream_t s) {
@@ -206,7 +217,7 @@ int lshm_conv1d_chain3(int up, const float* x, const float* const* w, const floa
   REQUIRE(x && w && out && B > 0 && (pad == 0 || pad == 1), "conv1d_chain3: bad argument");
   const int chd[4] = {12, 24, 48, 96}, chu[4] = {96, 48, 24, 12};
   if (!conv1d_chain_supported(up != 0, up ? chu : chd, up ? 16 : 1024)) {
-    set_last_error("conv1d_chain3: chains are switched off (LSHM_CHAIN_OFF)");
+    set_last_error("conv1d_chain3: not available on this device (LDS) or switched off by the calling scope's schedule word");
     return LSHM_ERR_UNSUPPORTED;
   }
   Chain1dStage st[3];

@@ -121,8 +121,7 @@ static size_t lds_up(int c0, int c1, int c2, int c3, int l0) {
 // the two chains of AutoEncoder1DCNN's mid layers: down 12 -> 24 -> 48 -> 96 channels from 1024 positions, up
 // 96 -> 48 -> 24 -> 12 channels from 16 positions
 bool conv1d_chain_supported(bool up, const int* ch, int L0) {
-  static const bool off = getenv("LSHM_CHAIN_OFF") != nullptr;
-  if (off) return false;
+  if (sched(LSHM_SCHED_NO_CHAIN1D)) return false;
   // (the LDS a chain needs is part of the answer: on a device that cannot hold it the plan keeps the three launches)
   if (!up) return ch[0] == 12 && ch[1] == 24 && ch[2] == 48 && ch[3] == 96 && L0 == 1024 && device_lds_fits(lds_down(12, 24, 48, 96, 1024));
   return ch[0] == 96 && ch[1] == 48 && ch[2] == 24 && ch[3] == 12 && L0 == 16 && device_lds_fits(lds_up(96, 48, 24, 12, 16));

@@ -271,11 +271,10 @@ int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const flo
                    float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks, hipStream_t st, int* grid_out,
                    const FusedDgrad& fd, int big_bf16, int small_bf16);
 bool conv1d_bwd_fused2_supported(int Cs, int Cb, int pad) {
-  // 12 / 8 channels: 96 accumulator registers + the data-gradient working set do not fit two wavefronts per SIMD
-  // (the compiler spills 80-330 registers; 67-129 us against 50 us for the two separate kernels, profiles/r03):
-  // opt-in only (LSHM_FUSED2_12_8=1) until those layers get an LDS-staged form
-  // -> the LDS-staged form below (conv1d_bwd_lds_kernel) is the default for them; LSHM_FUSED2_12_8=1 selects the register form
-  const bool wide = getenv("LSHM_FUSED2_12_8") != nullptr || getenv("LSHM_BWD_LDS_OFF") == nullptr;  // read per call (tests)
+  // 12 / 8 channels: only as the LDS-staged form below (conv1d_bwd_lds_kernel).  In registers 96 accumulators + the
+  // data-gradient working set do not fit two wavefronts per SIMD (80-330 spilled registers, 67-129 us against 50 us for the two
+  // separate kernels, profiles/r03/fused_bwd_probe.txt): that form was removed in round 4.
+  const bool wide = !sched(LSHM_SCHED_NO_BWD_LDS);
   return (wide && Cs == 12 && Cb == 8 && (pad == 0 || pad == 1)) || (Cs == 8 && Cb == 4 && (pad == 0 || pad == 1));
 }
 
@@ -284,10 +283,8 @@ int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const 
                       float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad, int max_blocks,
                       hipStream_t st, int* grid_out, int big_bf16, const FusedDgrad& fd, int small_bf16) {
   // (8 / 4 channels with bf16 storage stay on the register form below: the LDS form is 0.05 ms per iteration SLOWER there --
-  //  half the bytes, the same matrix and LDS work -- while it is 0.03 ms faster in fp32; LSHM_BWD_LDS_8_4_BF16=1 for A/B)
-  static const bool lds84_bf16 = getenv("LSHM_BWD_LDS_8_4_BF16") != nullptr;
-  if (((Cs == 12 && !small_bf16 && (big_bf16 || !getenv("LSHM_FUSED2_12_8"))) ||
-       (Cs == 8 && small_bf16 == big_bf16 && (!big_bf16 || lds84_bf16))) &&
+  //  half the bytes, the same matrix and LDS work -- while it is 0.03 ms faster in fp32)
+  if (((Cs == 12 && !small_bf16) || (Cs == 8 && small_bf16 == big_bf16 && !big_bf16)) &&
       conv1d_bwd_lds_supported(Cs, Cb, Ls, pad))
     return conv1d_bwd_lds(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, max_blocks, st, grid_out, fd, big_bf16,
                           small_bf16);
@@ -308,7 +305,7 @@ int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const 
   a.dout[0] = fd.dx; a.dout[1] = two ? fd.dx2 : fd.dx;
   a.s_bs = s_bs; a.big_bs = big_bs; a.d_bs = fd.dx_bs;
   a.Ls = Ls; a.Lb = Lb; a.ntiles = (Ls / 64) * B;
-  static const int tpw = [] { const char* v = getenv("LSHM_FUSED2_TPW"); return v && atoi(v) > 0 ? atoi(v) : 4; }();
+  constexpr int tpw = 4;
   int grid = a.ntiles / (4 * tpw);  // tiles per wavefront
   if (grid > 512) grid = 512;
   if (grid < 1) grid = 1;
@@ -321,9 +318,11 @@ int conv1d_bwd_fused2(const float* small, const float* small2, long s_bs, const 
     if (dact) hipLaunchKernelGGL((conv1d_bwd_fused2_kernel<CS, CB, CONV, true, WL, T, TS_>), g, dim3(256), 0, st, a);  \
     else hipLaunchKernelGGL((conv1d_bwd_fused2_kernel<CS, CB, CONV, false, WL, T, TS_>), g, dim3(256), 0, st, a);      \
   } while (0)
-  if (Cs == 12 && pad == 0) LSHM_FUSED2(12, 8, false, true, float, float);
-  else if (Cs == 12) LSHM_FUSED2(12, 8, true, true, float, float);
-  else if (pad == 0 && big_bf16 && small_bf16) LSHM_FUSED2(8, 4, false, false, bf16, bf16);
+  if (Cs == 12) {  // (the register form of the 12 / 8 layers spilled 80-330 registers and was removed: LDS form or nothing)
+    set_last_error("conv1d_bwd_fused: the 12 / 8 channel layers need a length the LDS-staged kernel takes (a multiple of 128)");
+    return LSHM_ERR_UNSUPPORTED;
+  }
+  if (pad == 0 && big_bf16 && small_bf16) LSHM_FUSED2(8, 4, false, false, bf16, bf16);
   else if (pad == 0 && big_bf16) LSHM_FUSED2(8, 4, false, false, bf16, float);
   else if (pad == 0) LSHM_FUSED2(8, 4, false, false, float, float);
   else if (big_bf16 && small_bf16) LSHM_FUSED2(8, 4, true, false, bf16, bf16);
@@ -558,10 +557,10 @@ __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs 
 }
 
 bool conv1d_bwd_lds_supported(int Cs, int Cb, int Ls, int pad) {
-  if (getenv("LSHM_BWD_LDS_OFF")) return false;
+  if (sched(LSHM_SCHED_NO_BWD_LDS)) return false;
   if (Cs == 12 && Cb == 8) return Ls % 128 == 0 && (pad == 0 || pad == 1);
   // conv0 of the 1-D autoencoders (4 -> 8 channels, pad 1): the register form runs at 3.0 TB/s with two wavefronts per SIMD
-  return Cs == 8 && Cb == 4 && pad == 1 && Ls % 256 == 0 && !getenv("LSHM_BWD_LDS_8_4_OFF");
+  return Cs == 8 && Cb == 4 && pad == 1 && Ls % 256 == 0 && !sched(LSHM_SCHED_NO_BWD_LDS_8_4);
 }
 
 int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const float* big, const float* big2, long big_bs, float* ws,
@@ -584,7 +583,7 @@ int conv1d_bwd_lds(const float* small, const float* small2, long s_bs, const flo
   a.s_bs = s_bs; a.big_bs = big_bs; a.d_bs = fd.dx_bs;
   const int TP = Cs == 8 ? 256 : 128;
   a.Ls = Ls; a.Lb = Lb; a.ntiles = (Ls / TP) * B;
-  static const int cap_env = [] { const char* v = getenv("LSHM_GRID_BWD_LDS"); return v && atoi(v) > 0 ? atoi(v) : 256; }();
+  constexpr int cap_env = 256;
   // 256 workgroups per problem: 128 / 256 / 384 / 512 / 768 are within 0.01 ms of each other in the step; fewer slabs for the closing sums
   int grid = a.ntiles < cap_env ? a.ntiles : cap_env;
   if (grid > max_blocks) grid = max_blocks;

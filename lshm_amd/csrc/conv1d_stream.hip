@@ -346,9 +346,8 @@ int conv1d_wgrad_stream(const float* small, const float* small2, long s_bs, cons
                         long big_bs, float* ws, float* ws2, int B, int Cs, int Cb, int Ls, int Lb, int pad,
                         int bias_from, int max_blocks, hipStream_t st, int* grid_out, int big_bf16,
                         const FusedDgrad* fd, int small_bf16) {
-  // every fused layer but the original 8 -> 4 transposed one (which keeps its own kernel unless LSHM_FUSED2_ALL=1)
-  static const bool fused2_all = getenv("LSHM_FUSED2_ALL") != nullptr;
-  if (fd && fd->dx && (fused2_all || !(Cs == 8 && Cb == 4 && pad == 0) || !fd->dact))
+  // every fused layer but the original 8 -> 4 transposed one (which keeps its own kernel)
+  if (fd && fd->dx && (!(Cs == 8 && Cb == 4 && pad == 0) || !fd->dact))
     return conv1d_bwd_fused2(small, small2, s_bs, big, big2, big_bs, ws, ws2, B, Cs, Cb, Ls, Lb, pad, max_blocks, st,
                              grid_out, big_bf16, *fd, small_bf16);
   const float* w = fd ? fd->w : nullptr;

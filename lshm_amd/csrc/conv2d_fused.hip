@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
 }
 
 bool conv2d_bwd_lds_supported(int Cs, int Cb, int Hs, int Ws) {
-  return !getenv("LSHM_BWD_LDS2D_OFF") && Cs == CS && Cb == CB && Hs % TH == 0 && Ws % TW == 0;
+  return !sched(LSHM_SCHED_NO_BWD_LDS2D) && Cs == CS && Cb == CB && Hs % TH == 0 && Ws % TW == 0;
 }
 
 // conv != 0: conv layer (small = dz, big = saved input, dout = dbig); else transposed layer (small = saved input, big = dz,
@@ -358,7 +358,7 @@ int conv2d_bwd_lds(const float* small, long s_bs, const float* big, long big_bs,
   a.dout = dout; a.d_bs = conv ? big_bs : s_bs;
   a.partial = ws;
   a.Hs = Hs; a.Ws = Ws; a.ntiles = (Ws / TW) * (Hs / TH) * B;
-  static const int cap = [] { const char* v = getenv("LSHM_GRID_BWD_LDS2D"); return v && atoi(v) > 0 && atoi(v) <= 1024 ? atoi(v) : 512; }();
+  constexpr int cap = 512;  // persistent workgroups (two per CU)
   const int grid = a.ntiles < cap ? a.ntiles : cap;
   int rc;
 #define LSHM_B2D(CONV_, DACT_, TB_) do { \

@@ -356,9 +356,8 @@ int tconv2d_direct(const float* small, long s_bs, const float* w, const float* b
     else
       hipLaunchKernelGGL((tconv2d_q4_kernel<4>), grid, dim3(256), 0, st, small, s_bs, w, bias, big, big_bs, dact, Hs, Ws, act, ntiles);
   } else if (Cs == 12 && Cb == 8) {
-    static const int cap = [] { const char* v = getenv("LSHM_GRID_TCONV2D_12_8"); return v && atoi(v) > 0 ? atoi(v) : 512; }();
-    static const bool h8 = getenv("LSHM_TCONV2D_H8") != nullptr;
-    if (h8 || Hs % 4) {
+    constexpr int cap = 512;  // persistent workgroups (768 / 1024: 25.1 / 27.5 us against 25.6, profiles/r03)
+    if (Hs % 4) {  // (8-row tiles only where the height asks for them: measured equal at best, profiles/r03/README.md)
       const int ntiles = (Ws / 32) * (Hs / 8) * B;
       const dim3 grid(ntiles < cap ? ntiles : cap);
       if (big_bf16)
@@ -642,7 +641,7 @@ int conv2d_wgrad_direct(const float* small, long s_bs, const float* big, long bi
     else LSHM_WG2D(12, 8, 8, 32, float, float);
   } else if (Cs == 24 && Cb == 12) {
     const int ntiles = (Ws / 16) * (Hs / 8) * B;
-    static const int cap2412 = [] { const char* v = getenv("LSHM_GRID_WGRAD2D_24_12"); return v && atoi(v) > 0 && atoi(v) <= 1024 ? atoi(v) : 768; }();
+    constexpr int cap2412 = 768;
     grid = ntiles < cap2412 ? ntiles : cap2412;
     LSHM_WG2D(24, 12, 8, 16, float, float);
   } else {
@@ -1219,7 +1218,7 @@ int conv2d_direct(const float* x, long x_bs, const float* w, const float* bias, 
 #undef LSHM_Q4
   } else if (Cin == 8 && Cout == 12) {
     const int ntiles = (Wo / 32) * (Ho / 4) * B;
-    static const int cap = [] { const char* v = getenv("LSHM_GRID_CONV2D_8_12"); return v && atoi(v) > 0 ? atoi(v) : 512; }();
+    constexpr int cap = 512;  // persistent workgroups over four 4 x 32 tiles each (256 / 1024 / 2048: 26.3 / 22.8 / 29.0 us, profiles/r03)
     const dim3 grid(ntiles < cap ? ntiles : cap);
     if (x_bf16)
       hipLaunchKernelGGL((conv2d_direct_kernel<8, 12, 4, 32, bf16>), grid, dim3(256), 0, st, x, x_bs, w, bias, y, y_bs, dact, Ho, Wo, act, ntiles);
@@ -1432,7 +1431,7 @@ int conv1d_wgrad_mid(const float* small, long s_bs, const float* big, long big_b
   const int nw = Cs * Cb * 4, slab = nw + wgrad_bias_pad(Cs, Cb);
   const int TP = Cs == 24 ? 128 : 64;
   const int ntiles = (Ls / TP) * B;
-  static const int capmid = [] { const char* v = getenv("LSHM_GRID_WGRAD_MID"); return v && atoi(v) > 0 && atoi(v) <= 1024 ? atoi(v) : 256; }();
+  constexpr int capmid = 256;
   // (workgroups over the pair = partial slabs for the closing sums; per iteration 1024 / 512 / 256 / 128: 2.037 / 2.033 / 2.019 / 2.022 ms)
   int grid = ntiles < capmid / G ? ntiles : capmid / G;
   if (grid < 1) grid = 1;

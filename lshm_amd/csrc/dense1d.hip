@@ -457,9 +457,9 @@ __global__ __launch_bounds__(NTH) void dense_wide_bwd_kernel(const Dense1dBwdArg
 // matrix pipe of ONE CU (8448 instructions x 32 cycles / 4 SIMDs = 28 us at best; measured 50 us forward, 81 us
 // backward, +0.03 ms per iteration), where the separate split-K launches spread each layer over the machine
 bool dense1d_supported(int L, int hd, int rica) {
-  static const bool off = getenv("LSHM_DENSE1D_OFF") != nullptr;
-  static const bool wide = getenv("LSHM_DENSE2D") != nullptr;
-  return !off && rica && hd == HD && (L == LT || (wide && dense1d_built(L)));
+  // (the 224 / 256-wide forms are reachable through lshm_dense2d_* only: measured slower in the step, and the 2-D
+  //  autoencoder's dense layers now run inside lshm_deep2d_*)
+  return !sched(LSHM_SCHED_NO_DENSE1D) && rica && hd == HD && L == LT;
 }
 bool dense1d_built(int L) { return L == LT || L == 224 || L == 256; }
 

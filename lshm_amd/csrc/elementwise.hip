@@ -461,7 +461,7 @@ int recon_losses_fwd_bwd(const float* x, const float* x1, const float* x2, const
 // multiplier_update_recon with the reconstructions of netT / netF formed from the inputs of their last layer (fp32 storage;
 // sums left as per-block partials: recon_sum7 finishes them)
 bool recon_from_a_supported(int C, int P, int Cin, int Cout, int Ls) {
-  return !getenv("LSHM_RECON_FROM_A_OFF") && Cin == 8 && Cout == C && C >= 1 && C <= 8 && P % TILE == 0 && (long)Ls * 4 == (long)P * P;
+  return !sched(LSHM_SCHED_NO_RECON_FROM_A) && Cin == 8 && Cout == C && C >= 1 && C <= 8 && P % TILE == 0 && (long)Ls * 4 == (long)P * P;
 }
 int multiplier_update_recon_from_a(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT,
                                    const float* bT, const float* wF, const float* bF, int C, float* y1, float* y2, float* y3,

@@ -514,8 +514,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   jobs.cap = e->defer_floats;
   // the six dense layers' weight gradients (twelve for a pair) go as one launch once the last of their
   // gradients exists, instead of six latency-bound 5-10 us launches
-  static const bool batch_dense = getenv("LSHM_DENSE_WGRAD_SEPARATE") == nullptr;
-  jobs.batch_dense = batch_dense;
+  jobs.batch_dense = true;
   // Weight gradients need only dz and the saved input of their layer, and nothing waits for them
   // before the optimizer: with a side stream they form a second chain beside the data-gradient
   // chain, each link waiting for "dz is ready" on `st`; `st` itself never waits (the caller joins
@@ -525,8 +524,8 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // "dz ready" without a marker packet on `st` (common.h: launch_stop_event): the launches of one layer on `st` carry an
   // event of their own as stop event; as long as nothing else has been put on `st` since, that event IS "everything on
   // `st` so far", and the side stream waits for it directly.  Otherwise (first release of a pass, after callbacks,
-  // under capture, LSHM_STOP_EVENTS_OFF=1) an event is recorded as before.
-  static const bool stop_events = getenv("LSHM_STOP_EVENTS_OFF") == nullptr;
+  // under capture, LSHM_SCHED_NO_STOP_EVENTS) an event is recorded as before.
+  const bool stop_events = !(c.schedule & LSHM_SCHED_NO_STOP_EVENTS);
   const bool use_stop = side && stop_events && !e->in_capture;
   hipEvent_t last_ev = nullptr;
   auto on_st = [&](auto&& f) -> int {
@@ -557,7 +556,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // on both queues (a few microseconds each), which for 5-10 us kernels is most of their run time.
   // (groups of 1 / 2 / 3 / 4: 2.224 / 2.220 / 2.240 / 2.255 ms per iteration once a release cost `st` nothing; at the end of
   //  round 3, with fewer and fused weight-gradient launches: 1 / 2 / 3 = 2.024 / 2.045 / 2.055 -- every layer on its own)
-  static const int group = [] { const char* v = getenv("LSHM_WGRAD_GROUP"); return v ? atoi(v) : 1; }();
+  constexpr int group = 1;
   std::vector<std::function<int()>> pending;
   auto release = [&](bool force) -> int {
     if (pending.empty() || (!force && (int)pending.size() < group)) return LSHM_OK;
@@ -571,7 +570,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // the mid layers of the 1-D autoencoders: data gradients of three layers as one LDS-resident chain (chain1d.hip)
   const int chd[4] = {a0.dec[3].Cout, a0.dec[3].Cin, a0.dec[2].Cin, a0.dec[1].Cin};  // tconv3 <- tconv2 <- tconv1: stride-4 conv direction
   const int chu[4] = {a0.enc[4].Cout, a0.enc[4].Cin, a0.enc[3].Cin, a0.enc[2].Cin};  // conv4 -> conv3 -> conv2: transposed direction
-  static const bool chain_bwd = getenv("LSHM_CHAIN_BWD_OFF") == nullptr;
+  const bool chain_bwd = !(c.schedule & LSHM_SCHED_NO_CHAIN1D_BWD);
   const bool chain_dec = chain_bwd && a0.ndim == 1 && conv1d_chain_supported(false, chd, a0.dec[3].Win * 4);
   const bool chain_enc = chain_bwd && a0.ndim == 1 && conv1d_chain_supported(true, chu, a0.enc[4].Win / 4);
   // 2-D autoencoder: the data gradients of tconv2 .. conv2 (eleven layers) as one launch (deep2d.hip); their weight
@@ -654,7 +653,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   };
   // 1-D autoencoders: the four data gradients of the dense layers are one launch (dense1d.hip); the weight gradients
   // below still read the buffers it fills
-  static const bool dense_bwd_on = getenv("LSHM_DENSE1D_BWD_OFF") == nullptr;
+  const bool dense_bwd_on = !(c.schedule & LSHM_SCHED_NO_DENSE1D_BWD);
   const bool dense_chain = deepb || (dense_bwd_on && dense1d_supported(L, hd, c.rica));  // (deepb: the chain below has every dense data gradient)
   auto dgrad = [&](long lddz, long lddx, long ldxs, long ldadd, int add_n, int K, int N) {
     if (dense_chain) return (int)LSHM_OK;
@@ -913,20 +912,15 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
 // A forward alternates bandwidth-bound stretches (the outer layers, the residual split) with latency-bound ones
 // (mid / deep / dense layers: a few microseconds per launch on a fraction of the machine); in lock step like meets
 // like: the latency-bound stretches overlap almost for free, the bandwidth-bound ones share the HBM pipe.
-// LSHM_FORWARD_STAGGER=n holds the second chain n steps behind the first (its first launch waits for an event
-// after step n - 1 of the first), which pairs one chain's outer layers with the other's deep layers instead --
-// measured slower (see below).  The second forward does not need the reconstructions of netT / netF
-// (skip_b_1d_output).
+// (Holding the second chain n steps behind the first, which pairs one chain's outer layers with the other's deep layers,
+// was measured slower -- 0 / 6 / 12 / 24 steps: 2.28 / 2.32 / 2.39 / 2.49 ms, profiles/r03/README.md -- and removed.)
+// The second forward does not need the reconstructions of netT / netF (skip_b_1d_output).
 static int two_forwards(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws_a, hipStream_t st_a,
                         float* ws_b, hipStream_t st_b, bool skip_b_1d_output, bool skip_a_1d_output = false) {
   e->recon_ready = false;
   e->sum7_pending = false;
   const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
-  // default 0 (lock step, no gate).  Measured (profiles/r03/README.md): 0: 2.28 ms, 6: 2.32, 12: 2.39, 24: 2.49 -- a
-  // latency-bound launch beside a bandwidth-bound one is starved (up to 10x longer), so like phases belong together
-  static const int stagger_env = [] { const char* v = getenv("LSHM_FORWARD_STAGGER"); return v ? atoi(v) : 0; }();
   const int n = (int)P.steps.size();
-  const int lead = stagger_env < 0 ? 0 : stagger_env > n ? n : stagger_env;
   int rc;
   // two chains side by side: the deep sections take two patches per workgroup, so that each chain's launch fills half of
   // the CUs and every weight fetched from L2 serves two patches (bit for bit the one-patch results)
@@ -937,8 +931,8 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
   } variant_scope(e);
   // chain a is the forward whose activations are not kept (the no-grad forward): its residual split + conv0 pair is one launch
   const bool fused_a = skip_b_1d_output && P.resid_conv0 && P.resid_mark + 1 < (size_t)n;
-  for (int i = 0; i < n + lead; ++i) {
-    if (i < n) {
+  for (int i = 0; i < n; ++i) {
+    {
       if (fused_a && (size_t)i == P.resid_mark) {
         // (nothing: the residual is formed on the fly by the next step)
       } else if (skip_a_1d_output && (size_t)i == P.output1d_mark) {
@@ -949,16 +943,8 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
         return rc;
       }
     }
-    if (lead > 0 && i == lead - 1) {
-      hipEvent_t gate = e->take_event();
-      if (hipEventRecord(gate, st_a) != hipSuccess || hipStreamWaitEvent(st_b, gate, 0) != hipSuccess) {
-        set_last_error("engine: stream fork failed");
-        return LSHM_ERR_ARG;
-      }
-    }
-    const int j = i - lead;
-    if (j < 0 || ((size_t)j == P.output1d_mark && skip_b_1d_output)) continue;
-    if ((rc = P.steps[j](ws_b, st_b))) return rc;
+    if ((size_t)i == P.output1d_mark && skip_b_1d_output) continue;
+    if ((rc = P.steps[i](ws_b, st_b))) return rc;
   }
   return LSHM_OK;
 }
@@ -1094,8 +1080,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
                        (double)c.alpha * inv_count, c.rica, rica_part, LOGCOSH3_BLOCKS * 3);
     return check_launch("finalize_terms");
   };
-  static const bool late_join = getenv("LSHM_LATENT_JOIN_EARLY") == nullptr;
-  const bool deferred = grd && late_join && (e->pair_mode || !e->side_ok);
+  const bool deferred = grd && (e->pair_mode || !e->side_ok);
   if (!deferred && (rc = join_latent())) return rc;
   if (!grd)  // gradient-free closure (line search): every rank needs the global loss to take the same branch
     return e->comm ? comm_allreduce_segments(e->comm, nullptr, nullptr, 0, terms, 10, st) : LSHM_OK;
@@ -1185,10 +1170,11 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
 // of this thread, and a stream capture is refused where it is known to crash the runtime.
 struct EngineCall {
   MatrixPrecisionScope prec;
+  ScheduleScope sched_scope;
   int prev_dev = -1;
   bool switched = false;
   bool ok = true;  // false: the engine's device could not be made current -- nothing may be launched
-  explicit EngineCall(const lshm_engine* e) : prec(e->cfg.precision != LSHM_PRECISION_F32) {
+  explicit EngineCall(const lshm_engine* e) : prec(e->cfg.precision != LSHM_PRECISION_F32), sched_scope(e->cfg.schedule) {
     if (e->device < 0) return;
     if (hipGetDevice(&prev_dev) != hipSuccess) { (void)hipGetLastError(); ok = false; return; }
     if (prev_dev != e->device) {
@@ -1403,38 +1389,27 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   // side stream + events, fork mode only (host objects; absent on a machine without a HIP device)
   e->side_ok = false;
   e->next_event = 0;
-  e->pair_mode = getenv("LSHM_FORK") == nullptr;
+  e->pair_mode = !(cfg->schedule & LSHM_SCHED_FORK);
   e->device = -1;
   {
     int ndev = 0;
-    e->side_wgrad = getenv("LSHM_WGRAD_INLINE") == nullptr;
+    e->side_wgrad = !(cfg->schedule & LSHM_SCHED_WGRAD_INLINE);
     if (hipGetDeviceCount(&ndev) == hipSuccess && ndev > 0 && hipGetDevice(&e->device) != hipSuccess) e->device = -1;
     if (e->device >= 0 && (!e->pair_mode || e->side_wgrad)) {
       // the weight-gradient stream sits BELOW the caller's stream in the dispatcher's order: when both have a kernel ready the
-      // data-gradient chain (every link of which something waits for) gets the CUs first.  2.145 against 2.155 ms per
-      // iteration; above it: 2.153 (LSHM_WST_PRIORITY=normal|high for A/B)
+      // data-gradient chain (every link of which something waits for) gets the CUs first (2.145 against 2.155 ms per iteration;
+      // above it: 2.153).  The no-grad forward's stream sits ABOVE: the reconstruction pass and with it the backward wait for
+      // that chain, the closure forward beside it has slack (2.127 against 2.141 ms; below: 2.139; profiles/r03/README.md)
       int plo = 0, phi = 0;
       (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-      const char* wp = getenv("LSHM_WST_PRIORITY");
-      bool ok = ((wp && wp[0] == 'n') ? hipStreamCreateWithFlags(&e->wstream, hipStreamNonBlocking)
-                                      : hipStreamCreateWithPriority(&e->wstream, hipStreamNonBlocking, (wp && wp[0] == 'h') ? phi : plo)) == hipSuccess;
+      bool ok = hipStreamCreateWithPriority(&e->wstream, hipStreamNonBlocking, plo) == hipSuccess;
       ok = ok && hipStreamCreateWithFlags(&e->lstream, hipStreamNonBlocking) == hipSuccess;
-      {  // the no-grad forward's stream ABOVE the caller's: the reconstruction pass and with it the backward wait for that
-         // chain (it is the longer one: it also runs the 1-D output layers), the closure forward beside it has ~0.2 ms of
-         // slack (profiles/r03/phase_times.txt).  2.127 against 2.141 ms; below: 2.139 (LSHM_FST_PRIORITY=normal|low for A/B)
-        const char* fp = getenv("LSHM_FST_PRIORITY");
-        ok = ok && ((fp && fp[0] == 'n') ? hipStreamCreateWithFlags(&e->fstream, hipStreamNonBlocking)
-                                         : hipStreamCreateWithPriority(&e->fstream, hipStreamNonBlocking, (fp && fp[0] == 'l') ? plo : phi)) == hipSuccess;
-      }
-      {
-        const char* v = getenv("LSHM_EVENT_POOL");
-        const int n = v ? atoi(v) : 256;
-        e->events.resize(n >= 32 ? n : 32);
-      }
+      ok = ok && hipStreamCreateWithPriority(&e->fstream, hipStreamNonBlocking, phi) == hipSuccess;
+      e->events.resize(256);
       for (size_t i = 0; i < e->events.size() && ok; ++i)
         ok = ok && hipEventCreateWithFlags(&e->events[i], hipEventDisableTiming) == hipSuccess;
       e->side_ok = ok;
-      if (ok && getenv("LSHM_PHASE_EVENTS")) {
+      if (ok && (cfg->schedule & LSHM_SCHED_PHASE_EVENTS)) {
         e->phase.resize(lshm_engine::PH_COUNT);
         for (auto& ev : e->phase) ok = ok && hipEventCreate(&ev) == hipSuccess;
         if (!ok) e->phase.clear();
@@ -1511,9 +1486,17 @@ int lshm_engine_set_comm(lshm_engine* e, lshm_comm* comm) {
 }
 
 int lshm_engine_device(const lshm_engine* e) { return e ? e->device : -1; }
+unsigned lshm_engine_set_schedule(lshm_engine* e, unsigned schedule) {
+  if (!e) return 0u;
+  const unsigned fixed = LSHM_SCHED_NO_DEEP2D | LSHM_SCHED_NO_DEEP2D_BWD | LSHM_SCHED_TRY_FULL1D | LSHM_SCHED_WGRAD_INLINE | LSHM_SCHED_FORK |
+                         LSHM_SCHED_PHASE_EVENTS;
+  e->cfg.schedule = (e->cfg.schedule & fixed) | (schedule & ~fixed);
+  e->plan.steps.clear();  // the cached forward plan was built under the old word
+  return e->cfg.schedule;
+}
 int lshm_engine_phase_times(const lshm_engine* e, float* ms, int n) {
   if (!e || !ms || n < 1) { set_last_error("engine_phase_times: bad argument"); return LSHM_ERR_ARG; }
-  if (e->phase.empty()) { set_last_error("engine_phase_times: the engine was created without LSHM_PHASE_EVENTS=1"); return LSHM_ERR_UNSUPPORTED; }
+  if (e->phase.empty()) { set_last_error("engine_phase_times: the engine was created without LSHM_SCHED_PHASE_EVENTS"); return LSHM_ERR_UNSUPPORTED; }
   EngineCall scope(e);  // the events live on the engine's device, whatever device is current in the caller
   if (!scope.ok) { set_last_error("engine: cannot make the engine's device current"); return LSHM_ERR_ARG; }
   if (hipDeviceSynchronize() != hipSuccess) { set_last_error("engine_phase_times: device synchronisation failed"); return LSHM_ERR_ARG; }

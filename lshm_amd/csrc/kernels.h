@@ -4,6 +4,7 @@
 #pragma once
 #include <vector>
 #include "common.h"
+#include "../../include/lshm.h"
 
 namespace lshm {
 
@@ -171,6 +172,18 @@ struct MatrixPrecisionScope {
   MatrixPrecisionScope& operator=(const MatrixPrecisionScope&) = delete;
 };
 int igemm_matrix_precision();  // of the calling thread's innermost scope
+// Schedule word (LSHM_SCHED_*, include/lshm.h) of the calling thread's innermost scope: an engine call runs under its
+// engine's lshm_step_config.schedule, the per-op C ABI under 0 (the shipped choices) unless its `_ex` form is given a word.
+// No environment variable chooses a kernel.
+struct ScheduleScope {
+  unsigned prev;
+  explicit ScheduleScope(unsigned word);
+  ~ScheduleScope();
+  ScheduleScope(const ScheduleScope&) = delete;
+  ScheduleScope& operator=(const ScheduleScope&) = delete;
+};
+unsigned schedule_word();
+inline bool sched(unsigned bit) { return (schedule_word() & bit) != 0; }
 size_t igemm_tuning_export(char* buf, size_t cap);  // returns the bytes needed (with the terminating 0)
 int igemm_tuning_import(const char* text);          // returns the entries read
 

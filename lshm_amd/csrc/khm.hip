@@ -686,7 +686,7 @@ __global__ __launch_bounds__(256) void khm_mfma_kernel(
 }
 static size_t khm_mfma_lds_bytes() { return (size_t)(4 * 16 * 64 * 4 + 64 * KHM_MM_XP + 64 * KHM_MM_WP + 64 + 256) * sizeof(float); }
 static bool khm_mfma_ok(int D, int K, long ldx, long lddx, const float* X, const float* dX, const float* M) {
-  static const bool off = getenv("LSHM_KHM_MFMA_OFF") != nullptr;
+  const bool off = sched(LSHM_SCHED_NO_KHM_MFMA);
   // 152 KB of LDS per workgroup: only where the device has it (gfx950: 160 KB); elsewhere the row-split kernel runs
   const int lds = device_lds_bytes();
   if (lds > 0 && khm_mfma_lds_bytes() > (size_t)lds) return false;

@@ -231,7 +231,7 @@ int conv_layer_dgrad(const ConvLayer& L, const ConvDgradIO& io, float* ws, size_
 }
 
 bool conv_layer_bwd_fusable(const ConvLayer& L, const ConvWgradIO& io, const ConvDgradIO& dio) {
-  if (getenv("LSHM_BWD_FUSED_OFF") || !dio.dx || dio.dz != io.dz || L.in_bs % 4 != 0) return false;
+  if (sched(LSHM_SCHED_NO_ONE_PASS_BWD) || !dio.dx || dio.dz != io.dz || L.in_bs % 4 != 0) return false;
   // the ELU' reference of the data gradient, if any, must be the layer's own input (it is, for every layer behind an ELU)
   if (dio.dact_in && dio.dact_in != io.x) return false;
   if (L.kind == 0) {  // 2-D conv: conv1 (8 -> 12 channels), fp32 storage
@@ -240,7 +240,7 @@ bool conv_layer_bwd_fusable(const ConvLayer& L, const ConvWgradIO& io, const Con
     return !L.out_bf16 && L.out_bs % 4 == 0 && conv2d_bwd_lds_supported(L.Cout, L.Cin, Ho2, Wo2);  // (its input may be bf16)
   }
   if (L.kind == 1)  // 2-D transposed: the outermost decoder layer (8 -> 4 channels) and, fp32 storage, tconv4 (12 -> 8)
-    return (!getenv("LSHM_BWD_FUSED2D_OFF") && tconv2d_bwd_fused_supported(L.Cin, L.Cout, L.Hin, L.Win)) ||
+    return (!sched(LSHM_SCHED_NO_BWD_FUSED2D) && tconv2d_bwd_fused_supported(L.Cin, L.Cout, L.Hin, L.Win)) ||
            (!L.in_bf16 && L.out_bs % 4 == 0 && conv2d_bwd_lds_supported(L.Cin, L.Cout, L.Hin, L.Win));  // (its output may be bf16)
   if (L.kind == 3)  // transposed: small = the layer's input, big = dz
     return conv1d_bwd_fused_supported(L.Cin, L.Cout, 0) && (dio.dact_in || conv1d_bwd_fused2_supported(L.Cin, L.Cout, 0)) &&
@@ -332,7 +332,7 @@ int conv_layer_wgrad(const ConvLayer& L, const ConvWgradIO& io, float* ws, size_
     }
     if (fuse) { set_last_error("conv wgrad: fused data gradient not available for this layer"); return LSHM_ERR_UNSUPPORTED; }
     if (big_bf16 || small_bf16) return bf16_unsupported();
-    static const bool use_mid = getenv("LSHM_WGRAD_MID_OFF") == nullptr;
+    const bool use_mid = !sched(LSHM_SCHED_NO_WGRAD_MID);
     if (use_mid && gemm_wsf >= G * conv1d_wgrad_mid_workspace_floats(Cs, Cb) &&
         conv1d_wgrad_mid_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(io), big_of(io)) &&
         (!io2 || conv1d_wgrad_mid_supported(Cs, Cb, Ls, Lb, tr ? 0 : 1, bias_from, s_bs, big_bs, small_of(*io2),

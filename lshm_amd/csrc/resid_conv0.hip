@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void resid_conv0_kernel(const ResidConv0Args a
 }
 
 bool resid_conv0_supported(int C, int Pp, int Cin, int Cout, int L1d) {
-  return !getenv("LSHM_RESID_CONV0_OFF") && C == CI && Pp == P && Cin == CI && Cout == CO && L1d == L;
+  return !sched(LSHM_SCHED_NO_RESID_CONV0) && C == CI && Pp == P && Cin == CI && Cout == CO && L1d == L;
 }
 
 int resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,

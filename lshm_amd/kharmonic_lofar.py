@@ -81,8 +81,10 @@ class TrainConfig:
     # After the optimiser step the no-grad forward that closes iteration k (:187-196) and the closure forward
     # that opens iteration k+1 (:135-150) depend on the updated parameters alone.  True (default): they are
     # issued together, as two chains on two HIP streams with separate activation buffers
-    # (lshm_engine_multiplier_update_next_ex, LSHM_NEXT_CONCURRENT_FORWARD); both are computed, as upstream
-    # computes both -- neither waits for the other.  Same trajectory bit for bit.  False: one after the other.
+    # (lshm_engine_multiplier_update_next_ex, LSHM_NEXT_CONCURRENT_FORWARD); neither waits for the other.  Both forwards
+    # run, up to their common subexpressions: the closure forward leaves out the last layer of netT / netF (nothing
+    # reads its copy of their reconstructions) and, with share_recon_pass, takes its reconstruction terms and gradient
+    # images from the pass behind the no-grad forward.  Same trajectory bit for bit.  False: one after the other.
     overlap_forwards: bool = True
     # Schedule choices of the engine to switch OFF (names of lshm_amd._lib.SCHEDULE_BITS, e.g. ("no_deep2d",)): each
     # restores the launch sequence the choice replaced -- for A/B measurements and the tests that hold a fused kernel's
@@ -212,6 +214,16 @@ class KHarmonicTrainer:
         self._comm = comm
         early = agree(bool(self.lib.lshm_engine_comm_early_bucket(self._h)), process_group)
         L.check(self.lib.lshm_engine_set_early_bucket(self._h, int(early)), "engine_set_early_bucket")
+
+    def set_schedule_off(self, names=()):
+        """Replace the per-call schedule choices that are switched off (lshm_engine_set_schedule; the bits that shaped the
+        engine at creation keep their value).  Returns the names in effect."""
+        word = 0
+        for n in names:
+            word |= L.SCHEDULE_BITS[n]
+        got = self.lib.lshm_engine_set_schedule(self._h, word)
+        self.invalidate_forward()
+        return tuple(n for n, b in L.SCHEDULE_BITS.items() if got & b)
 
     def _stream(self):
         return L.stream(self.device)

@@ -1,16 +1,15 @@
 #!/usr/bin/env python3
 """Where one ADMM iteration spends its time WITHOUT a profiler: device timestamps at the phase boundaries
-(LSHM_PHASE_EVENTS=1 -> lshm_engine_phase_times, include/lshm.h), B = 256, K = 10, fp32, the default schedule.
+(LSHM_SCHED_PHASE_EVENTS in the engine's schedule word -> lshm_engine_phase_times, include/lshm.h), B = 256, K = 10, fp32, the default schedule.
 Each mark is a hipEventRecord (a marker packet: ~6 us of idle queue on its stream), so the instrumented iteration is
-a little slower than the bench line's.  Usage: LSHM_PHASE_EVENTS=1 python profiles/phase_times_probe.py"""
+a little slower than the bench line's.  Usage: [PROBE_SCHEDULE_OFF=name,..] python profiles/phase_times_probe.py"""
 import ctypes as C, os, sys
-os.environ.setdefault("LSHM_PHASE_EVENTS", "1")
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lshm_amd import KHarmonicTrainer, TrainConfig, _lib as L
 
 B, dev = 256, torch.device("cuda:0")
-cfg = TrainConfig(Kc=10, schedule_off=tuple(n for n in os.environ.get("PROBE_SCHEDULE_OFF", "").split(",") if n),
+cfg = TrainConfig(Kc=10, schedule_off=("phase_events",) + tuple(n for n in os.environ.get("PROBE_SCHEDULE_OFF", "").split(",") if n),
                   tune=int(os.environ.get("PROBE_TUNE", 0)))
 tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=8, default_batch=B // 8, device=dev)
 tr.init_parameters(seed=0)

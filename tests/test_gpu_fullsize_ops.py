@@ -147,28 +147,23 @@ def test_dense_layers_at_full_batch(K, N, act):
 
 
 @pytest.mark.parametrize("kind,i,elu_grad,form", [(3, 5, 1, ""), (3, 4, 1, "lds"), (2, 1, 1, "lds"), (3, 4, 0, "lds"), (2, 1, 0, "lds"),
-                                                  (3, 4, 1, "reg"), (2, 1, 1, "reg"), (2, 0, 0, "lds"), (2, 0, 1, "lds"),
+                                                  (2, 0, 0, "lds"), (2, 0, 1, "lds"),
                                                   (2, 0, 0, "reg84"), (2, 0, 1, "reg84"), (3, 5, 0, ""), (1, 5, 1, ""), (1, 5, 0, ""),
                                                   (1, 4, 1, ""), (1, 4, 0, ""), (0, 1, 1, ""), (0, 1, 0, "")],
-                         ids=["tconv5", "tconv4", "conv1", "tconv4-noelu", "conv1-noelu", "tconv4-registers", "conv1-registers",
+                         ids=["tconv5", "tconv4", "conv1", "tconv4-noelu", "conv1-noelu",
                               "conv0", "conv0-elu", "conv0-registers", "conv0-elu-registers", "tconv5-noelu", "2d-tconv5",
                               "2d-tconv5-noelu", "2d-tconv4", "2d-tconv4-noelu", "2d-conv1", "2d-conv1-noelu"])
-def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, form, monkeypatch):
+def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, form):
     """lshm_conv_bwd_fused (weight + bias + data gradient from one read of dz and the saved input; backward of
     src/lofar_models.py:115-117,140-142) against the pair of kernels it replaces (lshm_conv_wgrad + lshm_conv_dgrad)
     and against fp64, at B = 256: the weight / bias gradients come from the same MFMA sequence as the stand-alone
     weight-gradient kernel (fp32 rounding apart: the pad-1 windows are assembled from other loads), the data
-    gradient agrees to fp32 rounding."""
+    gradient agrees to fp32 rounding.  "registers": 1-D conv0 on the register form (LSHM_SCHED_NO_BWD_LDS_8_4 through
+    lshm_conv_bwd_fused_ex: the kernel bf16 storage runs)."""
     from lshm_amd import _lib as L
     lib = L.load()
     ishape, wshape, cin, cout = _shapes(kind, i)
-    monkeypatch.delenv("LSHM_BWD_LDS_8_4_OFF", raising=False)
-    if form == "reg84":
-        monkeypatch.setenv("LSHM_BWD_LDS_8_4_OFF", "1")  # conv0 on the register form (what bf16 storage still uses)
-    if form == "reg":
-        monkeypatch.setenv("LSHM_FUSED2_12_8", "1")  # the register form of the 12 / 8 channel layers (opt-in: it spills)
-    else:
-        monkeypatch.delenv("LSHM_FUSED2_12_8", raising=False)  # default: the LDS-staged form (conv1d_bwd_lds_kernel)
+    word = L.SCHEDULE_BITS["no_bwd_lds_8_4"] if form == "reg84" else 0
     g = torch.Generator().manual_seed(31 * kind + i)
     x = TF.elu(torch.randn(ishape, generator=g))  # the saved input of a layer behind an ELU
     fan = (cout if kind in (1, 3) else cin) * (16 if kind < 2 else 4)  # (any scale will do: the products are linear in w)
@@ -184,8 +179,8 @@ def test_one_pass_backward_of_outer_layers(kind, i, elu_grad, form, monkeypatch)
     ws = torch.empty(nws, device=DEV)
     st = L.stream()
     dw, db, dx = torch.empty(wshape, device=DEV), torch.empty(cout, device=DEV), torch.full(ishape, float("nan"), device=DEV)
-    L.check(lib.lshm_conv_bwd_fused(kind, L.ptr(xd), L.ptr(dzd), L.ptr(wd), L.ptr(dw), L.ptr(db), L.ptr(dx), elu_grad, B, cin,
-                                    cout, Hin, Win, L.ptr(ws), nws, st), "conv_bwd_fused")
+    L.check(lib.lshm_conv_bwd_fused_ex(kind, L.ptr(xd), L.ptr(dzd), L.ptr(wd), L.ptr(dw), L.ptr(db), L.ptr(dx), elu_grad, B, cin,
+                                       cout, Hin, Win, L.ptr(ws), nws, word, st), "conv_bwd_fused")
     dw2, db2, dx2 = torch.empty_like(dw), torch.empty_like(db), torch.empty_like(dx)
     L.check(lib.lshm_conv_wgrad(kind, L.ptr(xd), L.ptr(dzd), L.ptr(dw2), L.ptr(db2), B, cin, cout, Hin, Win, 0, 0, L.ptr(ws),
                                 nws, 0, st), "conv_wgrad")

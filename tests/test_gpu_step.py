@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _trainer(B, K, bpb, bs, groups=("net", "netT", "netF", "mod"), rica=True):
+def _trainer(B, K, bpb, bs, groups=("net", "netT", "netF", "mod"), rica=True, schedule_off=()):
     from lshm_amd import KHarmonicTrainer, TrainConfig
-    cfg = TrainConfig(Kc=K, use_rica=rica, train_groups=groups)
+    cfg = TrainConfig(Kc=K, use_rica=rica, train_groups=groups, schedule_off=schedule_off)
     ocfg = O.StepConfig(K=K, bpb=bpb, batch_size=bs, rica=rica)
     params, M = O.make_params(ocfg)
     tr = KHarmonicTrainer(cfg, batch=B, batch_per_bline=bpb, default_batch=bs, device=DEV)
@@ -286,12 +286,12 @@ def test_step_with_k64_clusters():
 # ---------------------------------------------------------------------------------------------
 # full-size (BASELINE.json configs[1]: B=256, K=10) checks through size-independent properties
 # ---------------------------------------------------------------------------------------------
-def _full_trainer(world=1, batch=256, bs=None, K=10, precision="fp32"):
+def _full_trainer(world=1, batch=256, bs=None, K=10, precision="fp32", schedule_off=()):
     from lshm_amd import KHarmonicTrainer, TrainConfig
     import ctypes as C
     from lshm_amd import _lib as L
-    cfg = (TrainConfig(Kc=K, matrix_precision="bf16", activation_storage="bf16") if precision == "bf16s" else
-           TrainConfig(Kc=K, matrix_precision=precision))
+    cfg = (TrainConfig(Kc=K, matrix_precision="bf16", activation_storage="bf16", schedule_off=schedule_off) if precision == "bf16s" else
+           TrainConfig(Kc=K, matrix_precision=precision, schedule_off=schedule_off))
     tr = KHarmonicTrainer(cfg, batch=batch, batch_per_bline=8,
                           default_batch=bs if bs is not None else batch // 8, device=DEV)
     if world != 1:
@@ -330,20 +330,14 @@ def test_full_size_step_is_bitwise_reproducible_and_finite(K, precision):
 
 def test_full_size_two_stream_schedule_equals_single_stream():
     """The side stream (weight-gradient chain, latent-space terms) only re-orders launches: with
-    LSHM_WGRAD_INLINE=1 everything runs on the caller's stream.  Same kernels, same summation orders, so
+    LSHM_SCHED_WGRAD_INLINE everything runs on the caller's stream.  Same kernels, same summation orders, so
     3 iterations at B=256 must agree bit for bit - a missing event dependency would show up here."""
-    import os
     g = torch.Generator().manual_seed(11)
     x = torch.randn(256, 4, 128, 128, generator=g)
     uv = 1000.0 * torch.randn(256, 2, generator=g)
     outs = []
     for inline in (False, True):
-        if inline:
-            os.environ["LSHM_WGRAD_INLINE"] = "1"
-        try:
-            tr = _full_trainer()  # the engine reads the switch when it is created
-        finally:
-            os.environ.pop("LSHM_WGRAD_INLINE", None)
+        tr = _full_trainer(schedule_off=("wgrad_inline",) if inline else ())  # (a creation-time choice of the engine)
         tr.new_minibatch(x.to(DEV), uv.to(DEV))
         for _ in range(3):
             tr.step()
@@ -357,7 +351,7 @@ def test_full_size_two_stream_schedule_equals_single_stream():
 @pytest.mark.parametrize("precision", ["fp32", "bf16s"], ids=["fp32", "bf16-storage"])
 def test_fused_backward_of_outer_1d_layer_matches_separate_kernels(precision):
     """conv1d_bwd_fused_kernel (weight + bias + data gradient of netT / netF's last decoder layer from one pass,
-    src/lofar_models.py:141-142 backward) against the two kernels it replaces (LSHM_BWD_FUSED_OFF=1), full size:
+    src/lofar_models.py:141-142 backward) against the two kernels it replaces (LSHM_SCHED_NO_ONE_PASS_BWD), full size:
     the weight and bias gradients of that layer come from the same MFMA sequence (bitwise equal); everything
     upstream of its data gradient agrees to fp32 rounding (another summation order over the 16 taps x channels)."""
     g = torch.Generator().manual_seed(23)
@@ -369,13 +363,9 @@ def test_fused_backward_of_outer_1d_layer_matches_separate_kernels(precision):
         tr.y[k].normal_(0.0, 0.01)
     grads = []
     for off in (False, True):
-        if off:
-            os.environ["LSHM_BWD_FUSED_OFF"] = "1"
-        try:
-            tr.closure_only()
-            torch.cuda.synchronize()
-        finally:
-            os.environ.pop("LSHM_BWD_FUSED_OFF", None)
+        tr.set_schedule_off(("no_one_pass_bwd",) if off else ())
+        tr.closure_only()
+        torch.cuda.synchronize()
         grads.append(tr.grads.clone())
     for net in ("netT", "netF"):
         for leaf in ("tconv5.weight", "tconv5.bias"):
@@ -663,14 +653,9 @@ def test_checkpoint_files_roundtrip_into_the_modules(tmp_path):
 
 
 def test_capture_is_refused_in_fork_mode():
-    """LSHM_FORK=1 nests stream forks, and ending a capture of that topology crashes hipStreamEndCapture
+    """LSHM_SCHED_FORK nests stream forks, and ending a capture of that topology crashes hipStreamEndCapture
     (ROCm 7.2): the engine refuses a capturing stream in that mode instead (LSHM_ERR_UNSUPPORTED)."""
-    import os
-    os.environ["LSHM_FORK"] = "1"
-    try:
-        tr, *_ = _trainer(4, 4, 2, 2)  # the engine reads the switch when it is created
-    finally:
-        os.environ.pop("LSHM_FORK", None)
+    tr, *_ = _trainer(4, 4, 2, 2, schedule_off=("fork",))  # (a creation-time choice of the engine)
     tr.step()  # eager launches work in fork mode
     torch.cuda.synchronize()
     s = torch.cuda.Stream()
@@ -879,8 +864,8 @@ def test_engine_reports_its_device_and_refuses_what_is_not_on_it():
     assert torch.isfinite(tr.params).all() and not torch.equal(before, tr.params)
 
 
-def test_phase_timestamps_are_opt_in_and_ordered(monkeypatch):
-    """lshm_engine_phase_times (include/lshm.h): an engine created under LSHM_PHASE_EVENTS=1 reports the device time of the
+def test_phase_timestamps_are_opt_in_and_ordered():
+    """lshm_engine_phase_times (include/lshm.h): an engine created with LSHM_SCHED_PHASE_EVENTS reports the device time of the
     phase boundaries of the last iteration in the order the schedule runs them; any other engine refuses; the marks do
     not change the trajectory."""
     import ctypes as C
@@ -888,9 +873,7 @@ def test_phase_timestamps_are_opt_in_and_ordered(monkeypatch):
     plain, *_ = _trainer(4, 4, 2, 2)
     ms = (C.c_float * 10)()
     assert plain.lib.lshm_engine_phase_times(plain._h, ms, 10) == -3
-    monkeypatch.setenv("LSHM_PHASE_EVENTS", "1")
-    tr, *_ = _trainer(4, 4, 2, 2)
-    monkeypatch.delenv("LSHM_PHASE_EVENTS")
+    tr, *_ = _trainer(4, 4, 2, 2, schedule_off=("phase_events",))
     for _ in range(3):
         plain.step()
         tr.step()
@@ -935,3 +918,40 @@ def test_admm_loop_with_staged_minibatches_is_the_recompute_trajectory():
     assert torch.equal(out[0][0], out[1][0])
     assert all(torch.equal(p, q) for p, q in zip(out[0][1], out[1][1]))
     assert out[0][2] == out[1][2]
+
+
+def test_schedule_is_per_engine_and_the_launch_trace_shows_it():
+    """lshm_step_config.schedule belongs to ONE engine (no environment variable chooses a kernel): two trainers of one
+    process, one with the deep chains and the 1-D chains switched off, interleave their iterations; the per-launch trace
+    (lshm_trace_*) shows the one-launch kernels only in the iterations of the trainer that has them, and the two
+    trajectories agree to rounding."""
+    import ctypes as C
+    from lshm_amd import _lib as L
+    a, *_ = _trainer(4, 4, 2, 2)
+    b, *_ = _trainer(4, 4, 2, 2, schedule_off=("no_deep2d", "no_deep2d_bwd", "no_chain1d", "no_chain1d_bwd", "no_dense1d", "no_dense1d_bwd"))
+    lib = a.lib
+
+    def names_of(tr):
+        L.check(lib.lshm_trace_begin(2048), "trace_begin")
+        try:
+            tr.step()
+            n = lib.lshm_trace_end()
+            torch.cuda.synchronize()
+            out, buf = [], C.create_string_buffer(256)
+            st, du, sx, gt = C.c_float(), C.c_float(), C.c_int(), C.c_uint()
+            for i in range(n):
+                L.check(lib.lshm_trace_read(i, buf, 256, C.byref(st), C.byref(du), C.byref(sx), C.byref(gt)), "trace_read")
+                assert du.value > 0.0 and st.value >= 0.0
+                out.append(buf.value.decode())
+        finally:
+            lib.lshm_trace_free()
+        return out
+
+    for _ in range(2):
+        na, nb = names_of(a), names_of(b)
+        assert any("deep2d_kernel" in s for s in na) and any("conv1d_chain" in s for s in na) and any("dense1d" in s for s in na)
+        assert not any("deep2d_kernel" in s or "conv1d_chain" in s or "dense1d" in s for s in nb)
+        assert len(nb) > len(na) + 20  # the launches the chains replace
+    torch.cuda.synchronize()
+    assert rel_err(a.params, b.params) < 1e-6
+    assert lib.lshm_trace_end() == -1  # not recording any more
