@@ -552,6 +552,84 @@ def _variant(args, dev, pg, rank, world, barrier, x, uv, **cfg_kw):
             "loss_total": terms["total"], "nonfinite_terms": terms["nonfinite"]}
 
 
+def dp_evidence(tr, dev, rank, world):
+    """What the N > 1 line is worth, measured THROUGH the process group instead of read from the environment: how many
+    ranks a SUM all-reduce of 1 sees, which device every rank computes on (gathered), which data-parallel path the
+    trainer took, and the time of one all-reduce of the gradient arena (6.9 MB at K = 10)."""
+    import torch.distributed as dist
+    one = torch.ones(1, device=dev)
+    dist.all_reduce(one)
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device_index": dev.index, "name": props.name,
+          "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")),
+          "shared_with_other_ranks": os.environ.get("LSHM_SHARE_GPU0") == "1"}
+    devices = [None] * world
+    dist.all_gather_object(devices, me)
+    buf = torch.zeros(tr.nparams, device=dev)
+    for _ in range(3):
+        dist.all_reduce(buf)
+    torch.cuda.synchronize()
+    dist.barrier()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(10):
+        dist.all_reduce(buf)
+    b.record()
+    torch.cuda.synchronize()
+    us = torch.tensor([a.elapsed_time(b) * 100.0], device=dev, dtype=torch.float64)  # per all-reduce, us
+    dist.all_reduce(us, op=dist.ReduceOp.MAX)
+    return {"ranks_seen": int(round(one.item())), "devices": devices,
+            "path": "engine" if getattr(tr, "_comm", None) is not None else "torch",
+            "backend": dist.get_backend(), "allreduce_bytes": 4 * tr.nparams, "allreduce_us": round(us.item(), 1)}
+
+
+def config5_mode(args, dev, pg, rank, world, barrier):
+    """BASELINE.json configs[4] at one GPU per rank: the loader's minibatch (int8 visibilities of a synthetic SAP -> 3 x 3
+    overlapping 128-patches per baseline, normalised, lofar_tools.get_data_minibatch's device pipeline: lshm_patches_from_vis)
+    -> K = 64 clusters -> LBFGSNew refinement (history 7, max_iter 4, line search, batch mode; src/kharmonic_lofar.py:93,118),
+    ms per ADMM iteration.  28 baselines x 9 patches = 252 patches per minibatch (the largest whole-baseline batch <= 256)."""
+    from lshm_amd import KHarmonicTrainer, TrainConfig
+    from lshm_amd.lofar_tools import minibatch_from_sap
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tests.h5_fixture import make_sap
+    nb = 28
+    sap, info = make_sap(nbase=10, ntime=256, nfreq=256)  # (ten baselines in the synthetic SAP: drawn with replacement, as upstream's np.random.randint does)
+    t0 = time.perf_counter()
+    px, py, xb, uvb = minibatch_from_sap(sap, info, batch_size=nb, patch_size=128, normalize_data=True, num_channels=4,
+                                         uvdist=True, baselinelist=[(3 * i + 1) % 10 for i in range(nb)], device=dev)
+    torch.cuda.synchronize()
+    t_load = time.perf_counter() - t0
+    bpb = px * py
+    B = xb.shape[0]
+    tr = KHarmonicTrainer(TrainConfig(Kc=64), batch=B, batch_per_bline=bpb, default_batch=nb, device=dev, process_group=pg)
+    tr.init_parameters(seed=0)
+    tr.new_minibatch(xb.to(dev), uvb.to(dev))
+    opt = tr.make_lbfgs()
+    for _ in range(3):
+        tr.step_lbfgs(opt)
+    nl = max(2, args.steps // 5)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(nl):
+        tr.step_lbfgs(opt)
+    barrier()
+    dt = time.perf_counter() - t1
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    terms = tr.read_terms()
+    del tr
+    torch.cuda.empty_cache()
+    return {"value": round(world * B * nl / dt, 1), "unit": "patches/s", "ms_per_step": round(dt / nl * 1e3, 3), "steps": nl,
+            "patches_per_minibatch": B, "bpb": bpb, "K": 64, "optimizer": "LBFGSNew(history 7, max_iter 4, line search, batch mode)",
+            "loader_ms": round(t_load * 1e3, 2), "loss_total": terms["total"], "nonfinite_terms": terms["nonfinite"],
+            "note": "configs[4] composed on one GPU per rank: synthetic int8 SAP through the device patch pipeline (h5py itself is "
+                    "absent from the image), K = 64, LBFGSNew; tests/test_gpu_step.py::test_config5_composition_loader_k64_lbfgs holds "
+                    "the composition to the CPU oracle"}
+
+
 def admm10_loop(args, dev, pg, rank, world, barrier, gen):
     """The loop the reference runs (src/kharmonic_lofar.py:116-131,176-181): per minibatch ten ADMM iterations with the
     eight terms read back on the host in every one; a NEW minibatch every ten iterations, handed over as host
@@ -746,6 +824,8 @@ def main():
                         "note": "algorithmic 15.04 MB/patch (SURVEY 8d: layer-wise read input + write output, glue passes "
                                 "counted as zero); traffic = PMC HBM bytes summed over the iteration's launches"}}
     out["step_roofline"] = {k: out["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    if world > 1:
+        out["dp"] = dp_evidence(tr, dev, rank, world)
     if reuse is not None:
         out["reuse_forward_mode"] = reuse
     if not args.no_lbfgs and not use_graph:
@@ -807,6 +887,7 @@ def main():
         out["bf16_mode"]["traffic"] = _pmc_step_traffic("step_bf16")
         out["k64_mode"] = _variant(args, dev, pg, rank, world, barrier, x, uv, Kc=64)
         out["admm10_loop"] = admm10_loop(args, dev, pg, rank, world, barrier, gen)
+        out["config5_mode"] = config5_mode(args, dev, pg, rank, world, barrier)
     if rank == 0 and not args.no_roofline:
         out["gemm_family_roofline"] = gemm_family_roofline(tr, dev)
         out["stream_kernel_roofline"] = stream_kernel_roofline(tr, dev)

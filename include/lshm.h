@@ -160,14 +160,6 @@ int lshm_dense1d_fwd(const float* cat1, const float* const* wb, float* z1, float
 int lshm_dense1d_bwd(const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
                      const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
                      lshm_stream_t stream);
-/* The same for the 2-D autoencoder of kharmonic_lofar.py (AutoEncoderCNN2(latent_dim=L, rica=True), L = 224 upstream
- * (src/kharmonic_lofar.py:37, src/lofar_models.py:36-47,66-77); 224 and 256 are built, LSHM_ERR_UNSUPPORTED otherwise): every
- * 16 above reads L (z1, mu (B,L); cat3 (B,L+16) with its columns L..L+15 = elu(fcuv3(uvh)) in place). */
-int lshm_dense2d_fwd(int L, const float* cat1, const float* const* wb, float* z1, float* mu, long ldmu, float* cat3, float* d0, int B,
-                     lshm_stream_t stream);
-int lshm_dense2d_bwd(int L, const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
-                     const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
-                     lshm_stream_t stream);
 /* The whole mid + deep section of AutoEncoder1DCNN(latent_dim=16, rica=True)'s forward as ONE launch (src/lofar_models.py:
  * 119-135,137-140 and the forward :158-183): conv2 -> conv3 -> conv4 -> conv5 -> fc1 -> fc2in -> fc2out -> fc3 -> tconv0 -> tconv1 ->
  * tconv2 -> tconv3, one workgroup per patch, activations resident in LDS.  x1 (B,12,1024) = conv1's output; w[12] / bias[12] in
@@ -182,7 +174,7 @@ int lshm_chain1d_full_fwd(const float* x1, const float* const* w, const float* c
  * (hipExtLaunchKernel: the kernel's dispatch and completion timestamps, no marker packets), so the timeline of the
  * SHIPPED schedule can be read where rocprofv3 makes the host the bottleneck.  lshm_trace_end returns the number of
  * launches recorded; after the caller has synchronised the device, lshm_trace_read returns launch `index`: demangled
- * kernel name, start (us after the first recorded launch), duration (us), stream (numbered in order of first use) and
+ * kernel name, start (us after the start of the first recorded launch; a launch on another stream may precede it), duration (us), stream (numbered in order of first use) and
  * grid size in threads.  lshm_trace_free releases the events.  Cost: ~25 launches per iteration that signal a dependency
  * through their stop event record a marker instead. */
 int lshm_trace_begin(int capacity);

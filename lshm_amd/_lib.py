@@ -75,9 +75,6 @@ _SIGNATURES = {
     "lshm_dense1d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p]),
     "lshm_dense1d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
-    "lshm_dense2d_fwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p]),
-    "lshm_dense2d_bwd": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lshm_deep2d_packed_floats": (c_size_t, []),
     "lshm_deep2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lshm_deep2d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p]),

@@ -364,7 +364,7 @@ int lshm_deep2d_bwd(const float* g_t2, const float* const* w, const float* const
 static int dense_mid_fwd(int L, const float* cat1, const float* const* wb, float* z1, float* mu, long ldmu, float* cat3, float* d0,
                          int B, lshm_stream_t s) {
   REQUIRE(cat1 && wb && z1 && mu && cat3 && d0 && B > 0 && L > 0 && ldmu >= L, "dense1d_fwd: bad argument");
-  if (!dense1d_built(L)) { set_last_error("dense_fwd: latent width must be 16, 224 or 256"); return LSHM_ERR_UNSUPPORTED; }
+  if (!dense1d_built(L)) { set_last_error("dense_fwd: latent width must be 16"); return LSHM_ERR_UNSUPPORTED; }
   const Dense1dFwdIO io{cat1, wb[0], wb[1], wb[2], wb[3], wb[4], wb[5], wb[6], wb[7], z1, mu, cat3, d0};
   return dense1d_fwd(io, nullptr, ldmu, B, ST(s), L);
 }
@@ -373,7 +373,7 @@ static int dense_mid_bwd(int L, const float* dd0, const float* cat3, const float
                          float* dcat1, int B, lshm_stream_t s) {
   REQUIRE(dd0 && cat3 && mu && gmu && z1 && cat1 && w && dcat3 && dzmu && dz1 && dcat1 && B > 0 && ldmu >= L && ldgmu >= L,
           "dense1d_bwd: bad argument");
-  if (!dense1d_built(L)) { set_last_error("dense_bwd: latent width must be 16, 224 or 256"); return LSHM_ERR_UNSUPPORTED; }
+  if (!dense1d_built(L)) { set_last_error("dense_bwd: latent width must be 16"); return LSHM_ERR_UNSUPPORTED; }
   const Dense1dBwdIO io{dd0, cat3, mu, gmu, z1, cat1, w[0], w[1], w[2], w[3], dcat3, dzmu, dz1, dcat1};
   return dense1d_bwd(io, nullptr, ldmu, ldgmu, B, ST(s), L);
 }
@@ -385,15 +385,6 @@ int lshm_dense1d_bwd(const float* dd0, const float* cat3, const float* mu, long 
                      const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
                      lshm_stream_t s) {
   return dense_mid_bwd(16, dd0, cat3, mu, ldmu, gmu, ldgmu, z1, cat1, w, dcat3, dzmu, dz1, dcat1, B, s);
-}
-int lshm_dense2d_fwd(int L, const float* cat1, const float* const* wb, float* z1, float* mu, long ldmu, float* cat3, float* d0, int B,
-                     lshm_stream_t s) {
-  return dense_mid_fwd(L, cat1, wb, z1, mu, ldmu, cat3, d0, B, s);
-}
-int lshm_dense2d_bwd(int L, const float* dd0, const float* cat3, const float* mu, long ldmu, const float* gmu, long ldgmu, const float* z1,
-                     const float* cat1, const float* const* w, float* dcat3, float* dzmu, float* dz1, float* dcat1, int B,
-                     lshm_stream_t s) {
-  return dense_mid_bwd(L, dd0, cat3, mu, ldmu, gmu, ldgmu, z1, cat1, w, dcat3, dzmu, dz1, dcat1, B, s);
 }
 int lshm_elu_bwd(const float* gy, const float* y, float* dz, long n, lshm_stream_t s) {
   REQUIRE(gy && y && dz && n >= 0, "elu_bwd: bad argument");

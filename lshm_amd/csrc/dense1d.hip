@@ -256,212 +256,13 @@ __global__ __launch_bounds__(NTH) void dense1d_bwd_kernel(const Dense1dBwdArgs a
   }
 }
 
-// ----------------------------------------------------------------------------------------------
-// The same four layers at latent_dim L = 224 (the 2-D autoencoder of kharmonic_lofar.py: src/kharmonic_lofar.py:37,
-// src/lofar_models.py:36-47,66-77) or 256: fc1 784 -> L, fc2in / fc2out L -> L, fc3 L + 16 -> 768 -- ~2 MB of weights, five
-// launches of 6-21 us per forward and 75 us of launches + queue gaps on the backward's critical stream.  Same workgroup (16 rows, 16
-// wavefronts), other split: every layer has at least 16 column tiles, so a wavefront owns column tiles and runs the
-// whole K of each (no cross-wavefront sums except for the 16 harmonic columns of fc3's data gradient); what a launch
-// costs is a wavefront's chain of L2 fetches of its weight rows, so the loops keep 8 k-blocks of weights in flight.
-// ----------------------------------------------------------------------------------------------
-template <int AP, int UNR>
-__device__ __forceinline__ f32x4 gemm_kfast_deep(const float* __restrict__ As, const float* __restrict__ W, long ldw, int n0, int kblocks) {
-  const int lane = threadIdx.x & 63, lm = lane & 15, lk = lane >> 4;
-  const float* wrow = W + (long)(n0 + lm) * ldw + 4 * lk;
-  const float* arow = As + lm * AP + 4 * lk;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll UNR
-  for (int s = 0; s < kblocks; ++s) {
-    const f32x4 b = *reinterpret_cast<const f32x4*>(wrow + 16 * s);
-    const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * s);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], acc, 0, 0, 0);
-  }
-  return acc;
-}
-// C[16 x 16] = A[16 x K] (LDS rows, pitch AP) * W, W[k][n] n-fast (leading dimension ldw, global), columns n0.., k-steps
-// first, first + step, ... below ksteps
-template <int AP, int UNR>
-__device__ __forceinline__ f32x4 gemm_nfast_deep(const float* __restrict__ As, const float* __restrict__ W, long ldw, int n0, int ksteps,
-                                                 int first, int step) {
-  const int lane = threadIdx.x & 63, lm = lane & 15, lk = lane >> 4;
-  const float* wp = W + (long)lk * ldw + n0 + lm;
-  const float* ap = As + lm * AP + lk;
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll UNR
-  for (int s = first; s < ksteps; s += step) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], wp[(long)4 * s * ldw], acc, 0, 0, 0);
-  return acc;
-}
-
-template <int L>
-__global__ __launch_bounds__(NTH) void dense_wide_fwd_kernel(const Dense1dFwdArgs a) {
-  static_assert(L / 16 <= NWV && L % 16 == 0, "one column tile of the L-wide layers per wavefront");
-  constexpr int ZP = L + 4, CP = L + HD + 4;  // a quarter of the pitch is odd: conflict-free b128 row reads
-  __shared__ __attribute__((aligned(16))) float xs[16 * XP];
-  __shared__ __attribute__((aligned(16))) float z1s[16 * ZP], mus[16 * ZP], c3s[16 * CP];
-  const int pr = blockIdx.y, r0 = blockIdx.x * 16;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 15, lk = lane >> 4;
-  const int nrow = a.B - r0 < 16 ? a.B - r0 : 16;
-  const float* x = a.cat1[pr] + (long)r0 * NIN;
-  for (int i = t; i < 16 * (NIN / 4); i += NTH) {
-    const int r = i / (NIN / 4), c4 = i - r * (NIN / 4);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < nrow) v = *reinterpret_cast<const f32x4*>(x + (long)r * NIN + 4 * c4);
-    *reinterpret_cast<f32x4*>(xs + r * XP + 4 * c4) = v;
-  }
-  for (int i = t; i < 16 * HD; i += NTH) {
-    const int r = i / HD, c = i - r * HD;
-    c3s[r * CP + L + c] = r < nrow ? a.cat3[pr][(long)(r0 + r) * (L + HD) + L + c] : 0.f;
-  }
-  __syncthreads();
-  const int n0 = 16 * wave;
-  const bool mine = n0 < L;  // (L = 224: wavefronts 14 and 15 only join the barriers and fc3)
-  if (mine) {  // fc1
-    const f32x4 v = gemm_kfast_deep<XP, 8>(xs, a.fc1w[pr], NIN, n0, NIN / 16);
-    const float bv = a.fc1b[pr][n0 + lm];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float o = elu(v[r] + bv);
-      z1s[(4 * lk + r) * ZP + n0 + lm] = o;
-      if (4 * lk + r < nrow) a.z1[pr][(long)(r0 + 4 * lk + r) * L + n0 + lm] = o;
-    }
-  }
-  __syncthreads();
-  if (mine) {  // fc2in: the latent code
-    const f32x4 v = gemm_kfast_deep<ZP, 8>(z1s, a.fc2inw[pr], L, n0, L / 16);
-    const float bv = a.fc2inb[pr][n0 + lm];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float o = elu(v[r] + bv);
-      mus[(4 * lk + r) * ZP + n0 + lm] = o;
-      if (4 * lk + r < nrow) a.mu[pr][(long)(r0 + 4 * lk + r) * a.ldmu + n0 + lm] = o;
-    }
-  }
-  __syncthreads();
-  if (mine) {  // fc2out
-    const f32x4 v = gemm_kfast_deep<ZP, 8>(mus, a.fc2outw[pr], L, n0, L / 16);
-    const float bv = a.fc2outb[pr][n0 + lm];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float o = elu(v[r] + bv);
-      c3s[(4 * lk + r) * CP + n0 + lm] = o;
-      if (4 * lk + r < nrow) a.cat3[pr][(long)(r0 + 4 * lk + r) * (L + HD) + n0 + lm] = o;
-    }
-  }
-  __syncthreads();
-  // fc3: 48 column tiles, 3 per wavefront, K = L + 16
-  for (int nt = wave; nt < 768 / 16; nt += NWV) {
-    const f32x4 o = gemm_kfast_deep<CP, 8>(c3s, a.fc3w[pr], L + HD, 16 * nt, (L + HD) / 16);
-    const float bv = a.fc3b[pr][16 * nt + lm];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (4 * lk + r < nrow) a.d0[pr][(long)(r0 + 4 * lk + r) * 768 + 16 * nt + lm] = o[r] + bv;
-  }
-}
-
-template <int L>
-__global__ __launch_bounds__(NTH) void dense_wide_bwd_kernel(const Dense1dBwdArgs a) {
-  static_assert(L / 16 <= NWV && L % 16 == 0, "one column tile of the L-wide layers per wavefront");
-  constexpr int ZP = L + 4;
-  __shared__ __attribute__((aligned(16))) float ds[16 * DP];
-  __shared__ __attribute__((aligned(16))) float red[NWV][64 * 4];
-  __shared__ __attribute__((aligned(16))) float g3s[16 * ZP], gms[16 * ZP], g1s[16 * ZP];
-  const int pr = blockIdx.y, r0 = blockIdx.x * 16;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 15, lk = lane >> 4;
-  const int nrow = a.B - r0 < 16 ? a.B - r0 : 16;
-  const float* d = a.dd0[pr] + (long)r0 * 768;
-  for (int i = t; i < 16 * (768 / 4); i += NTH) {
-    const int r = i / (768 / 4), c4 = i - r * (768 / 4);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (r < nrow) v = *reinterpret_cast<const f32x4*>(d + (long)r * 768 + 4 * c4);
-    *reinterpret_cast<f32x4*>(ds + r * DP + 4 * c4) = v;
-  }
-  __syncthreads();
-  const int n0 = 16 * wave;
-  const bool mine = n0 < L;
-  {  // the 16 harmonic columns of dcat3: K shared by the wavefronts, added in wavefront order below
-    const f32x4 u = gemm_nfast_deep<DP, 4>(ds, a.fc3w[pr], L + HD, L, 768 / 4, wave, NWV);
-    *reinterpret_cast<f32x4*>(&red[wave][4 * lane]) = u;
-  }
-  if (mine) {  // dcat3 = (dd0 fc3w) * ELU'(cat3): the L latent columns, one tile per wavefront, K = 768
-    const f32x4 v = gemm_nfast_deep<DP, 8>(ds, a.fc3w[pr], L + HD, n0, 768 / 4, 0, 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * lk + r;
-      float o = 0.f;
-      if (row < nrow) {
-        o = v[r] * elu_grad_from_out(a.cat3[pr][(long)(r0 + row) * (L + HD) + n0 + lm]);
-        a.dcat3[pr][(long)(r0 + row) * (L + HD) + n0 + lm] = o;
-      }
-      g3s[row * ZP + n0 + lm] = o;
-    }
-  }
-  __syncthreads();
-  if (wave == NWV - 1) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(&red[0][4 * lane]);
-#pragma unroll
-    for (int w = 1; w < NWV; ++w) v += *reinterpret_cast<const f32x4*>(&red[w][4 * lane]);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * lk + r;
-      if (row < nrow) {
-        const long g = (long)(r0 + row) * (L + HD) + L + lm;
-        a.dcat3[pr][g] = v[r] * elu_grad_from_out(a.cat3[pr][g]);
-      }
-    }
-  }
-  if (mine) {  // dzmu = (dcat3[:, :L] fc2outw + gMu) * ELU'(mu)
-    const f32x4 m = gemm_nfast_deep<ZP, 8>(g3s, a.fc2outw[pr], L, n0, L / 4, 0, 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * lk + r;
-      float o = 0.f;
-      if (row < nrow) {
-        o = (m[r] + a.gmu[pr][(long)(r0 + row) * a.ldgmu + n0 + lm]) * elu_grad_from_out(a.mu[pr][(long)(r0 + row) * a.ldmu + n0 + lm]);
-        a.dzmu[pr][(long)(r0 + row) * L + n0 + lm] = o;
-      }
-      gms[row * ZP + n0 + lm] = o;
-    }
-  }
-  __syncthreads();
-  if (mine) {  // dz1 = (dzmu fc2inw) * ELU'(z1)
-    const f32x4 m = gemm_nfast_deep<ZP, 8>(gms, a.fc2inw[pr], L, n0, L / 4, 0, 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * lk + r;
-      float o = 0.f;
-      if (row < nrow) {
-        o = m[r] * elu_grad_from_out(a.z1[pr][(long)(r0 + row) * L + n0 + lm]);
-        a.dz1[pr][(long)(r0 + row) * L + n0 + lm] = o;
-      }
-      g1s[row * ZP + n0 + lm] = o;
-    }
-  }
-  __syncthreads();
-  // dcat1 = (dz1 fc1w) * ELU'(cat1): 49 column tiles over the wavefronts, K = L
-  for (int nt = wave; nt < NIN / 16; nt += NWV) {
-    const f32x4 m = gemm_nfast_deep<ZP, 8>(g1s, a.fc1w[pr], NIN, 16 * nt, L / 4, 0, 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = 4 * lk + r;
-      if (row < nrow) {
-        const long g = (long)(r0 + row) * NIN + 16 * nt + lm;
-        a.dcat1[pr][g] = m[r] * elu_grad_from_out(a.cat1[pr][g]);
-      }
-    }
-  }
-}
-
-// what the step engine uses: the 16-wide form (netT / netF) by default; the wide form only with LSHM_DENSE2D=1 -- it is
-// correct (tests) but SLOWER than the five launches it replaces: a workgroup's 16 rows run all ~2 MB of weights through the
-// matrix pipe of ONE CU (8448 instructions x 32 cycles / 4 SIMDs = 28 us at best; measured 50 us forward, 81 us
-// backward, +0.03 ms per iteration), where the separate split-K launches spread each layer over the machine
+// (A 224 / 256-wide form of the same kernels for the 2-D autoencoder existed in round 3: correct, but a workgroup's 16 rows ran
+// ~2 MB of weights through ONE CU's matrix pipe -- 50 / 81 us against ~45 / ~75 for the five launches -- and was removed; those
+// layers now run inside lshm_deep2d_fwd / _bwd, a patch per workgroup.)
 bool dense1d_supported(int L, int hd, int rica) {
-  // (the 224 / 256-wide forms are reachable through lshm_dense2d_* only: measured slower in the step, and the 2-D
-  //  autoencoder's dense layers now run inside lshm_deep2d_*)
   return !sched(LSHM_SCHED_NO_DENSE1D) && rica && hd == HD && L == LT;
 }
-bool dense1d_built(int L) { return L == LT || L == 224 || L == 256; }
+bool dense1d_built(int L) { return L == LT; }
 
 int dense1d_fwd(const Dense1dFwdIO& p, const Dense1dFwdIO* p1, long ldmu, int B, hipStream_t st, int L) {
   Dense1dFwdArgs a;
@@ -480,16 +281,10 @@ int dense1d_fwd(const Dense1dFwdIO& p, const Dense1dFwdIO* p1, long ldmu, int B,
   }
   a.ldmu = ldmu;
   a.B = B;
-  if (L == 224 || L == 256) {
-    const void* k = L == 224 ? reinterpret_cast<const void*>(dense_wide_fwd_kernel<224>) : reinterpret_cast<const void*>(dense_wide_fwd_kernel<256>);
-    int rc = kernel_budget_ok(k, NTH, 0, "dense_wide_fwd_kernel");
-    if (rc) return rc;
-    if (L == 224) hipLaunchKernelGGL((dense_wide_fwd_kernel<224>), dim3((B + 15) / 16, p1 ? 2 : 1), dim3(NTH), 0, st, a);
-    else hipLaunchKernelGGL((dense_wide_fwd_kernel<256>), dim3((B + 15) / 16, p1 ? 2 : 1), dim3(NTH), 0, st, a);
-  } else if (L == LT) {
+  if (L == LT) {
     hipLaunchKernelGGL(dense1d_fwd_kernel, dim3((B + 15) / 16, p1 ? 2 : 1), dim3(NTH), 0, st, a);
   } else {
-    set_last_error("dense1d_fwd: latent width must be 16, 224 or 256");
+    set_last_error("dense1d_fwd: latent width must be 16");
     return LSHM_ERR_UNSUPPORTED;
   }
   return check_launch("dense1d_fwd");
@@ -510,16 +305,10 @@ int dense1d_bwd(const Dense1dBwdIO& p, const Dense1dBwdIO* p1, long ldmu, long l
   }
   a.ldmu = ldmu; a.ldgmu = ldgmu;
   a.B = B;
-  if (L == 224 || L == 256) {
-    const void* k = L == 224 ? reinterpret_cast<const void*>(dense_wide_bwd_kernel<224>) : reinterpret_cast<const void*>(dense_wide_bwd_kernel<256>);
-    int rc = kernel_budget_ok(k, NTH, 0, "dense_wide_bwd_kernel");
-    if (rc) return rc;
-    if (L == 224) hipLaunchKernelGGL((dense_wide_bwd_kernel<224>), dim3((B + 15) / 16, p1 ? 2 : 1), dim3(NTH), 0, st, a);
-    else hipLaunchKernelGGL((dense_wide_bwd_kernel<256>), dim3((B + 15) / 16, p1 ? 2 : 1), dim3(NTH), 0, st, a);
-  } else if (L == LT) {
+  if (L == LT) {
     hipLaunchKernelGGL(dense1d_bwd_kernel, dim3((B + 15) / 16, p1 ? 2 : 1), dim3(NTH), 0, st, a);
   } else {
-    set_last_error("dense1d_bwd: latent width must be 16, 224 or 256");
+    set_last_error("dense1d_bwd: latent width must be 16");
     return LSHM_ERR_UNSUPPORTED;
   }
   return check_launch("dense1d_bwd");

@@ -249,3 +249,29 @@ def test_captured_closure_with_communicator_sends_no_early_bucket():
     assert torch.equal(tr.grads, eager)
     _lib.check(lib.lshm_engine_set_comm(tr._h, None))
     comm.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_line_at_world_two_carries_what_the_collective_measured():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank; here both ranks on the one GPU
+    over gloo): the line's `dp` object is measured THROUGH the process group -- ranks seen by an all-reduce of 1, the gathered
+    devices, the data-parallel path taken, one all-reduce of the gradient arena -- not read from the environment."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LSHM_SHARE_GPU0="1", LSHM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+           "--no-cpu-baseline", "--no-roofline", "--no-reuse-mode", "--no-lbfgs", "--no-rica", "--no-extra-modes"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=root, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 32
+    d = j["dp"]
+    assert d["ranks_seen"] == 2 and len(d["devices"]) == 2 and sorted(x["rank"] for x in d["devices"]) == [0, 1]
+    assert all(x["shared_with_other_ranks"] for x in d["devices"])
+    assert d["path"] in ("torch", "engine") and d["backend"] == "gloo"
+    assert d["allreduce_us"] > 0 and d["allreduce_bytes"] == 4 * 1725716

@@ -279,11 +279,10 @@ def test_three_layer_chain_matches_the_three_launches(mode):
 
 
 @pytest.mark.parametrize("nb", [256, 37])
-@pytest.mark.parametrize("Ld", [16, 224, 256], ids=["latent16", "latent224", "latent256"])
+@pytest.mark.parametrize("Ld", [16], ids=["latent16"])
 def test_dense_middle_of_the_1d_autoencoder_as_one_launch(nb, Ld):
     """lshm_dense1d_fwd / lshm_dense1d_bwd (fc1 -> fc2in -> fc2out -> fc3 of AutoEncoder1DCNN(latent_dim=16, rica=True) and the
-    data gradients back through them, src/lofar_models.py:127-135,165-176) and lshm_dense2d_fwd / _bwd (the same layers of
-    AutoEncoderCNN2(latent_dim=224 | 256, rica=True), :36-47,66-77) against fp64, every output, at the full batch and at a
+    data gradients back through them, src/lofar_models.py:127-135,165-176) against fp64, every output, at the full batch and at a
     ragged one (37 rows: the last workgroup has 5)."""
     import ctypes as C
     from lshm_amd import _lib as L
@@ -297,8 +296,7 @@ def test_dense_middle_of_the_1d_autoencoder_as_one_launch(nb, Ld):
     uvh = TF.elu(R(nb, 16))
     D = 288
     import functools
-    fwd, bwd = (lib.lshm_dense1d_fwd, lib.lshm_dense1d_bwd) if Ld == 16 else (functools.partial(lib.lshm_dense2d_fwd, Ld),
-                                                                             functools.partial(lib.lshm_dense2d_bwd, Ld))
+    fwd, bwd = lib.lshm_dense1d_fwd, lib.lshm_dense1d_bwd
     Mu = torch.zeros(nb, D)
     cat3 = torch.zeros(nb, Ld + 16)
     cat3[:, Ld:] = uvh
