@@ -178,6 +178,9 @@ int lshm_chain1d_full_fwd(const float* x1, const float* const* w, const float* c
  * grid size in threads.  lshm_trace_free releases the events.  Cost: ~25 launches per iteration that signal a dependency
  * through their stop event record a marker instead. */
 int lshm_trace_begin(int capacity);
+/* with_start == 0: stop events only -- no start timestamp packet in front of the kernels, so the queues run as they do untraced;
+ * lshm_trace_read then returns the COMPLETION time in `start_us` and -1 as the duration. */
+int lshm_trace_begin_ex(int capacity, int with_start);
 int lshm_trace_end(void);
 int lshm_trace_read(int index, char* name, int name_cap, float* start_us, float* dur_us, int* stream_index, unsigned* grid_threads);
 int lshm_trace_free(void);
@@ -454,7 +457,8 @@ typedef struct lshm_step_config {
 #define LSHM_SCHED_WGRAD_INLINE (1u << 17)    /* weight gradients on the data-gradient stream (no second stream) */
 #define LSHM_SCHED_FORK (1u << 18)            /* netT and netF on two streams instead of paired launches */
 #define LSHM_SCHED_PHASE_EVENTS (1u << 19)    /* diagnostic: record the phase-boundary events lshm_engine_phase_times reads */
-#define LSHM_SCHED_NO_KHM_MFMA (1u << 20)     /* K-harmonic pass for 16 < K <= 64 on the row-split kernel instead of the matrix cores */
+#define LSHM_SCHED_NO_KHM_MFMA (1u << 20)
+#define LSHM_SCHED_NO_EARLY_LATENT (1u << 21) /* latent-space terms at the head of the backward instead of beside the paired forwards */     /* K-harmonic pass for 16 < K <= 64 on the row-split kernel instead of the matrix cores */
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);
 void lshm_engine_destroy(lshm_engine* e);

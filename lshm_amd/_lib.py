@@ -43,7 +43,7 @@ SCHEDULE_BITS = {"no_deep2d": 1 << 0, "no_deep2d_bwd": 1 << 1, "no_wgrad_batch":
                  "no_resid_conv0": 1 << 8, "no_recon_from_a": 1 << 9, "no_one_pass_bwd": 1 << 10, "no_bwd_lds": 1 << 11,
                  "no_bwd_lds_8_4": 1 << 12, "no_bwd_lds2d": 1 << 13, "no_bwd_fused2d": 1 << 14, "no_wgrad_mid": 1 << 15,
                  "no_stop_events": 1 << 16, "wgrad_inline": 1 << 17, "fork": 1 << 18, "phase_events": 1 << 19,
-                 "no_khm_mfma": 1 << 20}
+                 "no_khm_mfma": 1 << 20, "no_early_latent": 1 << 21}
 SCHED_NO_DEEP2D, SCHED_NO_DEEP2D_BWD = SCHEDULE_BITS["no_deep2d"], SCHEDULE_BITS["no_deep2d_bwd"]
 STEP_RECON_READY = 1
 NEXT_CONCURRENT_FORWARD = 1
@@ -79,6 +79,7 @@ _SIGNATURES = {
     "lshm_deep2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "lshm_deep2d_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lshm_trace_begin": (c_int, [c_int]),
+    "lshm_trace_begin_ex": (c_int, [c_int, c_int]),
     "lshm_trace_end": (c_int, []),
     "lshm_trace_read": (c_int, [c_int, C.c_char_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lshm_trace_free": (c_int, []),

@@ -32,6 +32,7 @@ struct Trace {
   std::vector<TraceRec> recs;
   std::vector<LaunchTraceSlot> pool;
   size_t used = 0;
+  bool with_start = true;
 };
 thread_local Trace* g_trace = nullptr;
 }  // namespace
@@ -235,13 +236,16 @@ int lshm_conv1d_chain3(int up, const float* x, const float* const* w, const floa
   }
   return conv1d_chain(up != 0, st, x, nullptr, up ? 96L * 16 : 12L * 1024, pad, B, ST(s));
 }
-int lshm_trace_begin(int capacity) {
+int lshm_trace_begin(int capacity) { return lshm_trace_begin_ex(capacity, 1); }
+int lshm_trace_begin_ex(int capacity, int with_start) {
   if (capacity < 1 || capacity > 65536) { set_last_error("trace_begin: capacity must be 1..65536"); return LSHM_ERR_ARG; }
   if (g_trace) { set_last_error("trace_begin: this thread is already recording"); return LSHM_ERR_ARG; }
   Trace* t = new Trace();
+  t->with_start = with_start != 0;
   t->pool.resize(capacity);
   for (auto& sl : t->pool) {
-    if (hipEventCreate(&sl.start) != hipSuccess || hipEventCreate(&sl.stop) != hipSuccess) {
+    sl.start = nullptr;
+    if ((t->with_start && hipEventCreate(&sl.start) != hipSuccess) || hipEventCreate(&sl.stop) != hipSuccess) {
       (void)hipGetLastError();
       set_last_error("trace_begin: cannot create events");
       delete t;  // (events created so far are leaked: a diagnostic path on a device that is out of events)
@@ -263,10 +267,19 @@ int lshm_trace_read(int index, char* name, int name_cap, float* start_us, float*
   if (index < 0 || index >= (int)t->recs.size()) { set_last_error("trace_read: index past the end"); return LSHM_ERR_ARG; }
   const TraceRec& r = t->recs[index];
   float a = 0.f, d = 0.f;
-  if (hipEventElapsedTime(&a, t->recs[0].start, r.start) != hipSuccess || hipEventElapsedTime(&d, r.start, r.stop) != hipSuccess) {
-    (void)hipGetLastError();
-    set_last_error("trace_read: an event has not completed (synchronise the device first)");
-    return LSHM_ERR_ARG;
+  if (t->with_start) {
+    if (hipEventElapsedTime(&a, t->recs[0].start, r.start) != hipSuccess || hipEventElapsedTime(&d, r.start, r.stop) != hipSuccess) {
+      (void)hipGetLastError();
+      set_last_error("trace_read: an event has not completed (synchronise the device first)");
+      return LSHM_ERR_ARG;
+    }
+  } else {  // completion times only: `start` = completion time after the first recorded launch's, duration unknown (-1)
+    if (hipEventElapsedTime(&a, t->recs[0].stop, r.stop) != hipSuccess) {
+      (void)hipGetLastError();
+      set_last_error("trace_read: an event has not completed (synchronise the device first)");
+      return LSHM_ERR_ARG;
+    }
+    d = -1e-3f;
   }
   if (start_us) *start_us = a * 1000.f;
   if (dur_us) *dur_us = d * 1000.f;
@@ -295,7 +308,7 @@ int lshm_trace_free(void) {
   Trace* t = g_trace;
   if (!t) return LSHM_OK;
   launch_trace_on = false;
-  for (auto& sl : t->pool) { (void)hipEventDestroy(sl.start); (void)hipEventDestroy(sl.stop); }
+  for (auto& sl : t->pool) { if (sl.start) (void)hipEventDestroy(sl.start); (void)hipEventDestroy(sl.stop); }
   delete t;
   g_trace = nullptr;
   return LSHM_OK;
@@ -332,7 +345,7 @@ int lshm_deep2d_fwd(const float* x2, const float* const* w, const float* const* 
   REQUIRE(x2 && w && bias && out && packed && B > 0 && ldmu >= 224, "deep2d_fwd: bad argument");
   for (int i = 0; i < 11; ++i) REQUIRE(w[i] && bias[i] && out[i], "deep2d_fwd: null layer pointer");
   const Deep2dWeights dw{nullptr, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10]};
-  int rc = deep2d_pack(dw, packed, 0, ST(s));
+  int rc = deep2d_pack(dw, packed, 0, (variant & 4) ? 1 : 0, ST(s));
   if (rc) return rc;
   Deep2dIO io;
   io.x2 = x2;
@@ -350,7 +363,7 @@ int lshm_deep2d_bwd(const float* g_t2, const float* const* w, const float* const
   for (int i = 0; i < 10; ++i) REQUIRE(saved[i], "deep2d_bwd: null saved-activation pointer");
   for (int i = 0; i < 11; ++i) REQUIRE(out[i], "deep2d_bwd: null output pointer");
   const Deep2dWeights dw{w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], w[9], w[10], w[11]};
-  int rc = deep2d_pack(dw, packed, 1, ST(s));
+  int rc = deep2d_pack(dw, packed, 1, (variant & 4) ? 1 : 0, ST(s));
   if (rc) return rc;
   Deep2dBwdIO io;
   io.g_t2 = g_t2;

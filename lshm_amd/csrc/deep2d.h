@@ -45,8 +45,9 @@ struct Deep2dBwdIO {
 };
 bool deep2d_supported(int L, int hd, int rica, const int* enc_ch, int H2);
 size_t deep2d_packed_floats();  // of either direction's copy
-int deep2d_pack(const Deep2dWeights& w, float* packed, int backward, hipStream_t st);
-// variant 0: one patch per 1024-thread workgroup, 1: two patches, 2 (forward only): one patch per 512-thread workgroup
+int deep2d_pack(const Deep2dWeights& w, float* packed, int backward, int bf16_weights, hipStream_t st);
+// variant 0: one patch per 1024-thread workgroup, 1: two patches, 2 (forward only): one patch per 512-thread workgroup;
+// + 4: `packed` holds bf16 weights (deep2d_pack(.., bf16_weights = 1)): half the L2 stream, fp32 products and accumulation
 int deep2d_fwd(const Deep2dIO& io, const float* packed, int B, int variant, hipStream_t st);
 int deep2d_bwd(const Deep2dBwdIO& io, const float* packed, int B, int variant, hipStream_t st);
 

@@ -43,6 +43,8 @@
 // fc2out's ELU'.  Every stage's output (the dz the weight gradients read) goes to HBM once, as in the forward.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "deep2d.h"
 
@@ -142,7 +144,7 @@ __device__ __forceinline__ const float* pack_source(const PackSrc& w, long off) 
   }
 }
 
-template <bool BWD>
+template <bool BWD, bool BFW>
 __global__ __launch_bounds__(256) void deep2d_pack_kernel(const PackSrc w, float* __restrict__ packed) {
   const long i4 = (long)blockIdx.x * 256 + threadIdx.x;  // one float4 of the packed image per thread
   if (i4 * 4 >= Lay<BWD>::P_TOTAL) return;
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(256) void deep2d_pack_kernel(const PackSrc w, float
     const float* s = pack_source<BWD>(w, i4 * 4 + e);
     v[e] = s ? *s : 0.f;
   }
-  *reinterpret_cast<f32x4*>(packed + i4 * 4) = v;
+  if (BFW) reinterpret_cast<bf16x4*>(packed)[i4] = __builtin_convertvector(v, bf16x4);  // round to nearest even (v_cvt_pk_bf16_f32)
+  else *reinterpret_cast<f32x4*>(packed + i4 * 4) = v;
 }
 
 struct Deep2dArgs {
@@ -186,23 +189,27 @@ constexpr int T0_CP = 52, T0_RP = 8;     // 4 + 2 rows of 8 (+4): k-lanes land o
 constexpr int T1_CP = 100, T1_RP = 10;
 constexpr int kPF = 8;                   // float4 registers of the cross-barrier weight prefetch
 
-template <int NB>
-__device__ __forceinline__ void load_batch(f32x4 (&q)[NB], const f32x4* __restrict__ p, int s0, int nsteps) {
+// A weight slot is the four values a lane consumes in one step: a float4, or (bf16 operand precision, BASELINE configs[2]) four
+// bf16 in 8 bytes -- half the L2 stream; widened to fp32 registers on arrival (a shift), fp32 products and accumulation.
+__device__ __forceinline__ f32x4 wload(const f32x4* __restrict__ p) { return *p; }
+__device__ __forceinline__ f32x4 wload(const bf16x4* __restrict__ p) { return __builtin_convertvector(*p, f32x4); }
+template <int NB, class W4>
+__device__ __forceinline__ void load_batch(f32x4 (&q)[NB], const W4* __restrict__ p, int s0, int nsteps) {
 #pragma unroll
-  for (int k = 0; k < NB; ++k) q[k] = s0 + k < nsteps ? p[(long)(s0 + k) * 64] : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < NB; ++k) q[k] = s0 + k < nsteps ? wload(p + (long)(s0 + k) * 64) : (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 // the first NB steps of a wavefront's first unit of a stage, requested ahead of the barrier in front of the stage
-template <int NB>
-__device__ __forceinline__ void prefetch(f32x4 (&pf)[kPF], const f32x4* __restrict__ p, bool on) {
+template <int NB, class W4>
+__device__ __forceinline__ void prefetch(f32x4 (&pf)[kPF], const W4* __restrict__ p, bool on) {
   static_assert(NB <= kPF, "prefetch registers");
   if (on) {
 #pragma unroll
-    for (int k = 0; k < NB; ++k) pf[k] = p[(long)k * 64];
+    for (int k = 0; k < NB; ++k) pf[k] = wload(p + (long)k * 64);
   }
 }
 // NS steps of one unit: body(step, float4); `first`: the steps 0..NB-1 are already in pf
-template <int NS, int NB, class Body>
-__device__ __forceinline__ void stream_unit(const f32x4* __restrict__ wq, const f32x4 (&pf)[kPF], bool first, Body body) {
+template <int NS, int NB, class W4, class Body>
+__device__ __forceinline__ void stream_unit(const W4* __restrict__ wq, const f32x4 (&pf)[kPF], bool first, Body body) {
   static_assert(NS % NB == 0, "whole batches");
   f32x4 cur[NB], nxt[NB];
   if (first) {
@@ -222,15 +229,15 @@ __device__ __forceinline__ void stream_unit(const f32x4* __restrict__ wq, const 
 
 // One dense layer (one row per patch): out[n] = bias[n] + sum_k x[k] W[n][k]; unit = (64 columns, quarter of K).
 // The reduction + epilogue is the caller's (it differs per layer).
-template <int G, int NW, int N, int NG, int SPK, int NB>
+template <int G, int NW, int N, int NG, int SPK, int NB, class W4>
 __device__ __forceinline__ void dense_units(const float* __restrict__ xv /* RV + x offset, patch stride RV_F */,
-                                            const f32x4* __restrict__ wp4, float* __restrict__ slab, const float* __restrict__ bias,
+                                            const W4* __restrict__ wp4, float* __restrict__ slab, const float* __restrict__ bias,
                                             const f32x4 (&pf)[kPF]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int NGP = NG * 64;
   for (int u = wave; u < NG * 4; u += NW) {
     const int kg = u & 3, ng = u >> 2, n = 64 * ng + lane;
-    const f32x4* wq = wp4 + (long)((ng * 4 + kg) * SPK) * 64 + lane;
+    const W4* wq = wp4 + (long)((ng * 4 + kg) * SPK) * 64 + lane;
     float acc[G];
     const float bv = (bias && kg == 0 && n < N) ? bias[n] : 0.f;
 #pragma unroll
@@ -253,14 +260,15 @@ __device__ __forceinline__ float dense_sum(const float* __restrict__ slab, int g
   const float* sp = slab + g * 4 * NGP + n;
   return (sp[0] + sp[NGP]) + (sp[2 * NGP] + sp[3 * NGP]);
 }
-template <int SPK>
-__device__ __forceinline__ const f32x4* dense_wq(const f32x4* wp4, int u, int lane) {
+template <int SPK, class W4>
+__device__ __forceinline__ const W4* dense_wq(const W4* wp4, int u, int lane) {
   return wp4 + (long)(((u >> 2) * 4 + (u & 3)) * SPK) * 64 + lane;
 }
 
-template <int G, int THREADS, bool BWD>
+template <int G, int THREADS, bool BWD, bool BFW>
 __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   using Y = Lay<BWD>;
+  using W4 = typename std::conditional<BFW, bf16x4, f32x4>::type;
   constexpr int NW = THREADS / 64;
   static_assert(G == 1 || G == 2, "the reductions tell the patches apart with one compare");
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int lm = lane & 15, lk = lane >> 4;
   const int b0 = blockIdx.x * G;
-  const f32x4* const wp4 = reinterpret_cast<const f32x4*>(a.wp);
+  const W4* const wp4 = reinterpret_cast<const W4*>(a.wp);
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   int nstamp = 0;
   auto stamp = [&]() {
@@ -761,29 +769,29 @@ bool deep2d_supported(int L, int hd, int rica, const int* enc_ch /* the output c
          device_lds_fits(sizeof(float) * 2 * (RA_F + RS_F + RX_F + RV_F));  // (two patches per workgroup: 158 KB)
 }
 
-int deep2d_pack(const Deep2dWeights& w, float* packed, int backward, hipStream_t st) {
+int deep2d_pack(const Deep2dWeights& w, float* packed, int backward, int bf16_weights, hipStream_t st) {
   if (!packed || (backward && !w.c2) || !w.c3 || !w.c4 || !w.c5 || !w.fc1 || !w.fc2in || !w.fc2out || !w.fc3 || !w.t0 || !w.t1 || !w.t2 || !w.t3) {
     set_last_error("deep2d_pack: null pointer");
     return LSHM_ERR_ARG;
   }
   if (reinterpret_cast<uintptr_t>(packed) & 15) { set_last_error("deep2d_pack: unaligned destination"); return LSHM_ERR_ARG; }
-  if (backward) {
-    // the data-gradient pipeline: every conv-shaped stage reads the tensor of the layer it differentiates as it stands
-    // (tconv2' = conv with tconv2.weight (48, 24, 4, 4) ... conv2' = transposed conv with conv2.weight (24, 12, 4, 4)), the
-    // dense stages read theirs transposed: fc3' | fc2out' | fc2in' | fc1'
-    const PackSrc s{w.t2, w.t1, w.t0, w.fc3, w.fc2out, w.fc2in, w.fc1, w.c5, w.c4, w.c3, w.c2};
-    hipLaunchKernelGGL(deep2d_pack_kernel<true>, dim3(cdiv(Lay<true>::P_TOTAL / 4, 256)), dim3(256), 0, st, s, packed);
-  } else {
-    const PackSrc s{w.c3, w.c4, w.c5, w.fc1, w.fc2in, w.fc2out, w.fc3, w.t0, w.t1, w.t2, w.t3};
-    hipLaunchKernelGGL(deep2d_pack_kernel<false>, dim3(cdiv(Lay<false>::P_TOTAL / 4, 256)), dim3(256), 0, st, s, packed);
-  }
+  // backward: the data-gradient pipeline -- every conv-shaped stage reads the tensor of the layer it differentiates as it stands
+  // (tconv2' = conv with tconv2.weight (48, 24, 4, 4) ... conv2' = transposed conv with conv2.weight (24, 12, 4, 4)), the
+  // dense stages read theirs transposed: fc3' | fc2out' | fc2in' | fc1'
+  const PackSrc sb{w.t2, w.t1, w.t0, w.fc3, w.fc2out, w.fc2in, w.fc1, w.c5, w.c4, w.c3, w.c2};
+  const PackSrc sf{w.c3, w.c4, w.c5, w.fc1, w.fc2in, w.fc2out, w.fc3, w.t0, w.t1, w.t2, w.t3};
+  const dim3 gb(cdiv(Lay<true>::P_TOTAL / 4, 256)), gf(cdiv(Lay<false>::P_TOTAL / 4, 256));
+  if (backward && bf16_weights) hipLaunchKernelGGL((deep2d_pack_kernel<true, true>), gb, dim3(256), 0, st, sb, packed);
+  else if (backward) hipLaunchKernelGGL((deep2d_pack_kernel<true, false>), gb, dim3(256), 0, st, sb, packed);
+  else if (bf16_weights) hipLaunchKernelGGL((deep2d_pack_kernel<false, true>), gf, dim3(256), 0, st, sf, packed);
+  else hipLaunchKernelGGL((deep2d_pack_kernel<false, false>), gf, dim3(256), 0, st, sf, packed);
   return check_launch("deep2d_pack");
 }
 
-template <int G, int THREADS, bool BWD>
+template <int G, int THREADS, bool BWD, bool BFW>
 static int launch_deep(const Deep2dArgs& a, hipStream_t st) {
   const size_t lds = sizeof(float) * (size_t)G * (RA_F + RS_F + RX_F + RV_F);
-  auto kern = deep2d_kernel<G, THREADS, BWD>;
+  auto kern = deep2d_kernel<G, THREADS, BWD, BFW>;
   int rc;
   if ((rc = kernel_budget_ok(reinterpret_cast<const void*>(kern), THREADS, lds, "deep2d"))) return rc;
   if ((rc = raise_dynamic_lds(reinterpret_cast<const void*>(kern), lds, "deep2d"))) return rc;
@@ -806,10 +814,12 @@ int deep2d_fwd(const Deep2dIO& io, const float* packed, int B, int variant, hipS
   a.t0 = io.t0; a.t1 = io.t1; a.t2 = io.t2; a.t3 = io.t3;
   a.B = B;
   a.stamps = io.stamps;
-  switch (variant) {
-    case 0: return launch_deep<1, 1024, false>(a, st);
-    case 1: return launch_deep<2, 1024, false>(a, st);
-    case 2: return launch_deep<1, 512, false>(a, st);
+  switch (variant) {  // bit 2 (+4): the packed weights are bf16
+    case 0: return launch_deep<1, 1024, false, false>(a, st);
+    case 1: return launch_deep<2, 1024, false, false>(a, st);
+    case 2: return launch_deep<1, 512, false, false>(a, st);
+    case 4: return launch_deep<1, 1024, false, true>(a, st);
+    case 5: return launch_deep<2, 1024, false, true>(a, st);
     default: set_last_error("deep2d_fwd: unknown variant"); return LSHM_ERR_ARG;
   }
 }
@@ -831,8 +841,10 @@ int deep2d_bwd(const Deep2dBwdIO& io, const float* packed, int B, int variant, h
   a.B = B;
   a.stamps = io.stamps;
   switch (variant) {
-    case 0: return launch_deep<1, 1024, true>(a, st);
-    case 1: return launch_deep<2, 1024, true>(a, st);
+    case 0: return launch_deep<1, 1024, true, false>(a, st);
+    case 1: return launch_deep<2, 1024, true, false>(a, st);
+    case 4: return launch_deep<1, 1024, true, true>(a, st);
+    case 5: return launch_deep<2, 1024, true, true>(a, st);
     default: set_last_error("deep2d_bwd: unknown variant"); return LSHM_ERR_ARG;
   }
 }

@@ -90,6 +90,7 @@ struct lshm_engine {
   bool full1d = false;  // conv2 .. tconv3 of the 1-D autoencoders' forward as one launch (chain1d_full.hip)
   size_t o_pack2d_bwd = 0;  // the backward's fragment-ordered weight copy
   unsigned wgrad_on_main = 0;  // which of the deep layers' weight gradients follow the data-gradient chain on ITS stream (ae_backward)
+  int deep_bf16 = 0;    // the deep chains stream bf16 copies of the weights (precision != LSHM_PRECISION_F32)
   int deep_variant = 0; // 0: one patch per workgroup (a forward alone), 1: two (two forwards side by side: each fills half of the CUs)
   size_t o_recon_part;  // per-block partial sums of the reconstruction pass (its own buffer: their seven sums may be made later, beside the backward)
   hipStream_t fstream = nullptr;  // the no-grad forward + shared reconstruction pass, beside the next closure forward
@@ -110,6 +111,7 @@ struct lshm_engine {
   hipEvent_t latent_event;  // set while the latent-space terms of the current forward are in flight
   bool sim_started = false;  // cluster_similarity of the current forward already launched (side stream)
   bool recon_ready;         // the workspace already holds the reconstruction terms of the next closure
+  bool latent_early = false;  // the latent-space terms of the next closure are already in flight (started beside the paired forwards)
   bool sum7_pending = false;  // ... as per-block partials: their seven sums are made on the latent-space stream of the next closure
   size_t o_latent_ws, latent_ws_floats;
   bool side_ok;
@@ -270,7 +272,7 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
       const AEPlan& a = A(0);
       const Deep2dWeights w{prm + a.cw[2], prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw,
                             prm + a.fc3w, prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
-      return deep2d_pack(w, ws + e->o_pack2d, 0, st);
+      return deep2d_pack(w, ws + e->o_pack2d, 0, e->deep_bf16, st);
     });
   }
   // 1-D autoencoders: conv2 .. tconv3 (twelve layers) as one launch (chain1d_full.hip)
@@ -313,7 +315,7 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
         io.a3 = ws + a.act[3]; io.a4 = ws + a.act[4]; io.cat1 = ws + a.cat1; io.z1 = ws + a.z1;
         io.mu = ws + e->o_Mu + a.mu_col; io.mu_ld = D; io.cat3 = ws + a.cat3; io.d0 = ws + a.d0;
         io.t0 = ws + a.dact[0]; io.t1 = ws + a.dact[1]; io.t2 = ws + a.dact[2]; io.t3 = ws + a.dact[3];
-        return deep2d_fwd(io, ws + e->o_pack2d, B, e->deep_variant, st);
+        return deep2d_fwd(io, ws + e->o_pack2d, B, e->deep_variant + 4 * e->deep_bf16, st);
       });
       break;
     }
@@ -580,7 +582,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     const AEPlan& a = A(0);
     const Deep2dWeights w{prm + a.cw[2], prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw,
                           prm + a.fc3w, prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
-    if ((rc = deep2d_pack(w, ws + e->o_pack2d_bwd, 1, st))) return rc;
+    if ((rc = deep2d_pack(w, ws + e->o_pack2d_bwd, 1, e->deep_bf16, st))) return rc;
   }
   // ---- decoder, last layer first
   for (int i = 5; i >= 0; --i) {
@@ -672,7 +674,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     io.g_t1 = ws + la.o_gdec[2]; io.g_t0 = ws + la.o_gdec[1]; io.g_d0 = ws + la.o_dd0; io.g_cat3 = ws + la.o_dcat3;
     io.g_mu = ws + la.o_dzmu; io.g_mu_ld = L; io.g_z1 = ws + la.o_dz1; io.g_cat1 = ws + la.o_dcat1;
     io.g_c4 = ws + la.o_genc[5]; io.g_c3 = ws + la.o_genc[4]; io.g_c2 = ws + la.o_genc[3]; io.g_c1 = ws + la.o_genc[2];
-    if ((rc = on_st([&] { return deep2d_bwd(io, ws + e->o_pack2d_bwd, B, 0, st); }))) return rc;
+    if ((rc = on_st([&] { return deep2d_bwd(io, ws + e->o_pack2d_bwd, B, 4 * e->deep_bf16, st); }))) return rc;
     // every dz of the eleven layers exists now: their weight gradients, released together
     // ... between the two streams: the data-gradient stream has only conv1's one-pass backward left, so a share of the
     // weight gradients follows that kernel there (bit k of the placement word: item k on the data-gradient stream)
@@ -862,6 +864,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
   int rc;
   e->recon_ready = false;  // a new forward: whatever reconstruction terms the workspace held are stale
   e->sum7_pending = false;
+  e->latent_early = false;
   if (e->pair_mode || !e->side_ok) {  // every launch of netT / netF carries both problems
     const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
     for (size_t i = 0; i < P.steps.size(); ++i) {
@@ -916,9 +919,11 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
 // was measured slower -- 0 / 6 / 12 / 24 steps: 2.28 / 2.32 / 2.39 / 2.49 ms, profiles/r03/README.md -- and removed.)
 // The second forward does not need the reconstructions of netT / netF (skip_b_1d_output).
 static int two_forwards(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws_a, hipStream_t st_a,
-                        float* ws_b, hipStream_t st_b, bool skip_b_1d_output, bool skip_a_1d_output = false) {
+                        float* ws_b, hipStream_t st_b, bool skip_b_1d_output, bool skip_a_1d_output = false,
+                        const std::function<int()>* after_latents_b = nullptr) {  // called once chain b's latents are enqueued
   e->recon_ready = false;
   e->sum7_pending = false;
+  e->latent_early = false;
   const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
   const int n = (int)P.steps.size();
   int rc;
@@ -943,6 +948,7 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
         return rc;
       }
     }
+    if ((size_t)i == P.latent_mark && after_latents_b && (rc = (*after_latents_b)())) return rc;
     if ((size_t)i == P.output1d_mark && skip_b_1d_output) continue;
     if ((rc = P.steps[i](ws_b, st_b))) return rc;
   }
@@ -1328,8 +1334,8 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->o_fpart = take(cur, 4 * pf);  // split-K scratch of the forward launches (two pair-sized slots)
   {
     const int ech[5] = {e->ae[0].enc[1].Cout, e->ae[0].enc[2].Cout, e->ae[0].enc[3].Cout, e->ae[0].enc[4].Cout, e->ae[0].enc[5].Cout};
-    e->deep2d = !(cfg->schedule & LSHM_SCHED_NO_DEEP2D) && cfg->precision == LSHM_PRECISION_F32 /* fp32 weights and products */ &&
-                deep2d_supported(cfg->L, e->hdim, cfg->rica, ech, e->ae[0].enc[3].Hin);
+    e->deep_bf16 = cfg->precision != LSHM_PRECISION_F32;  // bf16 operand precision: the chains stream bf16 weights
+    e->deep2d = !(cfg->schedule & LSHM_SCHED_NO_DEEP2D) && deep2d_supported(cfg->L, e->hdim, cfg->rica, ech, e->ae[0].enc[3].Hin);
     if (e->deep2d) e->o_pack2d = take(cur, deep2d_packed_floats());
   }
   e->fwd_floats = cur;
@@ -1566,8 +1572,30 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
   const bool recon_done = e->recon_ready;
   e->recon_ready = false;
   e->mark(lshm_engine::PH_CLOSURE, st);
-  int rc = start_latent_losses(e, params, grads, ws, st);
-  if (rc) return rc;
+  int rc;
+  if (e->latent_early) {
+    // the terms were started beside the forwards (lshm_engine_multiplier_update_next_ex): what is left for their stream are
+    // the seven sums of the reconstruction pass and the centroid gradient's move from scratch into the arena
+    e->latent_early = false;
+    e->latent_event = nullptr;
+    hipEvent_t ev = e->take_event();
+    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->lstream, ev, 0) != hipSuccess) {
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
+    if ((rc = pending_sum7(e, ws, e->lstream))) return rc;
+    if (hipMemcpyAsync(grads + e->Moff, ws + e->o_dMscratch, sizeof(float) * (size_t)e->cfg.K * e->D, hipMemcpyDeviceToDevice, e->lstream) != hipSuccess) {
+      set_last_error("engine: centroid-gradient copy failed");
+      return LSHM_ERR_ARG;
+    }
+    e->latent_event = e->take_event();
+    if (hipEventRecord(e->latent_event, e->lstream) != hipSuccess) {
+      set_last_error("engine: event record failed");
+      return LSHM_ERR_ARG;
+    }
+  } else if ((rc = start_latent_losses(e, params, grads, ws, st))) {
+    return rc;
+  }
   rc = losses_and_backward(e, params, grads, x, y1, y2, y3, terms, ws, st, recon_done);
   e->mark(lshm_engine::PH_CLOSURE_END, st);
   return rc;
@@ -1611,8 +1639,25 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
   const bool bf_ok = !e->bf || (aT.dec[5].in_bf16 && aT.dec[5].out_bf16 && aF.dec[5].in_bf16 && aF.dec[5].out_bf16);
   const bool from_a = concurrent && bf_ok && aT.dec[5].in_bs == aF.dec[5].in_bs &&
                       recon_from_a_supported(c.C, c.P, aT.dec[5].Cin, aT.dec[5].Cout, aT.dec[5].Win);
-  int rc = concurrent ? two_forwards(e, params, x, uv, fws, fst, ws, st, true, from_a) : three_forward(e, params, x, uv, fws, fst);
+  // The latent-space terms of the NEXT closure (K-harmonic, similarity, augmentation, log-cosh: src/kharmonic_lofar.py:160-172)
+  // need only the codes of the closure forward and the centroids: they start on their own stream as soon as that forward
+  // has its three codes, beside the rest of the two forwards, instead of at the head of the backward -- where their ~150 us
+  // chain ended ~40 us after the 1-D decoders' data gradients needed its result.  The centroid gradient waits in scratch;
+  // lshm_engine_backward_saved moves it into the arena.  Same kernels on the same operands: the same bits.
+  const bool early_latent = concurrent && e->side_wgrad && e->lstream && !(c.schedule & LSHM_SCHED_NO_EARLY_LATENT);
+  const std::function<int()> latent_hook = [&]() -> int {
+    hipEvent_t ev = e->take_event();
+    if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->lstream, ev, 0) != hipSuccess) {
+      set_last_error("engine: stream fork failed");
+      return LSHM_ERR_ARG;
+    }
+    e->sim_started = false;
+    return latent_losses(e, params, nullptr, ws, e->lstream);
+  };
+  int rc = concurrent ? two_forwards(e, params, x, uv, fws, fst, ws, st, true, from_a, early_latent ? &latent_hook : nullptr)
+                      : three_forward(e, params, x, uv, fws, fst);
   if (rc) return rc;
+  e->latent_early = early_latent;
   if (concurrent) e->mark(lshm_engine::PH_FWD_CLOSURE_END, st);
   e->mark(lshm_engine::PH_FWD_NOGRAD_END, fst);
   // concurrent: the seven sums of the pass (a 13 us launch the caller's stream would wait for) move to the latent-space

@@ -438,8 +438,9 @@ def _deep2d_reference(w, b, x2, uv1, uv3, dt):
     return [a3, a4, cat1, z1, mu, cat3, d0, t0, t1, t2, t3]
 
 
-@pytest.mark.parametrize("variant,nb", [(0, 256), (1, 256), (2, 256), (0, 5), (1, 5)],
-                         ids=["one-patch", "two-patches", "512-threads", "one-patch-ragged", "two-patches-ragged"])
+@pytest.mark.parametrize("variant,nb", [(0, 256), (1, 256), (2, 256), (0, 5), (1, 5), (4, 256), (5, 37)],
+                         ids=["one-patch", "two-patches", "512-threads", "one-patch-ragged", "two-patches-ragged", "bf16-weights",
+                              "bf16-weights-two-patches-ragged"])
 def test_deep_section_of_the_2d_autoencoder_as_one_launch(variant, nb):
     """lshm_deep2d_fwd (conv3 -> conv4 -> conv5 -> fc1 -> fc2in -> fc2out -> fc3 -> tconv0 -> tconv1 -> tconv2 -> tconv3 of
     AutoEncoderCNN2, src/lofar_models.py:36-55,66-98, one workgroup per patch (or two), activations resident in LDS,
@@ -467,9 +468,13 @@ def test_deep_section_of_the_2d_autoencoder_as_one_launch(variant, nb):
         assert torch.isfinite(o).all(), k
     # fp64 on whole samples (first / last patch, both patches of a two-patch workgroup)
     idx = [i for i in SAMPLES if i < nb] if nb > 5 else list(range(nb))
-    ref = _deep2d_reference(w, b, x2[idx], uv1[idx], uv3[idx], torch.float64)
+    # variants 4, 5 stream bf16 copies of the weights (fp32 activations, products and sums): fp64 on the rounded weights
+    wref = [t.bfloat16().float() for t in w] if variant & 4 else w
+    ref = _deep2d_reference(wref, b, x2[idx], uv1[idx], uv3[idx], torch.float64)
     for k, (o, r) in enumerate(zip(got, ref)):
         assert rel_err(o[idx].cpu().double().reshape(r.shape), r) < 2e-5, (variant, k)
+    if variant & 4:
+        return
     # the separate launches of the library (implicit GEMMs with their own summation order)
     st = L.stream()
     cur = x2d
@@ -582,7 +587,8 @@ def _deep2d_bwd_problem(nb, seed):
     return w, saved, g_t2, gmu
 
 
-@pytest.mark.parametrize("variant,nb", [(0, 256), (1, 256), (0, 5), (1, 5)], ids=["one-patch", "two-patches", "one-patch-ragged", "two-patches-ragged"])
+@pytest.mark.parametrize("variant,nb", [(0, 256), (1, 256), (0, 5), (1, 5), (4, 37)],
+                         ids=["one-patch", "two-patches", "one-patch-ragged", "two-patches-ragged", "bf16-weights"])
 def test_deep_section_backward_as_one_launch(variant, nb):
     """lshm_deep2d_bwd: the data gradients of tconv2, tconv1, tconv0, fc3, fc2out (+ the latent-term gradient), fc2in, fc1,
     conv5, conv4, conv3, conv2 of AutoEncoderCNN2 (autograd of src/lofar_models.py:73-98) from ONE launch -- the forward's
@@ -615,9 +621,12 @@ def test_deep_section_backward_as_one_launch(variant, nb):
     for k, o in enumerate(got):
         assert torch.isfinite(o).all(), k
     idx = [i for i in SAMPLES if i < nb] if nb > 5 else list(range(nb))
-    ref = _deep2d_bwd_reference(w, [t[idx] for t in saved], g_t2[idx], gmu[idx], torch.float64)
+    wref = [t.bfloat16().float() for t in w] if variant & 4 else w  # (variant 4: bf16 copies of the weights are streamed)
+    ref = _deep2d_bwd_reference(wref, [t[idx] for t in saved], g_t2[idx], gmu[idx], torch.float64)
     for k, (o, r) in enumerate(zip(got, ref)):
         assert rel_err(o[idx].cpu().double().reshape(r.shape), r) < 3e-5, (variant, k)
+    if variant & 4:
+        return
     # the separate launches of the library (no latent-term gradient: the C entry of the dense data gradient has no addend)
     got0 = run(False)
     st = L.stream()
