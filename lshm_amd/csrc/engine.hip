@@ -90,6 +90,7 @@ struct lshm_engine {
   bool full1d = false;  // conv2 .. tconv3 of the 1-D autoencoders' forward as one launch (chain1d_full.hip)
   size_t o_pack2d_bwd = 0;  // the backward's fragment-ordered weight copy
   unsigned wgrad_on_main = 0;  // which of the deep layers' weight gradients follow the data-gradient chain on ITS stream (ae_backward)
+  bool pack_bwd_done = false;  // this closure's backward weight copy was already made (on the latent-space stream)
   int deep_bf16 = 0;    // the deep chains stream bf16 copies of the weights (precision != LSHM_PRECISION_F32)
   int deep_variant = 0; // 0: one patch per workgroup (a forward alone), 1: two (two forwards side by side: each fills half of the CUs)
   size_t o_recon_part;  // per-block partial sums of the reconstruction pass (its own buffer: their seven sums may be made later, beside the backward)
@@ -578,7 +579,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // 2-D autoencoder: the data gradients of tconv2 .. conv2 (eleven layers) as one launch (deep2d.hip); their weight
   // gradients follow behind it
   const bool deepb = G == 1 && a0.ndim == 2 && e->deep2d_bwd && dinput[0] == nullptr;
-  if (deepb) {  // the fragment-ordered weight copy of the data-gradient pipeline (the parameters changed since the last backward)
+  if (deepb && !e->pack_bwd_done) {  // the fragment-ordered weight copy of the data-gradient pipeline, unless the latent-space stream made it
     const AEPlan& a = A(0);
     const Deep2dWeights w{prm + a.cw[2], prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw,
                           prm + a.fc3w, prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
@@ -746,9 +747,14 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   if ((rc = wgrad(hd, 768 + hd, hd, hd))) return rc;
   // the decoder's and the dense layers' closing sums go now (side stream, behind their producers): the
   // tail after the last weight gradient then only has the encoder's
-  pending.push_back([&]() { return grad_jobs_launch_dense(jobs, wst); });
+  // (deepb: the dense batch joins the batched conv launch on the data-gradient stream, which has only conv1's kernel left;
+  //  the weight-gradient stream keeps the two direct kernels and the closing sums)
+  if (deepb && side && jobs.batch_conv) main_wgrads.insert(main_wgrads.begin(), [&jobs, st]() { return grad_jobs_launch_dense(jobs, st); });
+  else pending.push_back([&]() { return grad_jobs_launch_dense(jobs, wst); });
   if ((rc = release(true))) return rc;
-  if (side && !deepb && (rc = grad_jobs_finish(jobs, wst))) return rc;  // (deepb: everything that is left is short; one round at the end)
+  // (deepb: every sum whose producer has been enqueued by now -- all but the batched launch's slabs and the last two layers' --
+  //  runs here, beside the data-gradient stream's last kernels; the round at the end is then a few small jobs)
+  if (side && (rc = grad_jobs_finish(jobs, wst))) return rc;
   // ---- encoder
   bool fused_tail = false;  // a fused kernel on `st` wrote partials that the closing sums on `wst` have not been ordered behind yet
   for (int g = 0; g < G; ++g) dz[g] = enc_from == 5 ? ws + LA(g).o_dcat1 : ws + LA(g).o_genc[enc_from + 1];
@@ -1004,6 +1010,18 @@ static int pending_sum7(lshm_engine* e, float* ws, hipStream_t st) {
   e->sum7_pending = false;
   return recon_sum7(ws + e->o_recon_part, e->cfg.B * e->cfg.C, e->cfg.P, reinterpret_cast<double*>(ws + e->o_scal), st);
 }
+// The fragment-ordered weight copy of the backward's deep chain depends on the parameters alone: it is made on the
+// latent-space stream, whose event the data-gradient stream waits for anyway, instead of in front of the 2-D backward.
+static int pack_backward_weights(lshm_engine* e, const float* prm, float* ws, hipStream_t st) {
+  e->pack_bwd_done = false;
+  if (!e->deep2d_bwd) return LSHM_OK;
+  const AEPlan& a = e->ae[0];
+  const Deep2dWeights w{prm + a.cw[2], prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw,
+                        prm + a.fc3w, prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
+  const int rc = deep2d_pack(w, ws + e->o_pack2d_bwd, 1, e->deep_bf16, st);
+  e->pack_bwd_done = rc == LSHM_OK;
+  return rc;
+}
 static int start_latent_losses(lshm_engine* e, const float* prm, float* grd, float* ws, hipStream_t st) {
   e->latent_event = nullptr;
   int rc;
@@ -1019,6 +1037,7 @@ static int start_latent_losses(lshm_engine* e, const float* prm, float* grd, flo
   if ((rc = pending_sum7(e, ws, e->lstream))) return rc;  // the sums of the reconstruction pass made with the previous forwards
   rc = latent_losses(e, prm, grd, ws, e->lstream);
   if (rc) return rc;
+  if (grd && (rc = pack_backward_weights(e, prm, ws, e->lstream))) return rc;
   e->latent_event = e->take_event();
   if (hipEventRecord(e->latent_event, e->lstream) != hipSuccess) {
     set_last_error("engine: event record failed");
@@ -1138,6 +1157,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     float* di0[1] = {nullptr};
     if ((rc = ae_backward(e, 1, i0, prm, grd, in0, dz0, di0, ws, 2, st, wgs))) return rc;
   }
+  e->pack_bwd_done = false;
   e->mark(lshm_engine::PH_BWD_MAIN_END, st);
   if (wgs) e->mark(lshm_engine::PH_BWD_SIDE_END, wgs);
   if (wgs) {  // the weight-gradient chain joins here, before anything consumes the gradients
@@ -1588,6 +1608,7 @@ int lshm_engine_backward_saved(lshm_engine* e, const float* params, float* grads
       set_last_error("engine: centroid-gradient copy failed");
       return LSHM_ERR_ARG;
     }
+    if ((rc = pack_backward_weights(e, params, ws, e->lstream))) return rc;
     e->latent_event = e->take_event();
     if (hipEventRecord(e->latent_event, e->lstream) != hipSuccess) {
       set_last_error("engine: event record failed");
