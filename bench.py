@@ -150,7 +150,7 @@ def khm_distance_roofline(dev, N=1 << 20, D=256, K=10, p=4.0):
             "frac": round(ach / HBM_PEAK_GBS, 4), "ms": round(ms, 4)}
 
 
-PMC_FILE = next((q for q in (os.path.join(ROOT, "profiles", r, "hbm_traffic.json") for r in ("r03", "r02"))
+PMC_FILE = next((q for q in (os.path.join(ROOT, "profiles", r, "hbm_traffic.json") for r in ("r04", "r03", "r02"))
                  if os.path.exists(q)), os.path.join(ROOT, "profiles", "r03", "hbm_traffic.json"))
 
 

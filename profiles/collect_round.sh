@@ -5,7 +5,7 @@
 # gpurun_out/<round>/out; copy the latter to profiles/<round>/ afterwards.  PMC passes are separate runs with
 # --kernel-trace only (FETCH_SIZE and WRITE_SIZE cannot share a pass).
 set -o pipefail
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/$R/out
 RAW=gpurun_out/$R/raw
 mkdir -p $OUT $RAW
@@ -20,13 +20,16 @@ cp $(ls $RAW/default/*/*kernel_stats.csv | head -1) $OUT/bench_default_kernel_st
 python3 profiles/summarize.py $RAW/default 1 -1 > $OUT/bench_default_kernel_stats.txt
 # 2. un-profiled bench line
 python3 bench.py > $OUT/bench_unprofiled_output.json 2> $RAW/unprofiled.err
-# 3. one ADMM iteration, kernel by kernel.  LSHM_WGRAD_GROUP=2 (exported: nothing may sit between rocprofv3's "--" and the
-#    program): with the default one-layer-at-a-time releases the HOST becomes the bottleneck under the profiler (3.29 ms of
-#    wall for 2.18 ms of device-busy time), which the unprofiled run is not (profiles/r03/phase_times.txt)
-export LSHM_WGRAD_GROUP=2
+# 3. one ADMM iteration, kernel by kernel, under the profiler (the shipped schedule; round 4 has the same timeline WITHOUT a
+#    profiler: step_timeline_unprofiled.txt / step_completions_unprofiled.txt below)
 rocprofv3 --kernel-trace -d $RAW/step --output-format csv -- python3 bench.py $STEP > $RAW/step.json 2> $RAW/step.err
-unset LSHM_WGRAD_GROUP
 python3 profiles/step_trace.py $RAW/step > $OUT/step_timeline.txt
+# 3b. the same iteration through lshm_trace_* (no profiler): start + stop events per launch, then stop events only
+python3 profiles/step_trace_unprofiled.py > $OUT/step_timeline_unprofiled.txt 2> $RAW/trace.err
+TRACE_ENDS_ONLY=1 python3 profiles/step_trace_unprofiled.py > $OUT/step_completions_unprofiled.txt 2>> $RAW/trace.err
+python3 profiles/phase_times_probe.py > $OUT/phase_times.txt 2> $RAW/phase.err
+python3 profiles/deep2d_probe.py > $OUT/deep2d_probe.txt 2> $RAW/deep2d.err
+python3 profiles/chain1d_full_probe.py > $OUT/chain1d_full_probe.txt 2> $RAW/chain1d_full.err
 # 4. HBM traffic: FETCH_SIZE / WRITE_SIZE in separate passes, keyed by the profiled command
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $RAW/pmc_step_$C --output-format csv -- python3 bench.py $STEP > /dev/null 2> $RAW/pmc_step_$C.err

@@ -27,4 +27,4 @@ def short(name: str) -> str:
                 else:
                     return ident + "<?>"
         return ident + ("<" + ", ".join(args) + ">" if args else "")
-    return n.replace("lshm::", "").replace("void ", "").split("(")[0]
+    return n.replace("(anonymous namespace)::", "").replace("lshm::", "").replace("void ", "").split("(")[0]
