@@ -305,6 +305,11 @@ int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_st
  * lshm_residual_split followed by lshm_conv_fwd_pair; for a forward whose activations are not kept. */
 int lshm_resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF,
                      const float* bF, float* yF, int B, lshm_stream_t stream);
+/* The same launch for a forward whose activations ARE kept (the closure forward): also writes the two vectorisations
+ * (out_row = the residual as the image, out_col = its per-plane transpose; (B,4,128*128) each) that the backward's
+ * weight gradients read.  Bitwise lshm_residual_split + lshm_conv_fwd_pair. */
+int lshm_resid_conv0_keep(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF,
+                          const float* bF, float* yF, float* out_row, float* out_col, int B, lshm_stream_t stream);
 size_t lshm_recon_workspace_floats(int planes, int P);
 /* sums7 = [sum e^2, y1.r1, sum r1^2, y2.r2, sum r2^2, y3.r3, sum r3^2]; gradients scaled by 1/n;
  * x3c / gx3c are in the column-vectorised (per-plane transposed) layout of the third AE.
@@ -457,8 +462,9 @@ typedef struct lshm_step_config {
 #define LSHM_SCHED_WGRAD_INLINE (1u << 17)    /* weight gradients on the data-gradient stream (no second stream) */
 #define LSHM_SCHED_FORK (1u << 18)            /* netT and netF on two streams instead of paired launches */
 #define LSHM_SCHED_PHASE_EVENTS (1u << 19)    /* diagnostic: record the phase-boundary events lshm_engine_phase_times reads */
-#define LSHM_SCHED_NO_KHM_MFMA (1u << 20)
-#define LSHM_SCHED_NO_EARLY_LATENT (1u << 21) /* latent-space terms at the head of the backward instead of beside the paired forwards */     /* K-harmonic pass for 16 < K <= 64 on the row-split kernel instead of the matrix cores */
+#define LSHM_SCHED_NO_KHM_MFMA (1u << 20)     /* K-harmonic pass for 16 < K <= 64 on the row-split kernel instead of the matrix cores */
+#define LSHM_SCHED_NO_EARLY_LATENT (1u << 21) /* latent-space terms at the head of the backward instead of beside the paired forwards */
+#define LSHM_SCHED_NO_RESID_CONV0_KEEP (1u << 22) /* closure forward: residual split + conv0 of netT / netF as two launches (lshm_resid_conv0_keep) */
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);
 void lshm_engine_destroy(lshm_engine* e);

@@ -473,8 +473,13 @@ int lshm_residual_split(const float* x, const float* x1, float* out_row, float* 
 int lshm_resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,
                      float* yF, int B, lshm_stream_t s) {
   REQUIRE(x && x1 && wT && bT && yT && wF && bF && yF && B > 0, "resid_conv0: bad argument");
-  if (!resid_conv0_supported(4, 128, 4, 8, 128 * 128)) { set_last_error("resid_conv0: switched off (LSHM_RESID_CONV0_OFF)"); return LSHM_ERR_UNSUPPORTED; }
+  if (!resid_conv0_supported(4, 128, 4, 8, 128 * 128)) { set_last_error("resid_conv0: switched off by the schedule word (LSHM_SCHED_NO_RESID_CONV0)"); return LSHM_ERR_UNSUPPORTED; }
   return resid_conv0(x, x1, wT, bT, yT, wF, bF, yF, 8L * 4096, B, ST(s));
+}
+int lshm_resid_conv0_keep(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,
+                          float* yF, float* out_row, float* out_col, int B, lshm_stream_t s) {
+  REQUIRE(x && x1 && wT && bT && yT && wF && bF && yF && out_row && out_col && B > 0, "resid_conv0_keep: bad argument");
+  return resid_conv0(x, x1, wT, bT, yT, wF, bF, yF, 8L * 4096, B, ST(s), 0, out_row, out_col);
 }
 int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_stream_t s) {
   REQUIRE(in && out && planes > 0, "plane_transpose: bad argument");

@@ -69,6 +69,7 @@ struct lshm_engine {
     size_t latent_mark = 0, output1d_mark = 0;
     size_t resid_mark = 0;        // steps[resid_mark] = residual_split, steps[resid_mark + 1] = conv0 of netT / netF
     lshm::FwdStep resid_conv0;    // both in one launch, neither vectorisation written (resid_conv0.hip); empty: not available
+    lshm::FwdStep resid_conv0_keep;  // ... with both vectorisations written: what a forward with kept activations runs
   } plan;
   int D;        // L + 2 Lt
   int hdim;     // 4 H
@@ -453,7 +454,8 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
 // them alone, the 2-D autoencoder, the residual split, netT and netF as paired launches.
 static void three_forward_steps(const lshm_engine* e, const float* prm, const float* x, const float* uv,
                                 std::vector<FwdStep>& steps, size_t* latent_mark, size_t* output1d_mark,
-                                size_t* resid_mark = nullptr, FwdStep* resid_conv0_step = nullptr) {
+                                size_t* resid_mark = nullptr, FwdStep* resid_conv0_step = nullptr,
+                                FwdStep* resid_conv0_keep_step = nullptr) {
   const lshm_step_config& c = e->cfg;
   steps.push_back([=](float* ws, hipStream_t st) -> int {
     UvLayers ul;
@@ -485,6 +487,14 @@ static void three_forward_steps(const lshm_engine* e, const float* prm, const fl
         return resid_conv0(x, ws + e->ae[0].out, prm + aT.cw[0], prm + aT.cb[0], ws + aT.act[0], prm + aF.cw[0], prm + aF.cb[0],
                            ws + aF.act[0], aT.enc[0].out_bs, c.B, st, e->bf);
       };
+    if (resid_conv0_keep_step) {
+      *resid_conv0_keep_step = nullptr;
+      if (*resid_conv0_step && !sched(LSHM_SCHED_NO_RESID_CONV0_KEEP))
+        *resid_conv0_keep_step = [=](float* ws, hipStream_t st) -> int {
+          return resid_conv0(x, ws + e->ae[0].out, prm + aT.cw[0], prm + aT.cb[0], ws + aT.act[0], prm + aF.cw[0], prm + aF.cb[0],
+                             ws + aF.act[0], aT.enc[0].out_bs, c.B, st, e->bf, ws + e->o_row, ws + e->o_col);
+        };
+    }
   }
   steps.push_back([=](float* ws, hipStream_t st) -> int {
     return residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st, e->bf);
@@ -856,7 +866,7 @@ static const lshm_engine::FwdPlan& forward_plan(lshm_engine* e, const float* prm
   if (P.prm != prm || P.x != x || P.uv != uv || P.steps.empty()) {
     P.steps.clear();
     P.prm = prm; P.x = x; P.uv = uv;
-    three_forward_steps(e, prm, x, uv, P.steps, &P.latent_mark, &P.output1d_mark, &P.resid_mark, &P.resid_conv0);
+    three_forward_steps(e, prm, x, uv, P.steps, &P.latent_mark, &P.output1d_mark, &P.resid_mark, &P.resid_conv0, &P.resid_conv0_keep);
   }
   return P;
 }
@@ -876,6 +886,10 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
     for (size_t i = 0; i < P.steps.size(); ++i) {
       if (i == P.latent_mark && after_latents && (rc = (*after_latents)())) return rc;
       if (i == P.output1d_mark && skip_1d_output) continue;
+      if (P.resid_conv0_keep && (i == P.resid_mark || i == P.resid_mark + 1)) {  // residual split + conv0 pair: one launch
+        if (i == P.resid_mark && (rc = P.resid_conv0_keep(ws, st))) return rc;
+        continue;
+      }
       if ((rc = P.steps[i](ws, st))) return rc;
     }
     return LSHM_OK;
@@ -922,7 +936,9 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
 // (mid / deep / dense layers: a few microseconds per launch on a fraction of the machine); in lock step like meets
 // like: the latency-bound stretches overlap almost for free, the bandwidth-bound ones share the HBM pipe.
 // (Holding the second chain n steps behind the first, which pairs one chain's outer layers with the other's deep layers,
-// was measured slower -- 0 / 6 / 12 / 24 steps: 2.28 / 2.32 / 2.39 / 2.49 ms, profiles/r03/README.md -- and removed.)
+// was measured slower -- 0 / 6 / 12 / 24 steps: 2.28 / 2.32 / 2.39 / 2.49 ms, profiles/r03/README.md; again in round 4 with the
+// deep section as one launch and a cross-stream gate: 0 / 2 / 3 / 4 / 5 / 6 / 8 steps: 1.88 / 1.89 / 1.90 / 1.90 / 1.92 / 2.02 /
+// 2.04 ms, one patch per deep workgroup instead of two: +0.04, profiles/r04/README.md -- and removed.)
 // The second forward does not need the reconstructions of netT / netF (skip_b_1d_output).
 static int two_forwards(lshm_engine* e, const float* prm, const float* x, const float* uv, float* ws_a, hipStream_t st_a,
                         float* ws_b, hipStream_t st_b, bool skip_b_1d_output, bool skip_a_1d_output = false,
@@ -942,6 +958,13 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
   } variant_scope(e);
   // chain a is the forward whose activations are not kept (the no-grad forward): its residual split + conv0 pair is one launch
   const bool fused_a = skip_b_1d_output && P.resid_conv0 && P.resid_mark + 1 < (size_t)n;
+  auto step_b = [&](int i) -> int {
+    if ((size_t)i == P.latent_mark && after_latents_b && (rc = (*after_latents_b)())) return rc;
+    if ((size_t)i == P.output1d_mark && skip_b_1d_output) return LSHM_OK;
+    if (P.resid_conv0_keep && ((size_t)i == P.resid_mark || (size_t)i == P.resid_mark + 1))
+      return (size_t)i == P.resid_mark ? P.resid_conv0_keep(ws_b, st_b) : LSHM_OK;
+    return P.steps[i](ws_b, st_b);
+  };
   for (int i = 0; i < n; ++i) {
     {
       if (fused_a && (size_t)i == P.resid_mark) {
@@ -954,9 +977,7 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
         return rc;
       }
     }
-    if ((size_t)i == P.latent_mark && after_latents_b && (rc = (*after_latents_b)())) return rc;
-    if ((size_t)i == P.output1d_mark && skip_b_1d_output) continue;
-    if ((rc = P.steps[i](ws_b, st_b))) return rc;
+    if ((rc = step_b(i))) return rc;
   }
   return LSHM_OK;
 }
@@ -1401,7 +1422,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
     e->full1d = (cfg->schedule & LSHM_SCHED_TRY_FULL1D) && cfg->precision == LSHM_PRECISION_F32 &&
                 chain1d_full_supported(cfg->Lt, e->hdim, cfg->rica, ech, e->ae[1].enc[2].Win);
   }
-  e->wgrad_on_main = cfg->tune ? cfg->tune - 1 : 0u;  // (experimental placement word: lshm_step_config.tune, 0 = shipped)
+  e->wgrad_on_main = (cfg->tune & 0xffffu) ? (cfg->tune & 0xffffu) - 1 : 0u;  // (experimental placement word: lshm_step_config.tune, 0 = shipped)
   if (e->deep2d_bwd) e->o_pack2d_bwd = take(cur, deep2d_packed_floats());
   e->o_recon_part = take(cur, recon_partials_floats(B * cfg->C, cfg->P));
   e->latent_ws_floats = khm_workspace_floats(B, e->D, cfg->K);

@@ -219,7 +219,8 @@ int conv2d_bwd_lds(const float* small, long s_bs, const float* big, long big_bs,
 // conv0 of netT and netF from x and the 2-D reconstruction in one launch, no materialised residual (resid_conv0.hip)
 bool resid_conv0_supported(int C, int P, int Cin, int Cout, int L1d);
 int resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,
-                float* yF, long y_bs, int B, hipStream_t st, int bf = 0);  // bf: x1 and the outputs are bf16 tensors
+                float* yF, long y_bs, int B, hipStream_t st, int bf = 0,   // bf: x1, the outputs and the kept images are bf16 tensors
+                float* out_row = nullptr, float* out_col = nullptr);       // both given: the residual images are written too
 
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,

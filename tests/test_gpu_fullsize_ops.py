@@ -335,11 +335,12 @@ def test_dense_middle_of_the_1d_autoencoder_as_one_launch(nb, Ld):
         assert torch.isfinite(got).all() and rel_err(got, ref) < 2e-5
 
 
-@pytest.mark.parametrize("nb", [256, 3])
-def test_first_1d_layers_straight_from_the_images_are_bitwise_the_two_launches(nb):
-    """lshm_resid_conv0 (netT.conv0 and netF.conv0 of the row- / column-vectorised residual (x - x1) / 2 in one launch,
-    nothing materialised; src/kharmonic_lofar.py:142-147, src/lofar_models.py:115) against lshm_residual_split followed
-    by lshm_conv_fwd_pair: bit for bit, every output; and against fp64."""
+@pytest.mark.parametrize("nb,keep", [(256, False), (256, True), (3, False), (13, True), (8, True)])
+def test_first_1d_layers_straight_from_the_images_are_bitwise_the_two_launches(nb, keep):
+    """lshm_resid_conv0 / lshm_resid_conv0_keep (netT.conv0 and netF.conv0 of the row- / column-vectorised residual
+    (x - x1) / 2 in one launch from one 64 x 64 tile per workgroup; nothing materialised, or -- keep -- both vectorisations
+    written too; src/kharmonic_lofar.py:142-147, src/lofar_models.py:115) against lshm_residual_split followed by
+    lshm_conv_fwd_pair: bit for bit, every output; and against fp64."""
     from lshm_amd import _lib as L
     lib = L.load()
     g = torch.Generator().manual_seed(77 + nb)
@@ -350,7 +351,12 @@ def test_first_1d_layers_straight_from_the_images_are_bitwise_the_two_launches(n
     wd, bd = [t.to(DEV) for t in w], [t.to(DEV) for t in b]
     st, P = L.stream(), L.ptr
     y = [torch.full((nb, 8, 4096), float("nan"), device=DEV) for _ in range(2)]
-    L.check(lib.lshm_resid_conv0(P(xd), P(x1d), P(wd[0]), P(bd[0]), P(y[0]), P(wd[1]), P(bd[1]), P(y[1]), nb, st), "resid_conv0")
+    kept = [torch.full((nb, 4, 16384), float("nan"), device=DEV) for _ in range(2)]
+    if keep:
+        L.check(lib.lshm_resid_conv0_keep(P(xd), P(x1d), P(wd[0]), P(bd[0]), P(y[0]), P(wd[1]), P(bd[1]), P(y[1]), P(kept[0]), P(kept[1]),
+                                          nb, st), "resid_conv0_keep")
+    else:
+        L.check(lib.lshm_resid_conv0(P(xd), P(x1d), P(wd[0]), P(bd[0]), P(y[0]), P(wd[1]), P(bd[1]), P(y[1]), nb, st), "resid_conv0")
     row, col = torch.empty(nb, 4, 16384, device=DEV), torch.empty(nb, 4, 16384, device=DEV)
     L.check(lib.lshm_residual_split(P(xd), P(x1d), P(row), P(col), nb * 4, 128, st), "residual_split")
     z = [torch.empty(nb, 8, 4096, device=DEV) for _ in range(2)]
@@ -358,6 +364,8 @@ def test_first_1d_layers_straight_from_the_images_are_bitwise_the_two_launches(n
                                    None, 0, st), "conv_fwd_pair")
     torch.cuda.synchronize()
     assert torch.equal(y[0], z[0]) and torch.equal(y[1], z[1])
+    if keep:
+        assert torch.equal(kept[0], row) and torch.equal(kept[1], col)
     r = (x.double() - x1.double()) / 2
     refT = TF.elu(TF.conv1d(r.reshape(nb, 4, -1), w[0].double(), b[0].double(), stride=4, padding=1))
     refF = TF.elu(TF.conv1d(r.transpose(2, 3).reshape(nb, 4, -1), w[1].double(), b[1].double(), stride=4, padding=1))
