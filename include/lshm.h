@@ -310,6 +310,16 @@ int lshm_resid_conv0(const float* x, const float* x1, const float* wT, const flo
  * weight gradients read.  Bitwise lshm_residual_split + lshm_conv_fwd_pair. */
 int lshm_resid_conv0_keep(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF,
                           const float* bF, float* yF, float* out_row, float* out_col, int B, lshm_stream_t stream);
+/* Backward of netT.conv0 and netF.conv0 (src/lofar_models.py:115) and the gradient w.r.t. the 2-D reconstruction
+ * (src/kharmonic_lofar.py:142-147: both read (x - x1) / 2) in ONE pass over image tiles:
+ *   dwT, dbT, dwF, dbF (=|+=) the layers' weight / bias gradients, gx1 = gx1p - (dT + dF^T) / 2
+ * resid_row: the residual as the image (B,4,128*128) -- the column-vectorised copy is not read; dzT, dzF: (B,8,4096)
+ * gradients w.r.t. the layers' pre-activations; gx1p, gx1: (B,4,128,128).  Replaces lshm_conv_bwd_fused on the pair
+ * followed by lshm_combine_dx1 (same values up to fp32 summation order). */
+size_t lshm_conv0_bwd_tile_workspace_floats(void);
+int lshm_conv0_bwd_tile(const float* resid_row, const float* dzT, const float* dzF, const float* wT, const float* wF,
+                        const float* gx1p, float* gx1, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws,
+                        size_t ws_floats, int accumulate, lshm_stream_t stream);
 size_t lshm_recon_workspace_floats(int planes, int P);
 /* sums7 = [sum e^2, y1.r1, sum r1^2, y2.r2, sum r2^2, y3.r3, sum r3^2]; gradients scaled by 1/n;
  * x3c / gx3c are in the column-vectorised (per-plane transposed) layout of the third AE.
@@ -464,6 +474,7 @@ typedef struct lshm_step_config {
 #define LSHM_SCHED_PHASE_EVENTS (1u << 19)    /* diagnostic: record the phase-boundary events lshm_engine_phase_times reads */
 #define LSHM_SCHED_NO_KHM_MFMA (1u << 20)     /* K-harmonic pass for 16 < K <= 64 on the row-split kernel instead of the matrix cores */
 #define LSHM_SCHED_NO_EARLY_LATENT (1u << 21) /* latent-space terms at the head of the backward instead of beside the paired forwards */
+#define LSHM_SCHED_NO_CONV0_BWD_TILE (1u << 23) /* backward of 1-D conv0 (netT, netF) and the combination into the 2-D autoencoder's output gradient as two launches (lshm_conv0_bwd_tile) */
 #define LSHM_SCHED_NO_RESID_CONV0_KEEP (1u << 22) /* closure forward: residual split + conv0 of netT / netF as two launches (lshm_resid_conv0_keep) */
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);

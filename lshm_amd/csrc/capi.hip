@@ -481,6 +481,13 @@ int lshm_resid_conv0_keep(const float* x, const float* x1, const float* wT, cons
   REQUIRE(x && x1 && wT && bT && yT && wF && bF && yF && out_row && out_col && B > 0, "resid_conv0_keep: bad argument");
   return resid_conv0(x, x1, wT, bT, yT, wF, bF, yF, 8L * 4096, B, ST(s), 0, out_row, out_col);
 }
+size_t lshm_conv0_bwd_tile_workspace_floats(void) { return conv0_bwd_tile_workspace_floats(); }
+int lshm_conv0_bwd_tile(const float* r, const float* dzT, const float* dzF, const float* wT, const float* wF, const float* gx1p,
+                        float* gx1, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws, size_t wsf, int accumulate,
+                        lshm_stream_t s) {
+  REQUIRE(r && dzT && dzF && wT && wF && gx1p && gx1 && dwT && dwF && ws && B > 0, "conv0_bwd_tile: bad argument");
+  return conv0_bwd_tile(r, dzT, dzF, 8L * 4096, wT, wF, gx1p, gx1, dwT, dbT, dwF, dbF, B, ws, wsf, accumulate, ST(s), nullptr);
+}
 int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_stream_t s) {
   REQUIRE(in && out && planes > 0, "plane_transpose: bad argument");
   return plane_transpose(in, out, planes, P, ST(s));

@@ -509,10 +509,13 @@ static void three_forward_steps(const lshm_engine* e, const float* prm, const fl
 // the AE input, or null.  With G == 2, lane 0 holds problem 0's scratch and lane 1 problem 1's.
 // Weight-gradient launches leave their closing sums (split-K slabs, workgroup partials, bias
 // gradients) on a job list that two launches finish at the end; every dz therefore has its own buffer.
+// netT / netF as a pair: where their input gradients go (gx1 = gx1p - (dT + dF^T) / 2, src/kharmonic_lofar.py:142-147).  Given, the
+// backward of their first layer forms gx1 itself (conv0_bwd_tile.hip) and sets `done`; otherwise the caller combines dinput[].
+struct CombineInto { const float* gx1p; float* gx1; bool done; };
 static int ae_backward(const lshm_engine* e, int G, const int* idx, const float* prm, float* grd,
                        const float* const* input, const float* const* dz_out, float* const* dinput, float* ws,
                        int ln, hipStream_t st, hipStream_t wgrad_stream,
-                       const std::function<int()>* before_dense = nullptr) {
+                       const std::function<int()>* before_dense = nullptr, const CombineInto* combine = nullptr) {
   const lshm_step_config& c = e->cfg;
   const AEPlan& a0 = e->ae[idx[0]];
   const int B = c.B, hd = e->hdim, L = a0.L, D = e->D;
@@ -797,6 +800,21 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_genc[2];
       i = 2;
       continue;
+    }
+    if (i == 0 && G == 2 && combine && !e->bf && A(1).enc[0].out_bs == a0.enc[0].out_bs &&
+        conv0_bwd_tile_supported(c.C, c.P, a0.enc[0].Cin, a0.enc[0].Cout, a0.enc[0].Win, a0.enc[0].in_bs)) {
+      // first layer of netT and netF: both weight gradients, both data gradients and their combination with the
+      // reconstruction terms' share into the 2-D autoencoder's output gradient, one pass over image tiles
+      const size_t twf = conv0_bwd_tile_workspace_floats();
+      float* tws = jobs.take(twf);
+      if (!tws) { set_last_error("engine: deferred-sum scratch exhausted"); return LSHM_ERR_WORKSPACE; }
+      if ((rc = on_st([&] {
+             return conv0_bwd_tile(input[0], dz[0], dz[1], a0.enc[0].out_bs, prm + A(0).cw[0], prm + A(1).cw[0], combine->gx1p, combine->gx1,
+                                   grd + A(0).cw[0], grd + A(0).cb[0], grd + A(1).cw[0], grd + A(1).cb[0], B, tws, twf, 0, st, &jobs);
+           }))) return rc;
+      const_cast<CombineInto*>(combine)->done = true;
+      fused_tail = true;
+      break;
     }
     ConvWgradIO wg[2];
     ConvDgradIO dg[2];
@@ -1132,13 +1150,14 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     return e->comm ? comm_allreduce_segments(e->comm, nullptr, nullptr, 0, terms, 10, st) : LSHM_OK;
   // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
   hipStream_t wgs = (e->pair_mode && e->side_ok && e->side_wgrad) ? e->wstream : nullptr;
+  CombineInto combine{ws + e->o_gx1p, ws + e->o_gx1, false};
   {
     const int i12[2] = {1, 2};
     const float* in12[2] = {ws + e->o_row, ws + e->o_col};
     const float* dz12[2] = {ws + e->o_gx2, ws + e->o_gx3c};
     float* di12[2] = {ws + e->o_gT, ws + e->o_gFc};
     if (e->pair_mode || !e->side_ok) {
-      if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, 0, st, wgs, deferred ? &join_latent : nullptr))) return rc;
+      if ((rc = ae_backward(e, 2, i12, prm, grd, in12, dz12, di12, ws, 0, st, wgs, deferred ? &join_latent : nullptr, &combine))) return rc;
     } else {
       hipEvent_t evf = e->take_event();
       if (hipEventRecord(evf, st) != hipSuccess || hipStreamWaitEvent(e->wstream, evf, 0) != hipSuccess) {
@@ -1170,7 +1189,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     e->last_flags |= LSHM_ENGINE_USED_EARLY_BUCKET;
   }
   e->mark(lshm_engine::PH_BWD1D, st);
-  if ((rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st, e->bf))) return rc;
+  if (!combine.done && (rc = combine_dx1(ws + e->o_gx1p, ws + e->o_gT, ws + e->o_gFc, ws + e->o_gx1, planes, c.P, st, e->bf))) return rc;
   {
     const int i0[1] = {0};
     const float* in0[1] = {x};

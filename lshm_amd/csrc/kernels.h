@@ -222,6 +222,13 @@ int resid_conv0(const float* x, const float* x1, const float* wT, const float* b
                 float* yF, long y_bs, int B, hipStream_t st, int bf = 0,   // bf: x1, the outputs and the kept images are bf16 tensors
                 float* out_row = nullptr, float* out_col = nullptr);       // both given: the residual images are written too
 
+// backward of conv0 of netT / netF + the combination into the 2-D autoencoder's output gradient, one pass (conv0_bwd_tile.hip)
+bool conv0_bwd_tile_supported(int C, int P, int Cin, int Cout, int L1d, long in_bs);
+size_t conv0_bwd_tile_workspace_floats();
+int conv0_bwd_tile(const float* r, const float* dzT, const float* dzF, long z_bs, const float* wT, const float* wF, const float* gx1p,
+                   float* gx1, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws, size_t wsf, int accumulate,
+                   hipStream_t st, GradJobs* defer);
+
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
                                 const float* small, const float* big);

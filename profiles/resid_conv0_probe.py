@@ -21,7 +21,7 @@ flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 def timed(fn, reps=20):
     ts = []
     for _ in range(reps):
-        flush.zero_()
+        flush.max()   # evict by READING 512 MB: clean lines only (a fill would leave 256 MB of dirty lines to write back under the timed kernel)
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); fn(); e.record(); torch.cuda.synchronize()
         ts.append(a.elapsed_time(e) * 1e3)

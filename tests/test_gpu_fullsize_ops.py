@@ -372,6 +372,60 @@ def test_first_1d_layers_straight_from_the_images_are_bitwise_the_two_launches(n
     assert rel_err(y[0], refT) < 1e-5 and rel_err(y[1], refF) < 1e-5
 
 
+@pytest.mark.parametrize("nb", [256, 5, 8])
+def test_first_1d_layers_backward_and_the_combination_as_one_launch(nb):
+    """lshm_conv0_bwd_tile (weight, bias and data gradients of netT.conv0 and netF.conv0 and gx1 = gx1p - (dT + dF^T) / 2 from one
+    pass over 32 x 64 image tiles; backward of src/lofar_models.py:115 on both networks, src/kharmonic_lofar.py:142-147) against the
+    launches it replaces (lshm_conv_bwd_fused on each network, then lshm_combine_dx1) and against fp64.  The column-vectorised
+    residual is NOT given to the new entry: netF's windows are read column-wise from the row image."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(500 + nb)
+    r = torch.randn(nb, 4, 128, 128, generator=g)                    # the residual (x - x1) / 2 as the image
+    dz = [torch.randn(nb, 8, 4096, generator=g) for _ in range(2)]  # netT, netF: gradients w.r.t. conv0's pre-activations
+    w = [torch.randn(8, 4, 4, generator=g) * 0.3 for _ in range(2)]
+    gx1p = torch.randn(nb, 4, 128, 128, generator=g)
+    rd, gpd = r.to(DEV), gx1p.to(DEV)
+    rcol = r.transpose(2, 3).contiguous().to(DEV)
+    dzd, wd = [t.to(DEV) for t in dz], [t.to(DEV) for t in w]
+    st, P = L.stream(), L.ptr
+    nws = lib.lshm_conv0_bwd_tile_workspace_floats()
+    ws = torch.empty(nws, device=DEV)
+    dw = [torch.full((8, 4, 4), float("nan"), device=DEV) for _ in range(2)]
+    db = [torch.full((8,), float("nan"), device=DEV) for _ in range(2)]
+    gx1 = torch.full((nb, 4, 128, 128), float("nan"), device=DEV)
+    L.check(lib.lshm_conv0_bwd_tile(P(rd), P(dzd[0]), P(dzd[1]), P(wd[0]), P(wd[1]), P(gpd), P(gx1), P(dw[0]), P(db[0]), P(dw[1]), P(db[1]),
+                                    nb, P(ws), nws, 0, st), "conv0_bwd_tile")
+    # the replaced launches
+    nws2 = lib.lshm_conv_workspace_floats(2, nb, 4, 8, 1, 16384)
+    ws2 = torch.empty(nws2, device=DEV)
+    dw2 = [torch.empty(8, 4, 4, device=DEV) for _ in range(2)]
+    db2 = [torch.empty(8, device=DEV) for _ in range(2)]
+    dx2 = [torch.empty(nb, 4, 16384, device=DEV) for _ in range(2)]
+    for k, xin in enumerate((rd, rcol)):
+        L.check(lib.lshm_conv_bwd_fused(2, P(xin), P(dzd[k]), P(wd[k]), P(dw2[k]), P(db2[k]), P(dx2[k]), 0, nb, 4, 8, 1, 16384, P(ws2), nws2,
+                                        st), "conv_bwd_fused")
+    gx1_2 = torch.empty_like(gx1)
+    L.check(lib.lshm_combine_dx1(P(gpd), P(dx2[0]), P(dx2[1]), P(gx1_2), nb * 4, 128, st), "combine_dx1")
+    torch.cuda.synchronize()
+    assert torch.isfinite(gx1).all()
+    for k in range(2):
+        assert rel_err(dw[k], dw2[k]) < 2e-6 and rel_err(db[k], db2[k]) < 2e-6
+    assert rel_err(gx1, gx1_2) < 2e-6
+    # fp64
+    seqs = (r.double().reshape(nb, 4, -1), r.double().transpose(2, 3).reshape(nb, 4, -1))
+    gref = gx1p.double().clone()
+    for k in range(2):
+        xs = seqs[k].clone().requires_grad_(True)
+        wr = w[k].double().requires_grad_(True)
+        br = torch.zeros(8, dtype=torch.float64, requires_grad=True)
+        TF.conv1d(xs, wr, br, stride=4, padding=1).backward(dz[k].double())
+        assert rel_err(dw[k], wr.grad) < 1e-4 and rel_err(db[k], br.grad) < 1e-4
+        d = xs.grad.reshape(nb, 4, 128, 128)
+        gref -= 0.5 * (d if k == 0 else d.transpose(2, 3))
+    assert rel_err(gx1, gref) < 1e-5
+
+
 @pytest.mark.parametrize("nb", [256, 2])
 def test_reconstruction_pass_from_the_last_layers_input_is_bitwise_the_two_launches(nb):
     """lshm_recon_losses_from_a (the reconstruction terms and gradients with x2 / x3c formed inside the pass from the input of
