@@ -307,7 +307,8 @@ int lshm_resid_conv0(const float* x, const float* x1, const float* wT, const flo
                      const float* bF, float* yF, int B, lshm_stream_t stream);
 /* The same launch for a forward whose activations ARE kept (the closure forward): also writes the two vectorisations
  * (out_row = the residual as the image, out_col = its per-plane transpose; (B,4,128*128) each) that the backward's
- * weight gradients read.  Bitwise lshm_residual_split + lshm_conv_fwd_pair. */
+ * weight gradients read.  out_col may be NULL (lshm_conv0_bwd_tile reads the row image alone).  Bitwise
+ * lshm_residual_split + lshm_conv_fwd_pair. */
 int lshm_resid_conv0_keep(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF,
                           const float* bF, float* yF, float* out_row, float* out_col, int B, lshm_stream_t stream);
 /* Backward of netT.conv0 and netF.conv0 (src/lofar_models.py:115) and the gradient w.r.t. the 2-D reconstruction

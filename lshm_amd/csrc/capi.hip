@@ -478,7 +478,7 @@ int lshm_resid_conv0(const float* x, const float* x1, const float* wT, const flo
 }
 int lshm_resid_conv0_keep(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,
                           float* yF, float* out_row, float* out_col, int B, lshm_stream_t s) {
-  REQUIRE(x && x1 && wT && bT && yT && wF && bF && yF && out_row && out_col && B > 0, "resid_conv0_keep: bad argument");
+  REQUIRE(x && x1 && wT && bT && yT && wF && bF && yF && out_row && B > 0, "resid_conv0_keep: bad argument");
   return resid_conv0(x, x1, wT, bT, yT, wF, bF, yF, 8L * 4096, B, ST(s), 0, out_row, out_col);
 }
 size_t lshm_conv0_bwd_tile_workspace_floats(void) { return conv0_bwd_tile_workspace_floats(); }

@@ -26,7 +26,7 @@ typedef const __attribute__((address_space(4))) f32x4* cf32x4_ptr;
 __device__ __forceinline__ f32x4 uload4(const float* q) { return *(cf32x4_ptr)(q); }
 constexpr int P = 128, CI = 4, CO = 8, L = P * P, LO = L / 4;
 constexpr int TR = 32, TC = 64;          // tile rows / columns
-constexpr int NT = 256;
+constexpr int NT = 512;
 constexpr int TPI = (P / TR) * (P / TC);  // tiles per image
 constexpr int RP = TC + 2;               // res[ci][1 + r][1 + c]: row 0 = the row above the tile, column 0 = the column before it
 constexpr int RCH = (TR + 1) * RP;
@@ -50,23 +50,18 @@ struct Conv0BwdTileArgs {
   int B, ntiles;
 };
 
-__global__ __launch_bounds__(NT) void conv0_bwd_tile_kernel(const Conv0BwdTileArgs a) {
+__global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTileArgs a) {
+  static_assert(NT == 512 && TR == 32 && TC == 64, "the thread maps below are written for 512 threads and 32 x 64 tiles");
   __shared__ __attribute__((aligned(16))) float res[CI * RCH];
   __shared__ __attribute__((aligned(16))) float zT[CO * ZTP];
   __shared__ __attribute__((aligned(16))) float zF[CO * ZFP];
+  __shared__ float wfl[NW];  // netF's weights: a thread's rows all have the same (row + 1) mod 4 = tap, but lanes differ
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lm = lane & 15, lk = lane >> 4;
-  // data-gradient weights of netF for this thread's rows: every row it handles has the same (row + 1) mod 4 = tap
-  const int c4 = t & 15, rq = t >> 4;
-  float wf[CI][CO];
-  {
-    const int tap = (rq + 1) & 3;
-#pragma unroll
-    for (int ci = 0; ci < CI; ++ci)
-#pragma unroll
-      for (int cs = 0; cs < CO; ++cs) wf[ci][cs] = a.w[1][(cs * CI + ci) * 4 + tap];
-  }
+  const int c4 = t & 15, rq = t >> 4;  // this thread's output quads: row rq, columns 4 c4 .. 4 c4 + 3 of every channel
+  const int tap = (rq + 1) & 3;
+  if (t < NW) wfl[t] = a.w[1][t];
   f32x4 accT = {0.f, 0.f, 0.f, 0.f}, accF = {0.f, 0.f, 0.f, 0.f};
-  float bacc = 0.f;  // bias gradient: thread (net = t >> 7, cs = (t >> 4) & 7) sums 1/16 of the tile's positions
+  float bacc = 0.f;  // bias gradient: thread (net = t >> 8, cs = (t >> 5) & 7) sums 1/32 of the tile's positions
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     // tiles 64 q + 8 k + i  ->  image 8 q + i, tile k: the eight tiles of an image run on one XCD, close in time
     const int b = 8 * (tile >> 6) + (tile & 7), k = (tile >> 3) & 7;
@@ -76,134 +71,125 @@ __global__ __launch_bounds__(NT) void conv0_bwd_tile_kernel(const Conv0BwdTileAr
     const float* zTb = a.dz[0] + (long)b * a.z_bs;
     const float* zFb = a.dz[1] + (long)b * a.z_bs;
     __syncthreads();  // the previous tile's readers are done
-    // ---- stage the residual tile and its two halos
+    // ---- stage the residual tile, the positions that cover it and the halos
     {
-      f32x4 v[CI * TR * (TC / 4) / NT];
+      constexpr int NV = CI * TR * (TC / 4) / NT, NZT = CO * TR * 4 / NT, NZF = CO * TC * 2 / NT;
+      f32x4 v[NV], zt[NZT], zf[NZF];
 #pragma unroll
-      for (int q = 0; q < CI * TR * (TC / 4) / NT; ++q) {
-        const int i = t + NT * q, rr = i >> 4, ci = rr >> 5, r = rr & (TR - 1);
-        v[q] = *reinterpret_cast<const f32x4*>(rb + ((long)ci * P + r0 + r) * P + c0 + 4 * c4);
-      }
-      f32x4 zt[CO * TR * 4 / NT], zf[CO * TC * 2 / NT];
+      for (int q = 0; q < NV; ++q)  // i = t + NT q: channel q, row rq, quad c4
+        v[q] = *reinterpret_cast<const f32x4*>(rb + ((long)q * P + r0 + rq) * P + c0 + 4 * c4);
 #pragma unroll
-      for (int q = 0; q < CO * TR * 4 / NT; ++q) {
+      for (int q = 0; q < NZT; ++q) {
         const int i = t + NT * q, p4 = i & 3, rr = i >> 2, cs = rr >> 5, r = rr & (TR - 1);
         zt[q] = *reinterpret_cast<const f32x4*>(zTb + (long)cs * LO + (r0 + r) * (P / 4) + c0 / 4 + 4 * p4);
       }
 #pragma unroll
-      for (int q = 0; q < CO * TC * 2 / NT; ++q) {
+      for (int q = 0; q < NZF; ++q) {
         const int i = t + NT * q, g4 = i & 1, cc = i >> 1, cs = cc >> 6, c = cc & (TC - 1);
         zf[q] = *reinterpret_cast<const f32x4*>(zFb + (long)cs * LO + (c0 + c) * (P / 4) + r0 / 4 + 4 * g4);
       }
-      float hl = 0.f, ht = 0.f, et = 0.f, ef[2] = {0.f, 0.f};
+      float h = 0.f, ex = 0.f;
       if (t < CI * TR) {  // the element before each tile row: column c0 - 1, or the end of the row above
         const int ci = t >> 5, r = r0 + (t & (TR - 1));
         const long g = c0 > 0 ? ((long)ci * P + r) * P + c0 - 1 : ((long)ci * P + r - 1) * P + P - 1;
-        if (c0 > 0 || r > 0) hl = rb[g];
-      }
-      {  // the element above each tile column: row r0 - 1, or the end of the column before
-        const int ci = t >> 6, c = c0 + (t & (TC - 1));
+        if (c0 > 0 || r > 0) h = rb[g];
+      } else if (t >= 256) {  // the element above each tile column: row r0 - 1, or the end of the column before
+        const int u = t - 256, ci = u >> 6, c = c0 + (u & (TC - 1));
         const long g = r0 > 0 ? ((long)ci * P + r0 - 1) * P + c : ((long)ci * P + P - 1) * P + c - 1;
-        if (r0 > 0 || c > 0) ht = rb[g];
+        if (r0 > 0 || c > 0) h = rb[g];
       }
-      {  // netT: the position after each tile row's sixteen (its tap 0 is the row's last element of the tile)
+      {  // netF: the position below each tile column's eight (its tap 0 is the column's last element of the tile)
+        const int cs = t >> 6, c = t & (TC - 1);
+        const int j = (c0 + c) * (P / 4) + r0 / 4 + TR / 4;
+        if (j < LO) ex = zFb[(long)cs * LO + j];
+      }
+      float et = 0.f;
+      if (t < CO * TR) {  // netT: the position after each tile row's sixteen
         const int cs = t >> 5, r = t & (TR - 1);
         const int j = (r0 + r) * (P / 4) + c0 / 4 + TC / 4;
         if (j < LO) et = zTb[(long)cs * LO + j];
       }
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {  // netF: the position below each tile column's eight
-        const int i = t + NT * q, cs = i >> 6, c = i & (TC - 1);
-        const int j = (c0 + c) * (P / 4) + r0 / 4 + TR / 4;
-        if (j < LO) ef[q] = zFb[(long)cs * LO + j];
-      }
-#pragma unroll
-      for (int q = 0; q < CI * TR * (TC / 4) / NT; ++q) {
-        const int i = t + NT * q, rr = i >> 4, ci = rr >> 5, r = rr & (TR - 1);
-        float* d = &res[ci * RCH + (1 + r) * RP + 1 + 4 * c4];
+      for (int q = 0; q < NV; ++q) {
+        float* d = &res[q * RCH + (1 + rq) * RP + 1 + 4 * c4];
         d[0] = v[q][0]; d[1] = v[q][1]; d[2] = v[q][2]; d[3] = v[q][3];
       }
 #pragma unroll
-      for (int q = 0; q < CO * TR * 4 / NT; ++q) {
+      for (int q = 0; q < NZT; ++q) {
         const int i = t + NT * q, p4 = i & 3, rr = i >> 2, cs = rr >> 5, r = rr & (TR - 1);
         float* d = &zT[cs * ZTP + r * ZTR + 4 * p4];
         d[0] = zt[q][0]; d[1] = zt[q][1]; d[2] = zt[q][2]; d[3] = zt[q][3];
       }
 #pragma unroll
-      for (int q = 0; q < CO * TC * 2 / NT; ++q) {
+      for (int q = 0; q < NZF; ++q) {
         const int i = t + NT * q, g4 = i & 1, cc = i >> 1, cs = cc >> 6, c = cc & (TC - 1);
         float* d = &zF[cs * ZFP + 4 * g4 * TC + c];
         d[0] = zf[q][0]; d[TC] = zf[q][1]; d[2 * TC] = zf[q][2]; d[3 * TC] = zf[q][3];
       }
-      if (t < CI * TR) res[(t >> 5) * RCH + (1 + (t & (TR - 1))) * RP] = hl;
-      res[(t >> 6) * RCH + 1 + (t & (TC - 1))] = ht;
-      zT[(t >> 5) * ZTP + (t & (TR - 1)) * ZTR + TC / 4] = et;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int i = t + NT * q;
-        zF[(i >> 6) * ZFP + (TR / 4) * TC + (i & (TC - 1))] = ef[q];
-      }
+      if (t < CI * TR) res[(t >> 5) * RCH + (1 + (t & (TR - 1))) * RP] = h;
+      else if (t >= 256) res[((t - 256) >> 6) * RCH + 1 + (t & (TC - 1))] = h;
+      zF[(t >> 6) * ZFP + (TR / 4) * TC + (t & (TC - 1))] = ex;
+      if (t < CO * TR) zT[(t >> 5) * ZTP + (t & (TR - 1)) * ZTR + TC / 4] = et;
     }
     __syncthreads();
-    // the reconstruction terms' share of this thread's eight output quads: in flight while the matrix cores work
-    f32x4 gp[CI * TR * (TC / 4) / NT];
+    // the reconstruction terms' share of this thread's four output quads: in flight while the matrix cores work
+    f32x4 gp[CI];
 #pragma unroll
-    for (int q = 0; q < CI * TR * (TC / 4) / NT; ++q) {
-      const int ci = q >> 1, r = rq + 16 * (q & 1);
-      gp[q] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.gx1p + (long)b * CI * L + ((long)ci * P + r0 + r) * P + c0 + 4 * c4));
-    }
-    // ---- weight gradients: four positions per matrix instruction, every fourth group per wavefront
+    for (int ci = 0; ci < CI; ++ci)
+      gp[ci] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.gx1p + (long)b * CI * L + ((long)ci * P + r0 + rq) * P + c0 + 4 * c4));
+    // ---- weight gradients: four positions per matrix instruction, every eighth group per wavefront
     {
       const int cb = lm >> 2, tt = lm & 3;
 #pragma unroll 4
-      for (int s = wave; s < TR * (TC / 4) / 4; s += 4) {  // netT: positions (r, p), four consecutive p
+      for (int s = wave; s < TR * (TC / 4) / 4; s += NT / 64) {  // netT: positions (r, p), four consecutive p
         const int q = 4 * s + lk, r = q >> 4, p = q & 15;
         const float av = lm < CO ? zT[lm * ZTP + r * ZTR + p] : 0.f;
         accT = __builtin_amdgcn_mfma_f32_16x16x4f32(av, res[cb * RCH + (1 + r) * RP + 4 * p + tt], accT, 0, 0, 0);
       }
 #pragma unroll 4
-      for (int s = wave; s < TC * (TR / 4) / 4; s += 4) {  // netF: positions (c, g), four consecutive c
+      for (int s = wave; s < TC * (TR / 4) / 4; s += NT / 64) {  // netF: positions (c, g), four consecutive c
         const int q = 4 * s + lk, g = q >> 6, c = q & (TC - 1);
         const float av = lm < CO ? zF[lm * ZFP + g * TC + c] : 0.f;
         accF = __builtin_amdgcn_mfma_f32_16x16x4f32(av, res[cb * RCH + (4 * g + tt) * RP + 1 + c], accF, 0, 0, 0);
       }
     }
     {  // bias gradients
-      const int net = t >> 7, cs = (t >> 4) & 7, part = t & 15;
+      const int net = t >> 8, cs = (t >> 5) & 7, part = t & 31;
       float sum = 0.f;
       if (net == 0) {
 #pragma unroll
-        for (int i = 0; i < 2 * (TC / 4); ++i) sum += zT[cs * ZTP + (2 * part + (i >> 4)) * ZTR + (i & 15)];
+        for (int i = 0; i < TC / 4; ++i) sum += zT[cs * ZTP + part * ZTR + i];
       } else {
 #pragma unroll
-        for (int i = 0; i < 4 * (TR / 4); ++i) sum += zF[cs * ZFP + (i >> 2) * TC + 4 * part + (i & 3)];
+        for (int i = 0; i < 2 * (TR / 4); ++i) sum += zF[cs * ZFP + (i >> 1) * TC + 2 * part + (i & 1)];
       }
       bacc += sum;
     }
     // ---- data gradients and the combination: element (r, c) is tap (c + 1) % 4 of netT's position (r, (c + 1) / 4) and
     // tap (r + 1) % 4 of netF's position (c, (r + 1) / 4)
     float* gb = a.gx1 + (long)b * CI * L;
+    const int g = (rq + 1) >> 2;
 #pragma unroll
-    for (int q = 0; q < CI * TR * (TC / 4) / NT; ++q) {
-      const int ci = q >> 1, r = rq + 16 * (q & 1), g = (r + 1) >> 2;
+    for (int ci = 0; ci < CI; ++ci) {
       f32x4 dT = {0.f, 0.f, 0.f, 0.f}, dF = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int cs = 0; cs < CO; ++cs) {
-        const float z0 = zT[cs * ZTP + r * ZTR + c4], z1 = zT[cs * ZTP + r * ZTR + c4 + 1];
+        const float z0 = zT[cs * ZTP + rq * ZTR + c4], z1 = zT[cs * ZTP + rq * ZTR + c4 + 1];
         const f32x4 w4 = uload4(a.w[0] + (cs * CI + ci) * 4);
         dT[0] = fmaf(z0, w4[1], dT[0]); dT[1] = fmaf(z0, w4[2], dT[1]); dT[2] = fmaf(z0, w4[3], dT[2]);
         dT[3] = fmaf(z1, w4[0], dT[3]);
         const f32x4 zf4 = *reinterpret_cast<const f32x4*>(&zF[cs * ZFP + g * TC + 4 * c4]);
+        const float wfv = wfl[(cs * CI + ci) * 4 + tap];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) dF[e] = fmaf(zf4[e], wf[ci][cs], dF[e]);
+        for (int e = 0; e < 4; ++e) dF[e] = fmaf(zf4[e], wfv, dF[e]);
       }
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = gp[q][e] - 0.5f * (dT[e] + dF[e]);
-      *reinterpret_cast<f32x4*>(gb + ((long)ci * P + r0 + r) * P + c0 + 4 * c4) = o;
+      for (int e = 0; e < 4; ++e) o[e] = gp[ci][e] - 0.5f * (dT[e] + dF[e]);
+      *reinterpret_cast<f32x4*>(gb + ((long)ci * P + r0 + rq) * P + c0 + 4 * c4) = o;
     }
   }
-  // ---- the four wavefronts' weight-gradient images -> one slab (fixed order), bias partials
+  // ---- the eight wavefronts' weight-gradient images -> one slab (fixed order), bias partials
   __syncthreads();
   float* comb = zT;  // [wave][net][cs][16]
   if (lk < 2) {
@@ -213,17 +199,18 @@ __global__ __launch_bounds__(NT) void conv0_bwd_tile_kernel(const Conv0BwdTileAr
       comb[((wave * 2 + 1) * CO + 4 * lk + r) * 16 + lm] = accF[r];
     }
   }
-  // sixteen lanes share one (network, channel): butterfly inside the group of 16
+  // thirty-two lanes share one (network, channel): butterfly inside the half wavefront
 #pragma unroll
-  for (int off = 8; off > 0; off >>= 1) bacc += __shfl_xor(bacc, off, 16);
+  for (int off = 16; off > 0; off >>= 1) bacc += __shfl_xor(bacc, off, 32);
   __syncthreads();
   float* out = a.partial + (size_t)blockIdx.x * SLAB;
-  {
-    const int net = t >> 7, i = t & 127;  // 2 x 128 weights: one per thread
-    const float* c0p = comb + net * CO * 16 + i;
-    out[net * (NW + 16) + i] = (c0p[0] + c0p[2 * CO * 16]) + (c0p[4 * CO * 16] + c0p[6 * CO * 16]);
+  if (t < 2 * NW) {
+    const int net = t >> 7, i = t & 127;  // 2 x 128 weights
+    const float* cp = comb + net * NW + i;
+    constexpr int WS = 2 * NW;            // one wavefront's image
+    out[net * (NW + 16) + i] = ((cp[0] + cp[WS]) + (cp[2 * WS] + cp[3 * WS])) + ((cp[4 * WS] + cp[5 * WS]) + (cp[6 * WS] + cp[7 * WS]));
   }
-  if ((t & 15) == 0) out[(t >> 7) * (NW + 16) + NW + ((t >> 4) & 7)] = bacc;
+  if ((t & 31) == 0) out[(t >> 8) * (NW + 16) + NW + ((t >> 5) & 7)] = bacc;
   if (t < 16) out[(t >> 3) * (NW + 16) + NW + 8 + (t & 7)] = 0.f;
 }
 

@@ -110,6 +110,7 @@ struct lshm_engine {
   hipStream_t lstream = nullptr;  // latent-space terms (K-harmonic, similarity, augmentation, RICA): beside everything
   std::vector<hipEvent_t> events;
   mutable size_t next_event;
+  mutable bool col_written = true;  // false: the last closure forward kept only the row image of the residual (conv0_bwd_tile reads nothing else)
   hipEvent_t latent_event;  // set while the latent-space terms of the current forward are in flight
   bool sim_started = false;  // cluster_similarity of the current forward already launched (side stream)
   bool recon_ready;         // the workspace already holds the reconstruction terms of the next closure
@@ -490,13 +491,20 @@ static void three_forward_steps(const lshm_engine* e, const float* prm, const fl
     if (resid_conv0_keep_step) {
       *resid_conv0_keep_step = nullptr;
       if (*resid_conv0_step && !sched(LSHM_SCHED_NO_RESID_CONV0_KEEP))
+      {
+        // the column-vectorised residual is only read by conv0's weight gradient: not written when that is the tile kernel
+        const bool row_only = !e->bf && (e->pair_mode || !e->side_ok) && aT.enc[0].out_bs == aF.enc[0].out_bs &&
+                              conv0_bwd_tile_supported(c.C, c.P, aT.enc[0].Cin, aT.enc[0].Cout, aT.enc[0].Win, aT.enc[0].in_bs);
         *resid_conv0_keep_step = [=](float* ws, hipStream_t st) -> int {
+          e->col_written = !row_only;
           return resid_conv0(x, ws + e->ae[0].out, prm + aT.cw[0], prm + aT.cb[0], ws + aT.act[0], prm + aF.cw[0], prm + aF.cb[0],
-                             ws + aF.act[0], aT.enc[0].out_bs, c.B, st, e->bf, ws + e->o_row, ws + e->o_col);
+                             ws + aF.act[0], aT.enc[0].out_bs, c.B, st, e->bf, ws + e->o_row, row_only ? nullptr : ws + e->o_col);
         };
+      }
     }
   }
   steps.push_back([=](float* ws, hipStream_t st) -> int {
+    e->col_written = true;
     return residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st, e->bf);
   });
   const int i12[2] = {1, 2};
@@ -816,6 +824,11 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       fused_tail = true;
       break;
     }
+    if (i == 0 && a0.ndim == 1 && !e->col_written) {
+      set_last_error("engine: this workspace's forward kept only the row image of the residual (it ran under a schedule word with "
+                     "the one-pass backward of conv0); run the forward again under the current word");
+      return LSHM_ERR_UNSUPPORTED;
+    }
     ConvWgradIO wg[2];
     ConvDgradIO dg[2];
     float* dx[2];
@@ -930,6 +943,7 @@ static int three_forward(lshm_engine* e, const float* prm, const float* x, const
     const float* in0[1] = {x};
     if ((rc = ae_forward(e, 1, i0, prm, in0, ws, 0, st))) return rc;
   }
+  e->col_written = true;
   if ((rc = residual_split(x, ws + e->ae[0].out, ws + e->o_row, ws + e->o_col, c.B * c.C, c.P, st, e->bf))) return rc;
   const int i12[2] = {1, 2};
   const float* in12[2] = {ws + e->o_row, ws + e->o_col};

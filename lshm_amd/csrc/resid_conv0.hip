@@ -7,10 +7,11 @@
 // 267 MB fetched for 134 MB of input), every store is a 64-byte run, and the four tiles of an image are consecutive
 // workgroups of ONE XCD (block index -> (image, tile) below), so the halves of a 128-byte line meet in that XCD's L2 and the
 // one-element halos (the column left of the tile for netT, the row above it for netF) are L2 hits.
-//   KEEP = false: the forward whose activations nobody reads afterwards (the no-grad forward that closes an ADMM
+//   KEEP = 0: the forward whose activations nobody reads afterwards (the no-grad forward that closes an ADMM
 //     iteration, :187-196) -- neither vectorisation is written.
-//   KEEP = true: the closure forward -- the two vectorisations the backward's weight gradients read are written from the
+//   KEEP = 2: the closure forward -- the two vectorisations the backward's weight gradients read are written from the
 //     same tile (`residual_split` + `conv1d_stream<4,8>` read x, x1 and then both residual images again: 495 MB -> 330 MB).
+//   KEEP = 1: ... only the row image: conv0's backward as one tile kernel (conv0_bwd_tile.hip) reads nothing else.
 // The arithmetic is that of residual_split_kernel followed by conv1d_stream_kernel<4, 8, true>, operation for operation
 // (same products in the same fused-multiply-add order): results are bitwise the same.
 #include <stdlib.h>
@@ -68,7 +69,7 @@ __device__ __forceinline__ float resid(float xa, float xb) {
   if constexpr (sizeof(T) == 2) return (float)(T)v;
   return v;
 }
-template <class T, bool KEEP>
+template <class T, int KEEP>  // 0: nothing kept, 1: the row image, 2: the row image and its per-plane transpose
 __global__ __launch_bounds__(NT) void resid_conv0_kernel(const ResidConv0Args a) {
   const T* __restrict__ x1 = reinterpret_cast<const T*>(a.x1);
   __shared__ float res[CI * TS * PITCH];  // the residual of the tile, res[(ci * 64 + r) * 65 + c]
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(NT) void resid_conv0_kernel(const ResidConv0Args a)
     f32x4 v;
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = resid<T>(xa[k], xc[k]);
-    if constexpr (KEEP) Elem<T>::st4(orow + g, v);
+    if constexpr (KEEP > 0) Elem<T>::st4(orow + g, v);
     float* d = &res[rr * PITCH + 4 * c4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) d[k] = v[k];
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(NT) void resid_conv0_kernel(const ResidConv0Args a)
       conv0_point(xm, v, a.w[0], a.bias[0], yT + (long)(r0 + r) * (P / 4));
     }
   }
-  if constexpr (KEEP) {  // the column-vectorised residual: plane (ci) transposed, 64-element runs along the tile's rows
+  if constexpr (KEEP == 2) {  // the column-vectorised residual: plane (ci) transposed, 64-element runs along the tile's rows
     T* ocol = reinterpret_cast<T*>(a.out_col) + (long)b * CI * L;
 #pragma unroll 4
     for (int i = t; i < CI * TS * (TS / 4); i += NT) {
@@ -163,7 +164,7 @@ bool resid_conv0_supported(int C, int Pp, int Cin, int Cout, int L1d) {
   return !sched(LSHM_SCHED_NO_RESID_CONV0) && C == CI && Pp == P && Cin == CI && Cout == CO && L1d == L;
 }
 
-template <class T, bool KEEP>
+template <class T, int KEEP>
 static int launch_resid_conv0(const ResidConv0Args& a, hipStream_t st) {
   int rc = kernel_budget_ok(reinterpret_cast<const void*>(&resid_conv0_kernel<T, KEEP>), NT, 0, "resid_conv0");
   if (rc) return rc;
@@ -172,10 +173,11 @@ static int launch_resid_conv0(const ResidConv0Args& a, hipStream_t st) {
   return check_launch("resid_conv0");
 }
 
-// out_row / out_col: null (the no-grad form) or both given (the closure form: the residual images are kept)
+// out_row / out_col: both null (the no-grad form), both given (the closure form: the residual images are kept), or out_row
+// alone (the closure form when the backward of conv0 reads netF's windows from the row image: conv0_bwd_tile.hip)
 int resid_conv0(const float* x, const float* x1, const float* wT, const float* bT, float* yT, const float* wF, const float* bF,
                 float* yF, long y_bs, int B, hipStream_t st, int bf, float* out_row, float* out_col) {
-  if (!x || !x1 || !wT || !bT || !yT || !wF || !bF || !yF || B < 1 || !out_row != !out_col ||
+  if (!x || !x1 || !wT || !bT || !yT || !wF || !bF || !yF || B < 1 || (out_col && !out_row) ||
       ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(x1) | reinterpret_cast<uintptr_t>(wT) | reinterpret_cast<uintptr_t>(wF) |
         reinterpret_cast<uintptr_t>(out_row) | reinterpret_cast<uintptr_t>(out_col)) & 15)) {
     set_last_error("resid_conv0: null or unaligned pointer");
@@ -187,8 +189,9 @@ int resid_conv0(const float* x, const float* x1, const float* wT, const float* b
   a.w[1] = wF; a.bias[1] = bF; a.y[1] = yF;
   a.out_row = out_row; a.out_col = out_col;
   a.y_bs = y_bs; a.B = B;
-  if (out_row) return bf ? launch_resid_conv0<bf16, true>(a, st) : launch_resid_conv0<float, true>(a, st);
-  return bf ? launch_resid_conv0<bf16, false>(a, st) : launch_resid_conv0<float, false>(a, st);
+  if (out_col) return bf ? launch_resid_conv0<bf16, 2>(a, st) : launch_resid_conv0<float, 2>(a, st);
+  if (out_row) return bf ? launch_resid_conv0<bf16, 1>(a, st) : launch_resid_conv0<float, 1>(a, st);
+  return bf ? launch_resid_conv0<bf16, 0>(a, st) : launch_resid_conv0<float, 0>(a, st);
 }
 
 }  // namespace lshm
