@@ -338,6 +338,23 @@ int lshm_recon_losses_from_a(const float* x, const float* x1, const float* aT, c
                              const float* bT, const float* wF, const float* bF, const float* y1, const float* y2,
                              const float* y3, float rho, int planes, int P, int C, double* sums7, float* gx1_partial,
                              float* gx2, float* gx3c, float* workspace, lshm_stream_t stream);
+/* The pass of the paired schedule, with the backward of the last layer of netT / netF (ConvTranspose1d(8, 4, 4, stride=4),
+ * src/lofar_models.py:142) inside it: y_k += rho r_k (src/kharmonic_lofar.py:200-202), then with the new multipliers the seven
+ * sums and gx1_partial of lshm_recon_losses_from_a (bitwise), and instead of the two other gradient images
+ *   daT, daF (B,8,4096) = gradients w.r.t. the layer's inputs aT, aF times ELU'(input);  dwT, dbT, dwF, dbF = the layers'
+ *   weight / bias gradients (overwritten)
+ * -- what lshm_conv_bwd_fused(kind 3, elu_grad 1) on gx2 / gx3c gives, to fp32 summation order.  P = 128, C = 4, fp32. */
+size_t lshm_recon_bwd5_workspace_floats(int B);
+int lshm_recon_bwd5(const float* x, const float* x1, const float* aT, const float* aF, const float* wT, const float* bT,
+                    const float* wF, const float* bF, float* y1, float* y2, float* y3, float rho, int B, double* sums7,
+                    float* gx1_partial, float* daT, float* daF, float* dwT, float* dbT, float* dwF, float* dbF,
+                    float* workspace, size_t workspace_floats, lshm_stream_t stream);
+/* The backward of that layer ALONE, from the gradient images gx2 / gx3c (B,4,128,128; gx3c per plane transposed) another pass
+ * wrote: the tiles, workgroups and summation order of lshm_recon_bwd5, so that a schedule without the fused pass gets the same
+ * bits (what the engine runs for this layer whenever the pass has not done it). */
+int lshm_tconv5_pair_bwd(const float* gx2, const float* gx3c, const float* aT, const float* aF, const float* wT, const float* wF,
+                         float* daT, float* daF, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* workspace,
+                         size_t workspace_floats, lshm_stream_t stream);
 int lshm_combine_dx1(const float* gx1_partial, const float* gT, const float* gFc, float* gx1,
                      int planes, int P, lshm_stream_t stream);
 /* y_k += rho * r_k                                                src/kharmonic_lofar.py:200-202 */
@@ -476,6 +493,7 @@ typedef struct lshm_step_config {
 #define LSHM_SCHED_NO_KHM_MFMA (1u << 20)     /* K-harmonic pass for 16 < K <= 64 on the row-split kernel instead of the matrix cores */
 #define LSHM_SCHED_NO_EARLY_LATENT (1u << 21) /* latent-space terms at the head of the backward instead of beside the paired forwards */
 #define LSHM_SCHED_NO_CONV0_BWD_TILE (1u << 23) /* backward of 1-D conv0 (netT, netF) and the combination into the 2-D autoencoder's output gradient as two launches (lshm_conv0_bwd_tile) */
+#define LSHM_SCHED_NO_RECON_BWD5 (1u << 24)     /* the reconstruction pass does not include the backward of netT / netF's last layer (lshm_recon_bwd5) */
 #define LSHM_SCHED_NO_RESID_CONV0_KEEP (1u << 22) /* closure forward: residual split + conv0 of netT / netF as two launches (lshm_resid_conv0_keep) */
 
 int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out);

@@ -45,7 +45,7 @@ SCHEDULE_BITS = {"no_deep2d": 1 << 0, "no_deep2d_bwd": 1 << 1, "no_wgrad_batch":
                  "no_bwd_lds_8_4": 1 << 12, "no_bwd_lds2d": 1 << 13, "no_bwd_fused2d": 1 << 14, "no_wgrad_mid": 1 << 15,
                  "no_stop_events": 1 << 16, "wgrad_inline": 1 << 17, "fork": 1 << 18, "phase_events": 1 << 19,
                  "no_khm_mfma": 1 << 20, "no_early_latent": 1 << 21, "no_resid_conv0_keep": 1 << 22,
-                 "no_conv0_bwd_tile": 1 << 23}
+                 "no_conv0_bwd_tile": 1 << 23, "no_recon_bwd5": 1 << 24}
 SCHED_NO_DEEP2D, SCHED_NO_DEEP2D_BWD = SCHEDULE_BITS["no_deep2d"], SCHEDULE_BITS["no_deep2d_bwd"]
 STEP_RECON_READY = 1
 NEXT_CONCURRENT_FORWARD = 1
@@ -111,6 +111,9 @@ _SIGNATURES = {
                                      c_int, c_void_p]),
     "lshm_residual_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lshm_resid_conv0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lshm_recon_bwd5_workspace_floats": (c_size_t, [c_int]),
+    "lshm_recon_bwd5": (c_int, [c_void_p] * 11 + [C.c_float, c_int] + [c_void_p] * 9 + [c_size_t, c_void_p]),
+    "lshm_tconv5_pair_bwd": (c_int, [c_void_p] * 12 + [c_int, c_void_p, c_size_t, c_void_p]),
     "lshm_conv0_bwd_tile_workspace_floats": (c_size_t, []),
     "lshm_conv0_bwd_tile": (c_int, [c_void_p] * 11 + [c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lshm_resid_conv0_keep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

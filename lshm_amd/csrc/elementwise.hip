@@ -356,23 +356,13 @@ __global__ __launch_bounds__(256) void recon_kernel(
       a2 = Elem<T>::ld(x2 + o);
     }
     const float a3 = tile[threadIdx.x][threadIdx.y + 8 * i];
-    const float r1 = xv - a1, h = 0.5f * r1, r2 = h - a2, r3 = h - a3;
-    const float e = a1 + a2 + a3 - xv;
-    float m1 = __builtin_nontemporal_load(y1 + o), m2 = __builtin_nontemporal_load(y2 + o),
-          m3 = __builtin_nontemporal_load(y3 + o);
-    if (UPD) {
-      m1 = fmaf(rho, r1, m1); m2 = fmaf(rho, r2, m2); m3 = fmaf(rho, r3, m3);
-      y1[o] = m1; y2[o] = m2; y3[o] = m3;
-    }
-    s[0] += e * e;
-    s[1] += m1 * r1; s[2] += r1 * r1;
-    s[3] += m2 * r2; s[4] += r2 * r2;
-    s[5] += m3 * r3; s[6] += r3 * r3;
+    const float m1 = __builtin_nontemporal_load(y1 + o), m2 = __builtin_nontemporal_load(y2 + o), m3 = __builtin_nontemporal_load(y3 + o);
+    const ReconElem q = recon_elem<UPD, GRAD>(xv, a1, a2, a3, m1, m2, m3, rho, inv_n, s);
+    if (UPD) { y1[o] = q.m1; y2[o] = q.m2; y3[o] = q.m3; }
     if (GRAD) {
-      const float t2 = m2 + rho * r2, t3 = m3 + rho * r3;
-      Elem<T>::st(gx2 + o, (2.f * e - t2) * inv_n);
-      g3[i] = (2.f * e - t3) * inv_n;
-      Elem<T>::st(gx1p + o, (2.f * e - m1 - rho * r1) * inv_n - 0.5f * (t2 + t3) * inv_n);
+      Elem<T>::st(gx2 + o, q.g2);
+      g3[i] = q.g3;
+      Elem<T>::st(gx1p + o, q.g1p);
     }
   }
   if (GRAD) {

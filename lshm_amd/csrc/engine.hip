@@ -94,6 +94,8 @@ struct lshm_engine {
   bool pack_bwd_done = false;  // this closure's backward weight copy was already made (on the latent-space stream)
   int deep_bf16 = 0;    // the deep chains stream bf16 copies of the weights (precision != LSHM_PRECISION_F32)
   int deep_variant = 0; // 0: one patch per workgroup (a forward alone), 1: two (two forwards side by side: each fills half of the CUs)
+  size_t o_recon_w5;    // weight-gradient slabs of netT / netF's last layer, left by the reconstruction pass (recon_bwd5.hip)
+  bool recon_bwd5_done = false;  // ... and whether the pass that made the workspace's reconstruction terms was that one
   size_t o_recon_part;  // per-block partial sums of the reconstruction pass (its own buffer: their seven sums may be made later, beside the backward)
   hipStream_t fstream = nullptr;  // the no-grad forward + shared reconstruction pass, beside the next closure forward
   // Two "lanes" of backward scratch: netT and netF (independent given AE1's output, identical
@@ -519,7 +521,7 @@ static void three_forward_steps(const lshm_engine* e, const float* prm, const fl
 // gradients) on a job list that two launches finish at the end; every dz therefore has its own buffer.
 // netT / netF as a pair: where their input gradients go (gx1 = gx1p - (dT + dF^T) / 2, src/kharmonic_lofar.py:142-147).  Given, the
 // backward of their first layer forms gx1 itself (conv0_bwd_tile.hip) and sets `done`; otherwise the caller combines dinput[].
-struct CombineInto { const float* gx1p; float* gx1; bool done; };
+struct CombineInto { const float* gx1p; float* gx1; bool done; bool dec5_done; };  // dec5_done: the reconstruction pass already made the last decoder layer's backward (recon_bwd5.hip)
 static int ae_backward(const lshm_engine* e, int G, const int* idx, const float* prm, float* grd,
                        const float* const* input, const float* const* dz_out, float* const* dinput, float* ws,
                        int ln, hipStream_t st, hipStream_t wgrad_stream,
@@ -607,7 +609,28 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     if ((rc = deep2d_pack(w, ws + e->o_pack2d_bwd, 1, e->deep_bf16, st))) return rc;
   }
   // ---- decoder, last layer first
-  for (int i = 5; i >= 0; --i) {
+  int dec_from = 5;
+  if (G == 2 && combine && combine->dec5_done) {
+    // the reconstruction pass left the data gradients of netT / netF's last layer in the lanes' buffers and its weight-gradient
+    // slabs in the workspace: only their closing sums are left
+    if ((rc = recon_bwd5_close(ws + e->o_recon_w5, recon_bwd5_grid(B), grd + A(0).tw[5], grd + A(0).tb[5], grd + A(1).tw[5], grd + A(1).tb[5],
+                               0, wst, &jobs))) return rc;
+    for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_gdec[5];
+    dec_from = 4;
+  } else if (G == 2 && combine && !e->bf && a0.dec[5].in_bs == A(1).dec[5].in_bs && a0.dec[5].out_bs == (long)c.C * c.P * c.P &&
+             A(1).dec[5].out_bs == a0.dec[5].out_bs && recon_bwd5_supported(c.C, c.P, a0.dec[5].Cin, a0.dec[5].Cout, a0.dec[5].Win)) {
+    // ... or, when another pass made the gradient images (sequential forwards, a captured iteration, a line search's closure):
+    // the same tiles on the same workgroups in the same order from those images -- every schedule gets the same bits
+    if ((rc = on_st([&] {
+           return tconv5_pair_bwd(dz[0], dz[1], ws + A(0).dact[4], ws + A(1).dact[4], a0.dec[5].in_bs, prm + A(0).tw[5], prm + A(1).tw[5], B,
+                                  ws + LA(0).o_gdec[5], ws + LA(1).o_gdec[5], a0.dec[5].in_bs, ws + e->o_recon_w5, recon_bwd5_workspace_floats(), st);
+         }))) return rc;
+    if ((rc = recon_bwd5_close(ws + e->o_recon_w5, recon_bwd5_grid(B), grd + A(0).tw[5], grd + A(0).tb[5], grd + A(1).tw[5], grd + A(1).tb[5],
+                               0, wst, &jobs))) return rc;  // (closed with the other sums, behind the next "dz ready")
+    for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_gdec[5];
+    dec_from = 4;
+  }
+  for (int i = dec_from; i >= 0; --i) {
     if (deepb && i == 2) break;
     if (chain_dec && i == 3) {
       // dz of tconv3 (12 channels) -> gradients w.r.t. the inputs of tconv3, tconv2, tconv1, each multiplied by ELU' of
@@ -1164,7 +1187,7 @@ static int losses_and_backward(lshm_engine* e, const float* prm, float* grd, con
     return e->comm ? comm_allreduce_segments(e->comm, nullptr, nullptr, 0, terms, 10, st) : LSHM_OK;
   // backward: netT, netF (their input gradients feed AE1 through the residual), then AE1
   hipStream_t wgs = (e->pair_mode && e->side_ok && e->side_wgrad) ? e->wstream : nullptr;
-  CombineInto combine{ws + e->o_gx1p, ws + e->o_gx1, false};
+  CombineInto combine{ws + e->o_gx1p, ws + e->o_gx1, false, recon_done && e->recon_bwd5_done};
   {
     const int i12[2] = {1, 2};
     const float* in12[2] = {ws + e->o_row, ws + e->o_col};
@@ -1458,6 +1481,7 @@ int lshm_engine_create(const lshm_step_config* cfg, lshm_engine** out) {
   e->wgrad_on_main = (cfg->tune & 0xffffu) ? (cfg->tune & 0xffffu) - 1 : 0u;  // (experimental placement word: lshm_step_config.tune, 0 = shipped)
   if (e->deep2d_bwd) e->o_pack2d_bwd = take(cur, deep2d_packed_floats());
   e->o_recon_part = take(cur, recon_partials_floats(B * cfg->C, cfg->P));
+  e->o_recon_w5 = take(cur, recon_bwd5_workspace_floats());
   e->latent_ws_floats = khm_workspace_floats(B, e->D, cfg->K);
   e->o_latent_ws = take(cur, e->latent_ws_floats);
   e->latent_event = nullptr;
@@ -1737,7 +1761,17 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
   e->mark(lshm_engine::PH_FWD_NOGRAD_END, fst);
   // concurrent: the seven sums of the pass (a 13 us launch the caller's stream would wait for) move to the latent-space
   // stream of the next closure: nothing needs them before the loss terms are assembled there
-  if (from_a)
+  // ... and, fp32 storage, the backward of that layer (both networks) inside the same pass: two of the three gradient images are
+  // never written (recon_bwd5.hip); the backward finds the layer's data gradients in the lanes' buffers
+  const bool with_bwd5 = from_a && !e->bf && e->side_wgrad && aT.dec[5].out_bs == aF.dec[5].out_bs &&
+                         recon_bwd5_supported(c.C, c.P, aT.dec[5].Cin, aT.dec[5].Cout, aT.dec[5].Win);
+  e->recon_bwd5_done = with_bwd5;
+  if (with_bwd5)
+    rc = recon_bwd5(x, fws + e->ae[0].out, fws + aT.dact[4], fws + aF.dact[4], aT.dec[5].in_bs, params + aT.tw[5], params + aT.tb[5],
+                    params + aF.tw[5], params + aF.tb[5], y1, y2, y3, c.rho, c.B, ws + e->o_gx1p, ws + e->lane[0].o_gdec[5],
+                    ws + e->lane[1].o_gdec[5], aT.dec[5].in_bs, ws + e->o_recon_part, ws + e->o_recon_w5, recon_bwd5_workspace_floats(), fst,
+                    (float)(1.0 / world));
+  else if (from_a)
     rc = multiplier_update_recon_from_a(x, fws + e->ae[0].out, fws + aT.dact[4], fws + aF.dact[4], aT.dec[5].in_bs, params + aT.tw[5],
                                         params + aT.tb[5], params + aF.tw[5], params + aF.tb[5], c.C, y1, y2, y3, c.rho, c.B * c.C,
                                         c.P, ws + e->o_gx1p, ws + e->o_gx2, ws + e->o_gx3c, ws + e->o_recon_part, fst,

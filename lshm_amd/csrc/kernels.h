@@ -229,6 +229,46 @@ int conv0_bwd_tile(const float* r, const float* dzT, const float* dzF, long z_bs
                    float* gx1, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws, size_t wsf, int accumulate,
                    hipStream_t st, GradJobs* defer);
 
+// One element of the reconstruction pass (src/kharmonic_lofar.py:150-158,200-202), shared by recon_kernel (elementwise.hip) and
+// recon_bwd5_kernel so that both give the same bits whatever the compiler would have contracted in either context: every
+// fused multiply-add is written out, nothing else is fused.
+//   r1 = x - x1, h = r1 / 2, r2 = h - x2, r3 = h - x3, e = x1 + x2 + x3 - x;  UPD: m_k += rho r_k first
+//   s += [e^2, m1 r1, r1^2, m2 r2, r2^2, m3 r3, r3^2];  g2 = (2e - m2 - rho r2) / n, g3 likewise,
+//   g1p = (2e - m1 - rho r1) / n - (m2 + rho r2 + m3 + rho r3) / (2n)
+struct ReconElem { float m1, m2, m3, g1p, g2, g3; };
+template <bool UPD, bool GRAD>
+__device__ __forceinline__ ReconElem recon_elem(float xv, float a1, float a2, float a3, float m1, float m2, float m3, float rho, float inv_n,
+                                                float (&s)[7]) {
+#pragma clang fp contract(off)
+  const float r1 = xv - a1, h = 0.5f * r1, r2 = h - a2, r3 = h - a3;
+  const float e = a1 + a2 + a3 - xv;
+  if (UPD) { m1 = fmaf(rho, r1, m1); m2 = fmaf(rho, r2, m2); m3 = fmaf(rho, r3, m3); }
+  s[0] = fmaf(e, e, s[0]);
+  s[1] = fmaf(m1, r1, s[1]); s[2] = fmaf(r1, r1, s[2]);
+  s[3] = fmaf(m2, r2, s[3]); s[4] = fmaf(r2, r2, s[4]);
+  s[5] = fmaf(m3, r3, s[5]); s[6] = fmaf(r3, r3, s[6]);
+  ReconElem o{m1, m2, m3, 0.f, 0.f, 0.f};
+  if (GRAD) {
+    const float t2 = fmaf(rho, r2, m2), t3 = fmaf(rho, r3, m3), e2 = 2.f * e;
+    o.g2 = (e2 - t2) * inv_n;
+    o.g3 = (e2 - t3) * inv_n;
+    o.g1p = fmaf(-rho, r1, e2 - m1) * inv_n - (0.5f * (t2 + t3)) * inv_n;
+  }
+  return o;
+}
+
+// reconstruction pass + backward of the last layer of netT / netF (recon_bwd5.hip)
+bool recon_bwd5_supported(int C, int P, int Cin, int Cout, int Ls);
+size_t recon_bwd5_workspace_floats();
+int recon_bwd5_grid(int B);
+int recon_bwd5(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT, const float* bT,
+               const float* wF, const float* bF, float* y1, float* y2, float* y3, float rho, int B, float* gx1p, float* dT, float* dF,
+               long d_bs, float* block_partials, float* slabs, size_t slab_floats, hipStream_t st, float grad_scale);
+int tconv5_pair_bwd(const float* gx2, const float* gx3c, const float* aT, const float* aF, long a_bs, const float* wT, const float* wF,
+                    int B, float* dT, float* dF, long d_bs, float* slabs, size_t slab_floats, hipStream_t st);
+int recon_bwd5_close(const float* slabs, int grid, float* dwT, float* dbT, float* dwF, float* dbF, int accumulate, hipStream_t st,
+                     GradJobs* defer);
+
 // LDS-staged weight gradient of the mid 1-D layers (24/12 and 48/24 channels), see conv_direct.hip
 bool conv1d_wgrad_mid_supported(int Cs, int Cb, int Ls, int Lb, int pad, int bias_from, long s_bs, long big_bs,
                                 const float* small, const float* big);

@@ -465,6 +465,84 @@ def test_reconstruction_pass_from_the_last_layers_input_is_bitwise_the_two_launc
         assert torch.equal(p, q)
 
 
+@pytest.mark.parametrize("nb", [256, 3, 8])
+def test_reconstruction_pass_with_the_last_1d_layers_backward_inside(nb):
+    """lshm_recon_bwd5 (multiplier update, reconstruction terms and -- instead of two of the three gradient images -- the weight,
+    bias and data gradients of netT / netF's last layer, src/lofar_models.py:142, src/kharmonic_lofar.py:150-158,200-202) against
+    the launches it replaces: lshm_conv_fwd_pair of that layer, lshm_multiplier_update, lshm_recon_losses_fwd_bwd, then
+    lshm_conv_bwd_fused of the layer on each network.  Multipliers, the seven sums and gx1_partial bit for bit; the layer's
+    gradients to fp32 summation order; and against fp64."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(900 + nb)
+    C, P, rho = 4, 128, 0.7
+    planes = nb * C
+    x, x1 = torch.randn(nb, C, P, P, generator=g), torch.randn(nb, C, P, P, generator=g)
+    a = [TF.elu(torch.randn(nb, 8, P * P // 4, generator=g)) for _ in range(2)]
+    w = [torch.randn(8, C, 4, generator=g) * 0.3 for _ in range(2)]
+    b = [torch.randn(C, generator=g) * 0.1 for _ in range(2)]
+    ys = [torch.randn(nb, C, P, P, generator=g) * 0.1 for _ in range(3)]
+    dv = lambda t: t.to(DEV).contiguous()
+    xd, x1d, ad, wd, bd = dv(x), dv(x1), [dv(t) for t in a], [dv(t) for t in w], [dv(t) for t in b]
+    st, Pt = L.stream(), L.ptr
+    # ---- the replaced launches
+    y_ref = [dv(t) for t in ys]
+    nws = max(lib.lshm_recon_workspace_floats(planes, P), lib.lshm_conv_workspace_floats(3, nb, 8, C, 1, P * P // 4))
+    ws = torch.empty(nws, device=DEV)
+    x2, x3c = torch.empty(nb, C, P * P, device=DEV), torch.empty(nb, C, P * P, device=DEV)
+    L.check(lib.lshm_conv_fwd_pair(3, Pt(ad[0]), Pt(wd[0]), Pt(bd[0]), Pt(x2), Pt(ad[1]), Pt(wd[1]), Pt(bd[1]), Pt(x3c), nb, 8, C, 1,
+                                   P * P // 4, 0, 0, 0, None, 0, st), "tconv5 pair")
+    L.check(lib.lshm_multiplier_update(Pt(xd), Pt(x1d), Pt(x2), Pt(x3c), *[Pt(t) for t in y_ref], rho, planes, P, st), "multiplier update")
+    s_ref = torch.zeros(8, device=DEV, dtype=torch.float64)
+    g_ref = [torch.empty(nb, C, P * P, device=DEV) for _ in range(3)]
+    L.check(lib.lshm_recon_losses_fwd_bwd(Pt(xd), Pt(x1d), Pt(x2), Pt(x3c), *[Pt(t) for t in y_ref], rho, planes, P, Pt(s_ref),
+                                          *[Pt(t) for t in g_ref], Pt(ws), st), "recon")
+    dw_ref = [torch.empty(8, C, 4, device=DEV) for _ in range(2)]
+    db_ref = [torch.empty(C, device=DEV) for _ in range(2)]
+    da_ref = [torch.empty(nb, 8, P * P // 4, device=DEV) for _ in range(2)]
+    for k in range(2):
+        L.check(lib.lshm_conv_bwd_fused(3, Pt(ad[k]), Pt(g_ref[1 + k]), Pt(wd[k]), Pt(dw_ref[k]), Pt(db_ref[k]), Pt(da_ref[k]), 1, nb, 8, C, 1,
+                                        P * P // 4, Pt(ws), nws, st), "tconv5 backward")
+    # ---- the one pass
+    y_new = [dv(t) for t in ys]
+    nws5 = lib.lshm_recon_bwd5_workspace_floats(nb)
+    ws5 = torch.empty(nws5, device=DEV)
+    s_new = torch.zeros(8, device=DEV, dtype=torch.float64)
+    gx1p = torch.full((nb, C, P * P), float("nan"), device=DEV)
+    da = [torch.full((nb, 8, P * P // 4), float("nan"), device=DEV) for _ in range(2)]
+    dw = [torch.full((8, C, 4), float("nan"), device=DEV) for _ in range(2)]
+    db = [torch.full((C,), float("nan"), device=DEV) for _ in range(2)]
+    L.check(lib.lshm_recon_bwd5(Pt(xd), Pt(x1d), Pt(ad[0]), Pt(ad[1]), Pt(wd[0]), Pt(bd[0]), Pt(wd[1]), Pt(bd[1]), *[Pt(t) for t in y_new], rho,
+                                nb, Pt(s_new), Pt(gx1p), Pt(da[0]), Pt(da[1]), Pt(dw[0]), Pt(db[0]), Pt(dw[1]), Pt(db[1]), Pt(ws5), nws5, st),
+            "recon_bwd5")
+    torch.cuda.synchronize()
+    for p, q in zip(y_ref, y_new):
+        assert torch.equal(p, q)
+    assert torch.equal(s_ref[:7], s_new[:7])
+    assert torch.equal(g_ref[0], gx1p)
+    for k in range(2):
+        assert torch.isfinite(da[k]).all()
+        assert rel_err(da[k], da_ref[k]) < 2e-6 and rel_err(dw[k], dw_ref[k]) < 2e-6 and rel_err(db[k], db_ref[k]) < 2e-6
+    # ---- the layer's backward alone from the gradient images (what a schedule without the fused pass runs): the same bits
+    da2 = [torch.full((nb, 8, P * P // 4), float("nan"), device=DEV) for _ in range(2)]
+    dw2 = [torch.full((8, C, 4), float("nan"), device=DEV) for _ in range(2)]
+    db2 = [torch.full((C,), float("nan"), device=DEV) for _ in range(2)]
+    L.check(lib.lshm_tconv5_pair_bwd(Pt(g_ref[1]), Pt(g_ref[2]), Pt(ad[0]), Pt(ad[1]), Pt(wd[0]), Pt(wd[1]), Pt(da2[0]), Pt(da2[1]), Pt(dw2[0]),
+                                     Pt(db2[0]), Pt(dw2[1]), Pt(db2[1]), nb, Pt(ws5), nws5, st), "tconv5_pair_bwd")
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(da[k], da2[k]) and torch.equal(dw[k], dw2[k]) and torch.equal(db[k], db2[k])
+    # ---- fp64 (the layer's backward from the reference pass's gradient images)
+    for k in range(2):
+        av = a[k].double().requires_grad_(True)
+        wr = w[k].double().requires_grad_(True)
+        br = b[k].double().requires_grad_(True)
+        TF.conv_transpose1d(av, wr, br, stride=4).backward(g_ref[1 + k].cpu().double())
+        assert rel_err(dw[k], wr.grad) < 1e-4 and rel_err(db[k], br.grad) < 1e-4
+        eg = torch.where(a[k].double() > 0, torch.ones_like(av), a[k].double() + 1.0)
+        assert rel_err(da[k], (av.grad * eg)) < 1e-5
+
+
 def _deep2d_problem(nb, seed):
     """Random weights (torch layouts) and inputs of the deep section of AutoEncoderCNN2(latent_dim=224, rica=True)."""
     g = torch.Generator().manual_seed(seed)
