@@ -795,8 +795,9 @@ def main():
                       "schedule": ("no-grad forward of iteration k and closure forward of iteration k+1 side by side on two streams "
                                    "(TrainConfig.overlap_forwards); common subexpressions of the two are computed once: the closure "
                                    "forward does not run the last layer of netT / netF (nothing reads its copy of their reconstructions) "
-                                   "and takes its seven reconstruction terms and three gradient images from the pass that follows the "
-                                   "no-grad forward (TrainConfig.share_recon_pass) -- bit for bit the trajectory of the schedule that "
+                                   "and takes its seven reconstruction terms and their gradients from the pass that follows the "
+                                   "no-grad forward (TrainConfig.share_recon_pass; the pass also runs the backward of netT / netF's last "
+                                   "layer, so two of the three gradient images stay on chip) -- bit for bit the trajectory of the schedule that "
                                    "runs both (tests/test_gpu_step.py::test_overlapped_forwards_are_bitwise_the_same_trajectory, "
                                    "::test_shared_reconstruction_pass_is_bitwise_the_same_trajectory); literal_upstream_order_mode "
                                    "runs everything") if cfg.overlap_forwards and not use_graph else
