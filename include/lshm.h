@@ -320,7 +320,8 @@ int lshm_resid_conv0_keep(const float* x, const float* x1, const float* wT, cons
 size_t lshm_conv0_bwd_tile_workspace_floats(void);
 int lshm_conv0_bwd_tile(const float* resid_row, const float* dzT, const float* dzF, const float* wT, const float* wF,
                         const float* gx1p, float* gx1, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws,
-                        size_t ws_floats, int accumulate, lshm_stream_t stream);
+                        size_t ws_floats, int accumulate, int storage_bf16, lshm_stream_t stream);
+/* (storage_bf16 != 0: resid_row, dzT, dzF, gx1p and gx1 are bf16 tensors -- lshm_step_config.precision 2) */
 size_t lshm_recon_workspace_floats(int planes, int P);
 /* sums7 = [sum e^2, y1.r1, sum r1^2, y2.r2, sum r2^2, y3.r3, sum r3^2]; gradients scaled by 1/n;
  * x3c / gx3c are in the column-vectorised (per-plane transposed) layout of the third AE.
@@ -348,13 +349,15 @@ size_t lshm_recon_bwd5_workspace_floats(int B);
 int lshm_recon_bwd5(const float* x, const float* x1, const float* aT, const float* aF, const float* wT, const float* bT,
                     const float* wF, const float* bF, float* y1, float* y2, float* y3, float rho, int B, double* sums7,
                     float* gx1_partial, float* daT, float* daF, float* dwT, float* dbT, float* dwF, float* dbF,
-                    float* workspace, size_t workspace_floats, lshm_stream_t stream);
+                    float* workspace, size_t workspace_floats, int storage_bf16, lshm_stream_t stream);
+/* (storage_bf16 != 0: x1, aT, aF, gx1_partial, daT, daF are bf16 tensors; the reconstructions and the two gradient images are
+ *  rounded to bf16 where the separate launches stored them) */
 /* The backward of that layer ALONE, from the gradient images gx2 / gx3c (B,4,128,128; gx3c per plane transposed) another pass
  * wrote: the tiles, workgroups and summation order of lshm_recon_bwd5, so that a schedule without the fused pass gets the same
  * bits (what the engine runs for this layer whenever the pass has not done it). */
 int lshm_tconv5_pair_bwd(const float* gx2, const float* gx3c, const float* aT, const float* aF, const float* wT, const float* wF,
                          float* daT, float* daF, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* workspace,
-                         size_t workspace_floats, lshm_stream_t stream);
+                         size_t workspace_floats, int storage_bf16, lshm_stream_t stream);
 int lshm_combine_dx1(const float* gx1_partial, const float* gT, const float* gFc, float* gx1,
                      int planes, int P, lshm_stream_t stream);
 /* y_k += rho * r_k                                                src/kharmonic_lofar.py:200-202 */

@@ -112,10 +112,10 @@ _SIGNATURES = {
     "lshm_residual_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "lshm_resid_conv0": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lshm_recon_bwd5_workspace_floats": (c_size_t, [c_int]),
-    "lshm_recon_bwd5": (c_int, [c_void_p] * 11 + [C.c_float, c_int] + [c_void_p] * 9 + [c_size_t, c_void_p]),
-    "lshm_tconv5_pair_bwd": (c_int, [c_void_p] * 12 + [c_int, c_void_p, c_size_t, c_void_p]),
+    "lshm_recon_bwd5": (c_int, [c_void_p] * 11 + [C.c_float, c_int] + [c_void_p] * 9 + [c_size_t, c_int, c_void_p]),
+    "lshm_tconv5_pair_bwd": (c_int, [c_void_p] * 12 + [c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lshm_conv0_bwd_tile_workspace_floats": (c_size_t, []),
-    "lshm_conv0_bwd_tile": (c_int, [c_void_p] * 11 + [c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "lshm_conv0_bwd_tile": (c_int, [c_void_p] * 11 + [c_int, c_void_p, c_size_t, c_int, c_int, c_void_p]),
     "lshm_resid_conv0_keep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_void_p]),
     "lshm_plane_transpose": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),

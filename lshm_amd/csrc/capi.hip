@@ -484,32 +484,32 @@ int lshm_resid_conv0_keep(const float* x, const float* x1, const float* wT, cons
 size_t lshm_recon_bwd5_workspace_floats(int B) { return recon_partials_floats(B * 4, 128) + recon_bwd5_workspace_floats(); }
 int lshm_recon_bwd5(const float* x, const float* x1, const float* aT, const float* aF, const float* wT, const float* bT, const float* wF,
                     const float* bF, float* y1, float* y2, float* y3, float rho, int B, double* sums7, float* gx1p, float* daT, float* daF,
-                    float* dwT, float* dbT, float* dwF, float* dbF, float* ws, size_t wsf, lshm_stream_t s) {
+                    float* dwT, float* dbT, float* dwF, float* dbF, float* ws, size_t wsf, int bf, lshm_stream_t s) {
   REQUIRE(x && x1 && aT && aF && wT && bT && wF && bF && y1 && y2 && y3 && sums7 && gx1p && daT && daF && dwT && dwF && ws && B > 0,
           "recon_bwd5: bad argument");
   if (wsf < lshm_recon_bwd5_workspace_floats(B)) { set_last_error("recon_bwd5: workspace too small"); return LSHM_ERR_WORKSPACE; }
   if (!recon_bwd5_supported(4, 128, 8, 4, 4096)) { set_last_error("recon_bwd5: switched off by the schedule word"); return LSHM_ERR_UNSUPPORTED; }
   float* slabs = ws + recon_partials_floats(B * 4, 128);
   int rc = recon_bwd5(x, x1, aT, aF, 8L * 4096, wT, bT, wF, bF, y1, y2, y3, rho, B, gx1p, daT, daF, 8L * 4096, ws, slabs,
-                      recon_bwd5_workspace_floats(), ST(s), 1.f);
+                      recon_bwd5_workspace_floats(), ST(s), 1.f, bf);
   if (rc) return rc;
   if ((rc = recon_sum7(ws, B * 4, 128, sums7, ST(s)))) return rc;
   return recon_bwd5_close(slabs, recon_bwd5_grid(B), dwT, dbT, dwF, dbF, 0, ST(s), nullptr);
 }
 int lshm_tconv5_pair_bwd(const float* gx2, const float* gx3c, const float* aT, const float* aF, const float* wT, const float* wF, float* daT,
-                         float* daF, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws, size_t wsf, lshm_stream_t s) {
+                         float* daF, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws, size_t wsf, int bf, lshm_stream_t s) {
   REQUIRE(gx2 && gx3c && aT && aF && wT && wF && daT && daF && dwT && dwF && ws && B > 0, "tconv5_pair_bwd: bad argument");
   if (!recon_bwd5_supported(4, 128, 8, 4, 4096)) { set_last_error("tconv5_pair_bwd: switched off by the schedule word"); return LSHM_ERR_UNSUPPORTED; }
-  int rc = tconv5_pair_bwd(gx2, gx3c, aT, aF, 8L * 4096, wT, wF, B, daT, daF, 8L * 4096, ws, wsf, ST(s));
+  int rc = tconv5_pair_bwd(gx2, gx3c, aT, aF, 8L * 4096, wT, wF, B, daT, daF, 8L * 4096, ws, wsf, ST(s), bf);
   if (rc) return rc;
   return recon_bwd5_close(ws, recon_bwd5_grid(B), dwT, dbT, dwF, dbF, 0, ST(s), nullptr);
 }
 size_t lshm_conv0_bwd_tile_workspace_floats(void) { return conv0_bwd_tile_workspace_floats(); }
 int lshm_conv0_bwd_tile(const float* r, const float* dzT, const float* dzF, const float* wT, const float* wF, const float* gx1p,
                         float* gx1, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws, size_t wsf, int accumulate,
-                        lshm_stream_t s) {
+                        int bf, lshm_stream_t s) {
   REQUIRE(r && dzT && dzF && wT && wF && gx1p && gx1 && dwT && dwF && ws && B > 0, "conv0_bwd_tile: bad argument");
-  return conv0_bwd_tile(r, dzT, dzF, 8L * 4096, wT, wF, gx1p, gx1, dwT, dbT, dwF, dbF, B, ws, wsf, accumulate, ST(s), nullptr);
+  return conv0_bwd_tile(r, dzT, dzF, 8L * 4096, wT, wF, gx1p, gx1, dwT, dbT, dwF, dbF, B, ws, wsf, accumulate, ST(s), nullptr, bf);
 }
 int lshm_plane_transpose(const float* in, float* out, int planes, int P, lshm_stream_t s) {
   REQUIRE(in && out && planes > 0, "plane_transpose: bad argument");

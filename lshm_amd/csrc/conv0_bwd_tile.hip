@@ -50,6 +50,14 @@ struct Conv0BwdTileArgs {
   int B, ntiles;
 };
 
+// T: element type of the residual, of the two dz tensors and of gx1p / gx1 (bf16 storage, DESIGN 4.6: the two data gradients are
+// then rounded to bf16 before they are combined, as the kernels this replaces stored them)
+template <class T>
+__device__ __forceinline__ float stored(float v) {
+  if constexpr (sizeof(T) == 2) return (float)(T)v;
+  return v;
+}
+template <class T>
 __global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTileArgs a) {
   static_assert(NT == 512 && TR == 32 && TC == 64, "the thread maps below are written for 512 threads and 32 x 64 tiles");
   __shared__ __attribute__((aligned(16))) float res[CI * RCH];
@@ -67,9 +75,9 @@ __global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTil
     const int b = 8 * (tile >> 6) + (tile & 7), k = (tile >> 3) & 7;
     if (b >= a.B) continue;
     const int r0 = (k >> 1) * TR, c0 = (k & 1) * TC;
-    const float* rb = a.r + (long)b * CI * L;
-    const float* zTb = a.dz[0] + (long)b * a.z_bs;
-    const float* zFb = a.dz[1] + (long)b * a.z_bs;
+    const T* rb = reinterpret_cast<const T*>(a.r) + (long)b * CI * L;
+    const T* zTb = reinterpret_cast<const T*>(a.dz[0]) + (long)b * a.z_bs;
+    const T* zFb = reinterpret_cast<const T*>(a.dz[1]) + (long)b * a.z_bs;
     __syncthreads();  // the previous tile's readers are done
     // ---- stage the residual tile, the positions that cover it and the halos
     {
@@ -77,37 +85,37 @@ __global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTil
       f32x4 v[NV], zt[NZT], zf[NZF];
 #pragma unroll
       for (int q = 0; q < NV; ++q)  // i = t + NT q: channel q, row rq, quad c4
-        v[q] = *reinterpret_cast<const f32x4*>(rb + ((long)q * P + r0 + rq) * P + c0 + 4 * c4);
+        v[q] = Elem<T>::ld4(rb + ((long)q * P + r0 + rq) * P + c0 + 4 * c4);
 #pragma unroll
       for (int q = 0; q < NZT; ++q) {
         const int i = t + NT * q, p4 = i & 3, rr = i >> 2, cs = rr >> 5, r = rr & (TR - 1);
-        zt[q] = *reinterpret_cast<const f32x4*>(zTb + (long)cs * LO + (r0 + r) * (P / 4) + c0 / 4 + 4 * p4);
+        zt[q] = Elem<T>::ld4(zTb + (long)cs * LO + (r0 + r) * (P / 4) + c0 / 4 + 4 * p4);
       }
 #pragma unroll
       for (int q = 0; q < NZF; ++q) {
         const int i = t + NT * q, g4 = i & 1, cc = i >> 1, cs = cc >> 6, c = cc & (TC - 1);
-        zf[q] = *reinterpret_cast<const f32x4*>(zFb + (long)cs * LO + (c0 + c) * (P / 4) + r0 / 4 + 4 * g4);
+        zf[q] = Elem<T>::ld4(zFb + (long)cs * LO + (c0 + c) * (P / 4) + r0 / 4 + 4 * g4);
       }
       float h = 0.f, ex = 0.f;
       if (t < CI * TR) {  // the element before each tile row: column c0 - 1, or the end of the row above
         const int ci = t >> 5, r = r0 + (t & (TR - 1));
         const long g = c0 > 0 ? ((long)ci * P + r) * P + c0 - 1 : ((long)ci * P + r - 1) * P + P - 1;
-        if (c0 > 0 || r > 0) h = rb[g];
+        if (c0 > 0 || r > 0) h = Elem<T>::ld(rb + g);
       } else if (t >= 256) {  // the element above each tile column: row r0 - 1, or the end of the column before
         const int u = t - 256, ci = u >> 6, c = c0 + (u & (TC - 1));
         const long g = r0 > 0 ? ((long)ci * P + r0 - 1) * P + c : ((long)ci * P + P - 1) * P + c - 1;
-        if (r0 > 0 || c > 0) h = rb[g];
+        if (r0 > 0 || c > 0) h = Elem<T>::ld(rb + g);
       }
       {  // netF: the position below each tile column's eight (its tap 0 is the column's last element of the tile)
         const int cs = t >> 6, c = t & (TC - 1);
         const int j = (c0 + c) * (P / 4) + r0 / 4 + TR / 4;
-        if (j < LO) ex = zFb[(long)cs * LO + j];
+        if (j < LO) ex = Elem<T>::ld(zFb + (long)cs * LO + j);
       }
       float et = 0.f;
       if (t < CO * TR) {  // netT: the position after each tile row's sixteen
         const int cs = t >> 5, r = t & (TR - 1);
         const int j = (r0 + r) * (P / 4) + c0 / 4 + TC / 4;
-        if (j < LO) et = zTb[(long)cs * LO + j];
+        if (j < LO) et = Elem<T>::ld(zTb + (long)cs * LO + j);
       }
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTil
     f32x4 gp[CI];
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci)
-      gp[ci] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.gx1p + (long)b * CI * L + ((long)ci * P + r0 + rq) * P + c0 + 4 * c4));
+      gp[ci] = Elem<T>::ld4(reinterpret_cast<const T*>(a.gx1p) + (long)b * CI * L + ((long)ci * P + r0 + rq) * P + c0 + 4 * c4);
     // ---- weight gradients: four positions per matrix instruction, every eighth group per wavefront
     {
       const int cb = lm >> 2, tt = lm & 3;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTil
     }
     // ---- data gradients and the combination: element (r, c) is tap (c + 1) % 4 of netT's position (r, (c + 1) / 4) and
     // tap (r + 1) % 4 of netF's position (c, (r + 1) / 4)
-    float* gb = a.gx1 + (long)b * CI * L;
+    T* gb = reinterpret_cast<T*>(a.gx1) + (long)b * CI * L;
     const int g = (rq + 1) >> 2;
 #pragma unroll
     for (int ci = 0; ci < CI; ++ci) {
@@ -185,8 +193,8 @@ __global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTil
       }
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = gp[ci][e] - 0.5f * (dT[e] + dF[e]);
-      *reinterpret_cast<f32x4*>(gb + ((long)ci * P + r0 + rq) * P + c0 + 4 * c4) = o;
+      for (int e = 0; e < 4; ++e) o[e] = gp[ci][e] - 0.5f * (stored<T>(dT[e]) + stored<T>(dF[e]));
+      Elem<T>::st4(gb + ((long)ci * P + r0 + rq) * P + c0 + 4 * c4, o);
     }
   }
   // ---- the eight wavefronts' weight-gradient images -> one slab (fixed order), bias partials
@@ -222,7 +230,7 @@ size_t conv0_bwd_tile_workspace_floats() { return (size_t)MAX_GRID * SLAB; }
 // dw / db of both networks: closed here (defer == nullptr) or queued as closing sums
 int conv0_bwd_tile(const float* r, const float* dzT, const float* dzF, long z_bs, const float* wT, const float* wF, const float* gx1p,
                    float* gx1, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws, size_t wsf, int accumulate,
-                   hipStream_t st, GradJobs* defer) {
+                   hipStream_t st, GradJobs* defer, int bf) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!r || !dzT || !dzF || !wT || !wF || !gx1p || !gx1 || !dwT || !dwF || !ws || B < 1 || z_bs % 4 || !al16(r) || !al16(dzT) || !al16(dzF) ||
       !al16(wT) || !al16(wF) || !al16(gx1p) || !al16(gx1)) {
@@ -232,12 +240,14 @@ int conv0_bwd_tile(const float* r, const float* dzT, const float* dzF, long z_bs
   if (wsf < conv0_bwd_tile_workspace_floats()) { set_last_error("conv0_bwd_tile: workspace too small"); return LSHM_ERR_WORKSPACE; }
   Conv0BwdTileArgs a;
   a.r = r; a.dz[0] = dzT; a.dz[1] = dzF; a.w[0] = wT; a.w[1] = wF; a.gx1p = gx1p; a.gx1 = gx1; a.partial = ws;
-  a.z_bs = z_bs; a.B = B; a.ntiles = ((B + 7) / 8) * 8 * TPI;
-  int rc = kernel_budget_ok(reinterpret_cast<const void*>(&conv0_bwd_tile_kernel), NT, 0, "conv0_bwd_tile");
+  a.z_bs = z_bs; a.B = B; a.ntiles = ((B + 7) / 8) * 8 * TPI;  // (strides and offsets in elements of the storage type)
+  int rc = kernel_budget_ok(bf ? reinterpret_cast<const void*>(&conv0_bwd_tile_kernel<bf16>) : reinterpret_cast<const void*>(&conv0_bwd_tile_kernel<float>),
+                            NT, 0, "conv0_bwd_tile");
   if (rc) return rc;
   // two workgroups per CU (LDS); each keeps its weight-gradient accumulators over its tiles: 512 slabs for the closing sums
   const int grid = a.ntiles < 512 ? a.ntiles : 512;
-  hipLaunchKernelGGL(conv0_bwd_tile_kernel, dim3(grid), dim3(NT), 0, st, a);
+  if (bf) hipLaunchKernelGGL(conv0_bwd_tile_kernel<bf16>, dim3(grid), dim3(NT), 0, st, a);
+  else hipLaunchKernelGGL(conv0_bwd_tile_kernel<float>, dim3(grid), dim3(NT), 0, st, a);
   if ((rc = check_launch("conv0_bwd_tile"))) return rc;
   float* dw[2] = {dwT, dwF};
   float* db[2] = {dbT, dbF};

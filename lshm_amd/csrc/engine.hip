@@ -453,6 +453,18 @@ static int ae_forward(const lshm_engine* e, int G, const int* idx, const float* 
   return LSHM_OK;
 }
 
+// bf16 storage: the tile kernels of the 1-D pair's outermost layers take every image-sized tensor they touch as bf16, or none
+static bool conv0_tile_bf_ok(const lshm_engine* e) {
+  const ConvLayer& a = e->ae[1].enc[0];
+  const ConvLayer& b = e->ae[2].enc[0];
+  return !e->bf || (a.in_bf16 && a.out_bf16 && b.in_bf16 && b.out_bf16);
+}
+static bool dec5_bf_ok(const lshm_engine* e) {
+  const ConvLayer& a = e->ae[1].dec[5];
+  const ConvLayer& b = e->ae[2].dec[5];
+  return !e->bf || (a.in_bf16 && a.out_bf16 && b.in_bf16 && b.out_bf16);
+}
+
 // The three forwards of the default (paired) schedule as one step list: harmonic features + the six layers fed by
 // them alone, the 2-D autoencoder, the residual split, netT and netF as paired launches.
 static void three_forward_steps(const lshm_engine* e, const float* prm, const float* x, const float* uv,
@@ -495,7 +507,7 @@ static void three_forward_steps(const lshm_engine* e, const float* prm, const fl
       if (*resid_conv0_step && !sched(LSHM_SCHED_NO_RESID_CONV0_KEEP))
       {
         // the column-vectorised residual is only read by conv0's weight gradient: not written when that is the tile kernel
-        const bool row_only = !e->bf && (e->pair_mode || !e->side_ok) && aT.enc[0].out_bs == aF.enc[0].out_bs &&
+        const bool row_only = conv0_tile_bf_ok(e) && (e->pair_mode || !e->side_ok) && aT.enc[0].out_bs == aF.enc[0].out_bs &&
                               conv0_bwd_tile_supported(c.C, c.P, aT.enc[0].Cin, aT.enc[0].Cout, aT.enc[0].Win, aT.enc[0].in_bs);
         *resid_conv0_keep_step = [=](float* ws, hipStream_t st) -> int {
           e->col_written = !row_only;
@@ -617,13 +629,14 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
                                0, wst, &jobs))) return rc;
     for (int g = 0; g < G; ++g) dz[g] = ws + LA(g).o_gdec[5];
     dec_from = 4;
-  } else if (G == 2 && combine && !e->bf && a0.dec[5].in_bs == A(1).dec[5].in_bs && a0.dec[5].out_bs == (long)c.C * c.P * c.P &&
+  } else if (G == 2 && combine && dec5_bf_ok(e) && a0.dec[5].in_bs == A(1).dec[5].in_bs && a0.dec[5].out_bs == (long)c.C * c.P * c.P &&
              A(1).dec[5].out_bs == a0.dec[5].out_bs && recon_bwd5_supported(c.C, c.P, a0.dec[5].Cin, a0.dec[5].Cout, a0.dec[5].Win)) {
     // ... or, when another pass made the gradient images (sequential forwards, a captured iteration, a line search's closure):
     // the same tiles on the same workgroups in the same order from those images -- every schedule gets the same bits
     if ((rc = on_st([&] {
            return tconv5_pair_bwd(dz[0], dz[1], ws + A(0).dact[4], ws + A(1).dact[4], a0.dec[5].in_bs, prm + A(0).tw[5], prm + A(1).tw[5], B,
-                                  ws + LA(0).o_gdec[5], ws + LA(1).o_gdec[5], a0.dec[5].in_bs, ws + e->o_recon_w5, recon_bwd5_workspace_floats(), st);
+                                  ws + LA(0).o_gdec[5], ws + LA(1).o_gdec[5], a0.dec[5].in_bs, ws + e->o_recon_w5, recon_bwd5_workspace_floats(), st,
+                                  e->bf);
          }))) return rc;
     if ((rc = recon_bwd5_close(ws + e->o_recon_w5, recon_bwd5_grid(B), grd + A(0).tw[5], grd + A(0).tb[5], grd + A(1).tw[5], grd + A(1).tb[5],
                                0, wst, &jobs))) return rc;  // (closed with the other sums, behind the next "dz ready")
@@ -832,7 +845,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       i = 2;
       continue;
     }
-    if (i == 0 && G == 2 && combine && !e->bf && A(1).enc[0].out_bs == a0.enc[0].out_bs &&
+    if (i == 0 && G == 2 && combine && conv0_tile_bf_ok(e) && A(1).enc[0].out_bs == a0.enc[0].out_bs &&
         conv0_bwd_tile_supported(c.C, c.P, a0.enc[0].Cin, a0.enc[0].Cout, a0.enc[0].Win, a0.enc[0].in_bs)) {
       // first layer of netT and netF: both weight gradients, both data gradients and their combination with the
       // reconstruction terms' share into the 2-D autoencoder's output gradient, one pass over image tiles
@@ -841,7 +854,7 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       if (!tws) { set_last_error("engine: deferred-sum scratch exhausted"); return LSHM_ERR_WORKSPACE; }
       if ((rc = on_st([&] {
              return conv0_bwd_tile(input[0], dz[0], dz[1], a0.enc[0].out_bs, prm + A(0).cw[0], prm + A(1).cw[0], combine->gx1p, combine->gx1,
-                                   grd + A(0).cw[0], grd + A(0).cb[0], grd + A(1).cw[0], grd + A(1).cb[0], B, tws, twf, 0, st, &jobs);
+                                   grd + A(0).cw[0], grd + A(0).cb[0], grd + A(1).cw[0], grd + A(1).cb[0], B, tws, twf, 0, st, &jobs, e->bf);
            }))) return rc;
       const_cast<CombineInto*>(combine)->done = true;
       fused_tail = true;
@@ -1763,14 +1776,14 @@ int lshm_engine_multiplier_update_next_ex(lshm_engine* e, const float* params, c
   // stream of the next closure: nothing needs them before the loss terms are assembled there
   // ... and, fp32 storage, the backward of that layer (both networks) inside the same pass: two of the three gradient images are
   // never written (recon_bwd5.hip); the backward finds the layer's data gradients in the lanes' buffers
-  const bool with_bwd5 = from_a && !e->bf && e->side_wgrad && aT.dec[5].out_bs == aF.dec[5].out_bs &&
+  const bool with_bwd5 = from_a && dec5_bf_ok(e) && e->side_wgrad && aT.dec[5].out_bs == aF.dec[5].out_bs &&
                          recon_bwd5_supported(c.C, c.P, aT.dec[5].Cin, aT.dec[5].Cout, aT.dec[5].Win);
   e->recon_bwd5_done = with_bwd5;
   if (with_bwd5)
     rc = recon_bwd5(x, fws + e->ae[0].out, fws + aT.dact[4], fws + aF.dact[4], aT.dec[5].in_bs, params + aT.tw[5], params + aT.tb[5],
                     params + aF.tw[5], params + aF.tb[5], y1, y2, y3, c.rho, c.B, ws + e->o_gx1p, ws + e->lane[0].o_gdec[5],
                     ws + e->lane[1].o_gdec[5], aT.dec[5].in_bs, ws + e->o_recon_part, ws + e->o_recon_w5, recon_bwd5_workspace_floats(), fst,
-                    (float)(1.0 / world));
+                    (float)(1.0 / world), e->bf);
   else if (from_a)
     rc = multiplier_update_recon_from_a(x, fws + e->ae[0].out, fws + aT.dact[4], fws + aF.dact[4], aT.dec[5].in_bs, params + aT.tw[5],
                                         params + aT.tb[5], params + aF.tw[5], params + aF.tb[5], c.C, y1, y2, y3, c.rho, c.B * c.C,

@@ -227,7 +227,7 @@ bool conv0_bwd_tile_supported(int C, int P, int Cin, int Cout, int L1d, long in_
 size_t conv0_bwd_tile_workspace_floats();
 int conv0_bwd_tile(const float* r, const float* dzT, const float* dzF, long z_bs, const float* wT, const float* wF, const float* gx1p,
                    float* gx1, float* dwT, float* dbT, float* dwF, float* dbF, int B, float* ws, size_t wsf, int accumulate,
-                   hipStream_t st, GradJobs* defer);
+                   hipStream_t st, GradJobs* defer, int bf = 0);  // bf: the residual, both dz tensors, gx1p and gx1 are bf16 tensors
 
 // One element of the reconstruction pass (src/kharmonic_lofar.py:150-158,200-202), shared by recon_kernel (elementwise.hip) and
 // recon_bwd5_kernel so that both give the same bits whatever the compiler would have contracted in either context: every
@@ -263,9 +263,10 @@ size_t recon_bwd5_workspace_floats();
 int recon_bwd5_grid(int B);
 int recon_bwd5(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT, const float* bT,
                const float* wF, const float* bF, float* y1, float* y2, float* y3, float rho, int B, float* gx1p, float* dT, float* dF,
-               long d_bs, float* block_partials, float* slabs, size_t slab_floats, hipStream_t st, float grad_scale);
+               long d_bs, float* block_partials, float* slabs, size_t slab_floats, hipStream_t st, float grad_scale, int bf = 0);
+// (bf: x1, the layers' inputs, gx1p, the gradient images and the data gradients are bf16 tensors)
 int tconv5_pair_bwd(const float* gx2, const float* gx3c, const float* aT, const float* aF, long a_bs, const float* wT, const float* wF,
-                    int B, float* dT, float* dF, long d_bs, float* slabs, size_t slab_floats, hipStream_t st);
+                    int B, float* dT, float* dF, long d_bs, float* slabs, size_t slab_floats, hipStream_t st, int bf = 0);
 int recon_bwd5_close(const float* slabs, int grid, float* dwT, float* dbT, float* dwF, float* dbF, int accumulate, hipStream_t st,
                      GradJobs* defer);
 

@@ -47,7 +47,14 @@ struct ReconBwd5Args {
 
 // FUSED == false: the layer's backward alone, from the two gradient images another pass wrote -- the same tiles on the same
 // workgroups in the same order, so that a schedule without the fused pass gets the same bits (the closing sums are shared too)
-template <bool FUSED>
+// T: element type of x1, of the layers' inputs, of gx1p, of the two gradient images and of the data gradients (bf16 storage, DESIGN
+// 4.6): the reconstructions and the two gradient images are then rounded to bf16 where the separate launches stored them
+template <class T>
+__device__ __forceinline__ float stored5(float v) {
+  if constexpr (sizeof(T) == 2) return (float)(T)v;
+  return v;
+}
+template <bool FUSED, class T>
 __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a) {
   __shared__ __attribute__((aligned(16))) float g2[C * GP];     // d/dx2 of the tile, g2[co][r * 33 + c]
   __shared__ __attribute__((aligned(16))) float g3[C * GP];     // x3 (as read by the pass: [column][row]), then d/dx3 as g3[co][r * 33 + c]
@@ -67,9 +74,9 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
 #pragma unroll
     for (int u = 0; u < 2; ++u) {  // the layer inputs a 32 x 32 tile needs: 32 rows (columns) x 8 positions x 8 channels per network
       const int j = t + NT * u, net = j >> 9, idx = j & 511, cs = idx >> 6, rr = (idx >> 1) & 31, half = idx & 1;
-      const float* src = net == 0 ? a.aT + (long)b * a.a_bs + (long)cs * LA + (long)(h0 + rr) * (P / 4) + w0 / 4 + 4 * half
-                                  : a.aF + (long)b * a.a_bs + (long)cs * LA + (long)(w0 + rr) * (P / 4) + h0 / 4 + 4 * half;
-      *reinterpret_cast<f32x4*>(&stage[(net * CA + cs) * SP + rr * 8 + 4 * half]) = *reinterpret_cast<const f32x4*>(src);
+      const T* src = net == 0 ? reinterpret_cast<const T*>(a.aT) + (long)b * a.a_bs + (long)cs * LA + (long)(h0 + rr) * (P / 4) + w0 / 4 + 4 * half
+                              : reinterpret_cast<const T*>(a.aF) + (long)b * a.a_bs + (long)cs * LA + (long)(w0 + rr) * (P / 4) + h0 / 4 + 4 * half;
+      *reinterpret_cast<f32x4*>(&stage[(net * CA + cs) * SP + rr * 8 + 4 * half]) = Elem<T>::ld4(src);
     }
     __syncthreads();
     const float* sT = stage;
@@ -84,11 +91,11 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
       if constexpr (!FUSED) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)  // d/dx3 arrives per plane transposed: read along the image's columns, kept in image orientation
-          g3p[tx * (T32 + 1) + ty + 8 * i] = a.gx3c[plane + (long)(w0 + ty + 8 * i) * P + h0 + tx];
+          g3p[tx * (T32 + 1) + ty + 8 * i] = Elem<T>::ld(reinterpret_cast<const T*>(a.gx3c) + plane + (long)(w0 + ty + 8 * i) * P + h0 + tx);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float v2 = a.gx2[plane + (long)(h0 + ty + 8 * i) * P + w0 + tx];
+          const float v2 = Elem<T>::ld(reinterpret_cast<const T*>(a.gx2) + plane + (long)(h0 + ty + 8 * i) * P + w0 + tx);
           g2p[(ty + 8 * i) * (T32 + 1) + tx] = v2;
           b2 += v2; b3 += g3p[(ty + 8 * i) * (T32 + 1) + tx];
         }
@@ -107,7 +114,7 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
           float v = bfv;
 #pragma unroll
           for (int cs = 0; cs < CA; ++cs) v = fmaf(sF[cs * SP + (ty + 8 * i) * 8 + (tx >> 2)], wf[cs], v);
-          g3p[(ty + 8 * i) * (T32 + 1) + tx] = v;
+          g3p[(ty + 8 * i) * (T32 + 1) + tx] = stored5<T>(v);
         }
         __syncthreads();
         float s[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -115,18 +122,20 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const long o = plane + (long)(h0 + ty + 8 * i) * P + w0 + tx;
-          const float xv = __builtin_nontemporal_load(a.x + o), a1 = a.x1[o];
+          const float xv = __builtin_nontemporal_load(a.x + o), a1 = Elem<T>::ld(reinterpret_cast<const T*>(a.x1) + o);
           float a2 = bt;
 #pragma unroll
           for (int cs = 0; cs < CA; ++cs) a2 = fmaf(sT[cs * SP + (ty + 8 * i) * 8 + (tx >> 2)], wt[cs], a2);
+          a2 = stored5<T>(a2);
           const float a3 = g3p[tx * (T32 + 1) + ty + 8 * i];
           const float m1 = __builtin_nontemporal_load(a.y1 + o), m2 = __builtin_nontemporal_load(a.y2 + o), m3 = __builtin_nontemporal_load(a.y3 + o);
           const ReconElem q = recon_elem<true, true>(xv, a1, a2, a3, m1, m2, m3, rho, inv_n, s);
           a.y1[o] = q.m1; a.y2[o] = q.m2; a.y3[o] = q.m3;
-          g2p[(ty + 8 * i) * (T32 + 1) + tx] = q.g2;
-          gv3[i] = q.g3;
-          b2 += q.g2; b3 += q.g3;
-          a.gx1p[o] = q.g1p;
+          const float v2 = stored5<T>(q.g2);
+          g2p[(ty + 8 * i) * (T32 + 1) + tx] = v2;
+          gv3[i] = stored5<T>(q.g3);
+          b2 += v2; b3 += gv3[i];
+          Elem<T>::st(reinterpret_cast<T*>(a.gx1p) + o, q.g1p);
         }
         __syncthreads();  // every x3 of the tile has been read: the plane's tile now takes d/dx3 in image orientation
 #pragma unroll
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
       float gv[C][4];
       const float* w;
       const float* sa;
-      float* dst;
+      T* dst;
       if (net == 0) {  // netT: position (row r, p): elements 4p .. 4p + 3 of the row
         const int r = q >> 3, p = q & 7;
 #pragma unroll
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
 #pragma unroll
           for (int e = 0; e < 4; ++e) gv[co][e] = g2[co * GP + r * (T32 + 1) + 4 * p + e];
         w = a.wT; sa = sT + r * 8 + p;
-        dst = a.dT + (long)b * a.d_bs + (long)(h0 + r) * (P / 4) + w0 / 4 + p;
+        dst = reinterpret_cast<T*>(a.dT) + (long)b * a.d_bs + (long)(h0 + r) * (P / 4) + w0 / 4 + p;
       } else {         // netF: position (column c, g): elements 4g .. 4g + 3 of the column
         const int c = q >> 3, g = q & 7;
 #pragma unroll
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
 #pragma unroll
           for (int e = 0; e < 4; ++e) gv[co][e] = g3[co * GP + (4 * g + e) * (T32 + 1) + c];
         w = a.wF; sa = sF + c * 8 + g;
-        dst = a.dF + (long)b * a.d_bs + (long)(w0 + c) * (P / 4) + h0 / 4 + g;
+        dst = reinterpret_cast<T*>(a.dF) + (long)b * a.d_bs + (long)(w0 + c) * (P / 4) + h0 / 4 + g;
       }
 #pragma unroll
       for (int cs = 0; cs < CA; ++cs) {
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc = fmaf(gv[co][e], w4[e], acc);
         }
-        dst[(long)cs * LA] = acc * elu_grad_from_out(sa[cs * SP]);
+        Elem<T>::st(dst + (long)cs * LA, acc * elu_grad_from_out(sa[cs * SP]));
       }
     }
     // ---- weight gradients: four positions per matrix instruction, every eighth group per wavefront
@@ -262,7 +271,7 @@ int recon_bwd5_grid(int B) {
 
 int recon_bwd5(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT, const float* bT,
                const float* wF, const float* bF, float* y1, float* y2, float* y3, float rho, int B, float* gx1p, float* dT, float* dF,
-               long d_bs, float* block_partials, float* slabs, size_t slab_floats, hipStream_t st, float grad_scale) {
+               long d_bs, float* block_partials, float* slabs, size_t slab_floats, hipStream_t st, float grad_scale, int bf) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!x || !x1 || !aT || !aF || !wT || !bT || !wF || !bF || !y1 || !y2 || !y3 || !gx1p || !dT || !dF || !block_partials || !slabs || B < 1 ||
       a_bs % 4 || !al16(aT) || !al16(aF) || !al16(wT) || !al16(wF)) {
@@ -277,16 +286,18 @@ int recon_bwd5(const float* x, const float* x1, const float* aT, const float* aF
   a.slabs = slabs; a.a_bs = a_bs; a.d_bs = d_bs; a.rho = rho; a.inv_n = (float)(grad_scale / n);
   a.B = B; a.ntiles = ((B + 7) / 8) * 8 * 16;
   a.gx2 = a.gx3c = nullptr;
-  int rc = kernel_budget_ok(reinterpret_cast<const void*>(&recon_bwd5_kernel<true>), NT, 0, "recon_bwd5");
+  int rc = kernel_budget_ok(bf ? reinterpret_cast<const void*>(&recon_bwd5_kernel<true, bf16>) : reinterpret_cast<const void*>(&recon_bwd5_kernel<true, float>),
+                            NT, 0, "recon_bwd5");
   if (rc) return rc;
-  hipLaunchKernelGGL(recon_bwd5_kernel<true>, dim3(recon_bwd5_grid(B)), dim3(NT), 0, st, a);
+  if (bf) hipLaunchKernelGGL((recon_bwd5_kernel<true, bf16>), dim3(recon_bwd5_grid(B)), dim3(NT), 0, st, a);
+  else hipLaunchKernelGGL((recon_bwd5_kernel<true, float>), dim3(recon_bwd5_grid(B)), dim3(NT), 0, st, a);
   return check_launch("recon_bwd5");
 }
 
 // The layer's backward alone (both networks), bit for bit what the fused pass leaves: data gradients times ELU' in dT / dF, slabs for
 // recon_bwd5_close.  gx2: (B, 4, 128, 128); gx3c: the same per plane transposed.
 int tconv5_pair_bwd(const float* gx2, const float* gx3c, const float* aT, const float* aF, long a_bs, const float* wT, const float* wF,
-                    int B, float* dT, float* dF, long d_bs, float* slabs, size_t slab_floats, hipStream_t st) {
+                    int B, float* dT, float* dF, long d_bs, float* slabs, size_t slab_floats, hipStream_t st, int bf) {
   auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
   if (!gx2 || !gx3c || !aT || !aF || !wT || !wF || !dT || !dF || !slabs || B < 1 || a_bs % 4 || !al16(aT) || !al16(aF) || !al16(wT) || !al16(wF)) {
     set_last_error("tconv5_pair_bwd: null or unaligned pointer");
@@ -296,9 +307,11 @@ int tconv5_pair_bwd(const float* gx2, const float* gx3c, const float* aT, const 
   ReconBwd5Args a{};
   a.aT = aT; a.aF = aF; a.wT = wT; a.wF = wF; a.dT = dT; a.dF = dF; a.slabs = slabs; a.gx2 = gx2; a.gx3c = gx3c;
   a.a_bs = a_bs; a.d_bs = d_bs; a.B = B; a.ntiles = ((B + 7) / 8) * 8 * 16;
-  int rc = kernel_budget_ok(reinterpret_cast<const void*>(&recon_bwd5_kernel<false>), NT, 0, "tconv5_pair_bwd");
+  int rc = kernel_budget_ok(bf ? reinterpret_cast<const void*>(&recon_bwd5_kernel<false, bf16>) : reinterpret_cast<const void*>(&recon_bwd5_kernel<false, float>),
+                            NT, 0, "tconv5_pair_bwd");
   if (rc) return rc;
-  hipLaunchKernelGGL(recon_bwd5_kernel<false>, dim3(recon_bwd5_grid(B)), dim3(NT), 0, st, a);
+  if (bf) hipLaunchKernelGGL((recon_bwd5_kernel<false, bf16>), dim3(recon_bwd5_grid(B)), dim3(NT), 0, st, a);
+  else hipLaunchKernelGGL((recon_bwd5_kernel<false, float>), dim3(recon_bwd5_grid(B)), dim3(NT), 0, st, a);
   return check_launch("tconv5_pair_bwd");
 }
 

@@ -395,7 +395,7 @@ def test_first_1d_layers_backward_and_the_combination_as_one_launch(nb):
     db = [torch.full((8,), float("nan"), device=DEV) for _ in range(2)]
     gx1 = torch.full((nb, 4, 128, 128), float("nan"), device=DEV)
     L.check(lib.lshm_conv0_bwd_tile(P(rd), P(dzd[0]), P(dzd[1]), P(wd[0]), P(wd[1]), P(gpd), P(gx1), P(dw[0]), P(db[0]), P(dw[1]), P(db[1]),
-                                    nb, P(ws), nws, 0, st), "conv0_bwd_tile")
+                                    nb, P(ws), nws, 0, 0, st), "conv0_bwd_tile")
     # the replaced launches
     nws2 = lib.lshm_conv_workspace_floats(2, nb, 4, 8, 1, 16384)
     ws2 = torch.empty(nws2, device=DEV)
@@ -513,7 +513,7 @@ def test_reconstruction_pass_with_the_last_1d_layers_backward_inside(nb):
     dw = [torch.full((8, C, 4), float("nan"), device=DEV) for _ in range(2)]
     db = [torch.full((C,), float("nan"), device=DEV) for _ in range(2)]
     L.check(lib.lshm_recon_bwd5(Pt(xd), Pt(x1d), Pt(ad[0]), Pt(ad[1]), Pt(wd[0]), Pt(bd[0]), Pt(wd[1]), Pt(bd[1]), *[Pt(t) for t in y_new], rho,
-                                nb, Pt(s_new), Pt(gx1p), Pt(da[0]), Pt(da[1]), Pt(dw[0]), Pt(db[0]), Pt(dw[1]), Pt(db[1]), Pt(ws5), nws5, st),
+                                nb, Pt(s_new), Pt(gx1p), Pt(da[0]), Pt(da[1]), Pt(dw[0]), Pt(db[0]), Pt(dw[1]), Pt(db[1]), Pt(ws5), nws5, 0, st),
             "recon_bwd5")
     torch.cuda.synchronize()
     for p, q in zip(y_ref, y_new):
@@ -528,7 +528,7 @@ def test_reconstruction_pass_with_the_last_1d_layers_backward_inside(nb):
     dw2 = [torch.full((8, C, 4), float("nan"), device=DEV) for _ in range(2)]
     db2 = [torch.full((C,), float("nan"), device=DEV) for _ in range(2)]
     L.check(lib.lshm_tconv5_pair_bwd(Pt(g_ref[1]), Pt(g_ref[2]), Pt(ad[0]), Pt(ad[1]), Pt(wd[0]), Pt(wd[1]), Pt(da2[0]), Pt(da2[1]), Pt(dw2[0]),
-                                     Pt(db2[0]), Pt(dw2[1]), Pt(db2[1]), nb, Pt(ws5), nws5, st), "tconv5_pair_bwd")
+                                     Pt(db2[0]), Pt(dw2[1]), Pt(db2[1]), nb, Pt(ws5), nws5, 0, st), "tconv5_pair_bwd")
     torch.cuda.synchronize()
     for k in range(2):
         assert torch.equal(da[k], da2[k]) and torch.equal(dw[k], dw2[k]) and torch.equal(db[k], db2[k])
@@ -541,6 +541,100 @@ def test_reconstruction_pass_with_the_last_1d_layers_backward_inside(nb):
         assert rel_err(dw[k], wr.grad) < 1e-4 and rel_err(db[k], br.grad) < 1e-4
         eg = torch.where(a[k].double() > 0, torch.ones_like(av), a[k].double() + 1.0)
         assert rel_err(da[k], (av.grad * eg)) < 1e-5
+
+
+@pytest.mark.parametrize("nb", [64, 3])
+def test_tile_kernels_of_the_1d_pair_with_bf16_storage(nb):
+    """lshm_conv0_bwd_tile, lshm_recon_bwd5 and lshm_tconv5_pair_bwd with storage_bf16 = 1 (BASELINE configs[2]: image-sized
+    tensors are bf16 in HBM, arithmetic and the small results fp32): against fp64 on the bf16-rounded inputs, to bf16 rounding of
+    the image-sized outputs."""
+    from lshm_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(1200 + nb)
+    C, P, rho = 4, 128, 0.7
+    bf = lambda t: t.to(torch.bfloat16)
+    dv = lambda t: t.to(DEV).contiguous()
+    st, Pt = L.stream(), L.ptr
+    # ---- backward of conv0 of both networks + the combination
+    r = bf(torch.randn(nb, C, P, P, generator=g))
+    dz = [bf(torch.randn(nb, 8, 4096, generator=g)) for _ in range(2)]
+    w = [torch.randn(8, C, 4, generator=g) * 0.3 for _ in range(2)]
+    gp = bf(torch.randn(nb, C, P, P, generator=g))
+    rd, gpd, dzd, wd = dv(r), dv(gp), [dv(t) for t in dz], [dv(t) for t in w]
+    nws = lib.lshm_conv0_bwd_tile_workspace_floats()
+    ws = torch.empty(nws, device=DEV)
+    dw = [torch.full((8, C, 4), float("nan"), device=DEV) for _ in range(2)]
+    db = [torch.full((8,), float("nan"), device=DEV) for _ in range(2)]
+    gx1 = torch.full((nb, C, P, P), float("nan"), device=DEV, dtype=torch.bfloat16)
+    L.check(lib.lshm_conv0_bwd_tile(Pt(rd), Pt(dzd[0]), Pt(dzd[1]), Pt(wd[0]), Pt(wd[1]), Pt(gpd), Pt(gx1), Pt(dw[0]), Pt(db[0]), Pt(dw[1]), Pt(db[1]),
+                                    nb, Pt(ws), nws, 0, 1, st), "conv0_bwd_tile bf16")
+    torch.cuda.synchronize()
+    seqs = (r.double().reshape(nb, C, -1), r.double().transpose(2, 3).reshape(nb, C, -1))
+    gref = gp.double().clone()
+    for k in range(2):
+        xs = seqs[k].clone().requires_grad_(True)
+        wr = w[k].double().requires_grad_(True)
+        br = torch.zeros(8, dtype=torch.float64, requires_grad=True)
+        TF.conv1d(xs, wr, br, stride=4, padding=1).backward(dz[k].double())
+        assert rel_err(dw[k], wr.grad) < 1e-4 and rel_err(db[k], br.grad) < 1e-4
+        d = xs.grad.reshape(nb, C, P, P)
+        gref -= 0.5 * (d if k == 0 else d.transpose(2, 3))
+    assert torch.isfinite(gx1.float()).all() and rel_err(gx1.float(), gref) < 6e-3
+    # ---- reconstruction pass with the last 1-D layer's backward inside
+    x = torch.randn(nb, C, P, P, generator=g)
+    x1 = bf(torch.randn(nb, C, P, P, generator=g))
+    a = [bf(TF.elu(torch.randn(nb, 8, P * P // 4, generator=g))) for _ in range(2)]
+    w5 = [torch.randn(8, C, 4, generator=g) * 0.3 for _ in range(2)]
+    b5 = [torch.randn(C, generator=g) * 0.1 for _ in range(2)]
+    ys = [torch.randn(nb, C, P, P, generator=g) * 0.1 for _ in range(3)]
+    xd, x1d, ad, w5d, b5d, yd = dv(x), dv(x1), [dv(t) for t in a], [dv(t) for t in w5], [dv(t) for t in b5], [dv(t) for t in ys]
+    nws5 = lib.lshm_recon_bwd5_workspace_floats(nb)
+    ws5 = torch.empty(nws5, device=DEV)
+    s7 = torch.zeros(8, device=DEV, dtype=torch.float64)
+    gx1p = torch.full((nb, C, P, P), float("nan"), device=DEV, dtype=torch.bfloat16)
+    da = [torch.full((nb, 8, P * P // 4), float("nan"), device=DEV, dtype=torch.bfloat16) for _ in range(2)]
+    dw5 = [torch.full((8, C, 4), float("nan"), device=DEV) for _ in range(2)]
+    db5 = [torch.full((C,), float("nan"), device=DEV) for _ in range(2)]
+    L.check(lib.lshm_recon_bwd5(Pt(xd), Pt(x1d), Pt(ad[0]), Pt(ad[1]), Pt(w5d[0]), Pt(b5d[0]), Pt(w5d[1]), Pt(b5d[1]), *[Pt(t) for t in yd], rho, nb,
+                                Pt(s7), Pt(gx1p), Pt(da[0]), Pt(da[1]), Pt(dw5[0]), Pt(db5[0]), Pt(dw5[1]), Pt(db5[1]), Pt(ws5), nws5, 1, st),
+            "recon_bwd5 bf16")
+    torch.cuda.synchronize()
+    # fp64 restatement of the pass (src/kharmonic_lofar.py:150-158,200-202) with the storage roundings of the separate launches
+    rb = lambda t: t.to(torch.bfloat16).double()
+    X, X1 = x.double(), x1.double()
+    x2 = rb(TF.conv_transpose1d(a[0].double(), w5[0].double(), b5[0].double(), stride=4)).reshape(nb, C, P, P)
+    x3 = rb(TF.conv_transpose1d(a[1].double(), w5[1].double(), b5[1].double(), stride=4)).reshape(nb, C, P, P).transpose(2, 3)
+    r1 = X - X1; h = 0.5 * r1; r2 = h - x2; r3 = h - x3; e = X1 + x2 + x3 - X
+    m = [ys[0].double() + rho * r1, ys[1].double() + rho * r2, ys[2].double() + rho * r3]
+    for k in range(3):  # (a reconstruction within 1e-7 of a bf16 rounding boundary may round the other way in fp64: ~1e-5 of them)
+        assert rel_err(yd[k], m[k]) < 3e-4
+    n = float(nb * C * P * P)
+    sums = torch.stack([(e * e).sum(), (m[0] * r1).sum(), (r1 * r1).sum(), (m[1] * r2).sum(), (r2 * r2).sum(), (m[2] * r3).sum(), (r3 * r3).sum()])
+    assert rel_err(s7[:7].cpu(), sums) < 1e-4
+    t2, t3 = m[1] + rho * r2, m[2] + rho * r3
+    g1p = (2 * e - m[0] - rho * r1) / n - 0.5 * (t2 + t3) / n
+    assert rel_err(gx1p.float(), g1p) < 6e-3
+    g2, g3 = rb((2 * e - t2) / n), rb((2 * e - t3) / n)
+    gim = (g2.reshape(nb, C, -1), g3.transpose(2, 3).reshape(nb, C, -1))
+    for k in range(2):
+        av = a[k].double().requires_grad_(True)
+        wr = w5[k].double().requires_grad_(True)
+        br = b5[k].double().requires_grad_(True)
+        TF.conv_transpose1d(av, wr, br, stride=4).backward(gim[k])
+        assert rel_err(dw5[k], wr.grad) < 2e-3 and rel_err(db5[k], br.grad) < 2e-3   # (the images' bf16 rounding is modelled, not reproduced bit for bit)
+        eg = torch.where(a[k].double() > 0, torch.ones_like(av), a[k].double() + 1.0)
+        assert rel_err(da[k].float(), av.grad * eg) < 6e-3
+    # ---- the layer's backward alone from (modelled) bf16 gradient images agrees with the fused pass
+    gx2d = dv(g2.reshape(nb, C, P * P).to(torch.bfloat16))
+    gx3d = dv(g3.transpose(2, 3).reshape(nb, C, P * P).to(torch.bfloat16))
+    da2 = [torch.full((nb, 8, P * P // 4), float("nan"), device=DEV, dtype=torch.bfloat16) for _ in range(2)]
+    dw2 = [torch.full((8, C, 4), float("nan"), device=DEV) for _ in range(2)]
+    db2 = [torch.full((C,), float("nan"), device=DEV) for _ in range(2)]
+    L.check(lib.lshm_tconv5_pair_bwd(Pt(gx2d), Pt(gx3d), Pt(ad[0]), Pt(ad[1]), Pt(w5d[0]), Pt(w5d[1]), Pt(da2[0]), Pt(da2[1]), Pt(dw2[0]), Pt(db2[0]),
+                                     Pt(dw2[1]), Pt(db2[1]), nb, Pt(ws5), nws5, 1, st), "tconv5_pair_bwd bf16")
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert rel_err(dw2[k], dw5[k]) < 2e-3 and rel_err(da2[k].float(), da[k].float()) < 6e-3
 
 
 def _deep2d_problem(nb, seed):
