@@ -30,6 +30,8 @@ TRACE_ENDS_ONLY=1 python3 profiles/step_trace_unprofiled.py > $OUT/step_completi
 python3 profiles/phase_times_probe.py > $OUT/phase_times.txt 2> $RAW/phase.err
 python3 profiles/deep2d_probe.py > $OUT/deep2d_probe.txt 2> $RAW/deep2d.err
 python3 profiles/chain1d_full_probe.py > $OUT/chain1d_full_probe.txt 2> $RAW/chain1d_full.err
+python3 profiles/resid_conv0_probe.py > $OUT/resid_conv0_probe.txt 2> $RAW/resid_conv0.err
+python3 profiles/conv0_bwd_tile_probe.py > $OUT/conv0_bwd_tile_probe.txt 2> $RAW/conv0_bwd_tile.err
 # 4. HBM traffic: FETCH_SIZE / WRITE_SIZE in separate passes, keyed by the profiled command
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace -d $RAW/pmc_step_$C --output-format csv -- python3 bench.py $STEP > /dev/null 2> $RAW/pmc_step_$C.err

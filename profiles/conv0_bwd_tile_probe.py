@@ -36,7 +36,7 @@ def timed(fn, reps=20):
 
 
 def tile():
-    L.check(lib.lshm_conv0_bwd_tile(P(r), P(dz[0]), P(dz[1]), P(w[0]), P(w[1]), P(gp), P(gx1), P(dw[0]), P(db[0]), P(dw[1]), P(db[1]), nb, P(ws), nws, 0, st), "t")
+    L.check(lib.lshm_conv0_bwd_tile(P(r), P(dz[0]), P(dz[1]), P(w[0]), P(w[1]), P(gp), P(gx1), P(dw[0]), P(db[0]), P(dw[1]), P(db[1]), nb, P(ws), nws, 0, 0, st), "t")
 def old():
     for k, xin in enumerate((r, rcol)):
         L.check(lib.lshm_conv_bwd_fused(2, P(xin), P(dz[k]), P(w[k]), P(dw[k]), P(db[k]), P(dx[k]), 0, nb, 4, 8, 1, 16384, P(ws2), nws2, st), "o")
