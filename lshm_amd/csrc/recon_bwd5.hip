@@ -264,9 +264,12 @@ int recon_bwd5_close(const float* slabs, int grid, float* dwT, float* dbT, float
   return LSHM_OK;
 }
 
+// 768 workgroups for the 4096 tiles of B = 256 (two fit a CU: 512 threads x 128 registers): 256 / 384 / 512 / 768 / 1024 ->
+// 1.860 / 1.828 / 1.803 / 1.790 / 1.799 ms per iteration (profiles/r04/README.md) -- with every CU held by persistent workgroups
+// from start to end, the closure forward's last kernels, which run beside the pass, wait for all of it
 int recon_bwd5_grid(int B) {
   const int ntiles = ((B + 7) / 8) * 8 * 16;
-  return ntiles < 512 ? ntiles : 512;
+  return ntiles < 768 ? ntiles : 768;
 }
 
 int recon_bwd5(const float* x, const float* x1, const float* aT, const float* aF, long a_bs, const float* wT, const float* bT,
