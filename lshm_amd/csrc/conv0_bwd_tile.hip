@@ -244,8 +244,9 @@ int conv0_bwd_tile(const float* r, const float* dzT, const float* dzF, long z_bs
   int rc = kernel_budget_ok(bf ? reinterpret_cast<const void*>(&conv0_bwd_tile_kernel<bf16>) : reinterpret_cast<const void*>(&conv0_bwd_tile_kernel<float>),
                             NT, 0, "conv0_bwd_tile");
   if (rc) return rc;
-  // two workgroups per CU (LDS); each keeps its weight-gradient accumulators over its tiles: 512 slabs for the closing sums
-  const int grid = a.ntiles < 512 ? a.ntiles : 512;
+  // two workgroups fit a CU (LDS); each keeps its weight-gradient accumulators over its tiles.  256 / 512 / 768 / 1024 workgroups for
+  // the 2048 tiles of B = 256: 1.820 / 1.816 / 1.793 / 1.802 ms per iteration -- the weight-gradient stream's kernels run beside this one
+  const int grid = a.ntiles < 768 ? a.ntiles : 768;
   if (bf) hipLaunchKernelGGL(conv0_bwd_tile_kernel<bf16>, dim3(grid), dim3(NT), 0, st, a);
   else hipLaunchKernelGGL(conv0_bwd_tile_kernel<float>, dim3(grid), dim3(NT), 0, st, a);
   if ((rc = check_launch("conv0_bwd_tile"))) return rc;
