@@ -149,13 +149,15 @@ __global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTil
     {
       const int cb = lm >> 2, tt = lm & 3;
 #pragma unroll 4
-      for (int s = wave; s < TR * (TC / 4) / 4; s += NT / 64) {  // netT: positions (r, p), four consecutive p
+      for (int it = 0; it < TR * (TC / 4) / 4 / (NT / 64); ++it) {  // netT: positions (r, p), four consecutive p
+        const int s = wave + (NT / 64) * it;
         const int q = 4 * s + lk, r = q >> 4, p = q & 15;
         const float av = lm < CO ? zT[lm * ZTP + r * ZTR + p] : 0.f;
         accT = __builtin_amdgcn_mfma_f32_16x16x4f32(av, res[cb * RCH + (1 + r) * RP + 4 * p + tt], accT, 0, 0, 0);
       }
 #pragma unroll 4
-      for (int s = wave; s < TC * (TR / 4) / 4; s += NT / 64) {  // netF: positions (c, g), four consecutive c
+      for (int it = 0; it < TC * (TR / 4) / 4 / (NT / 64); ++it) {  // netF: positions (c, g), four consecutive c
+        const int s = wave + (NT / 64) * it;
         const int q = 4 * s + lk, g = q >> 6, c = q & (TC - 1);
         const float av = lm < CO ? zF[lm * ZFP + g * TC + c] : 0.f;
         accF = __builtin_amdgcn_mfma_f32_16x16x4f32(av, res[cb * RCH + (4 * g + tt) * RP + 1 + c], accF, 0, 0, 0);

@@ -454,7 +454,8 @@ __global__ __launch_bounds__(256) void conv1d_bwd_lds_kernel(const BwdLds1dArgs 
     if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
     // ---- weight gradient: groups of 4 positions, every 4th group per wavefront
 #pragma unroll 4
-    for (int s = wave; s < TP / 4; s += 4) {
+    for (int it = 0; it < TP / 16; ++it) {  // (a constant trip count: `s = wave; s < TP / 4; s += 4` is refused by the unroller)
+      const int s = wave + 4 * it;
       const int p = 4 * s + lk;
       const float av = stile[lm * LDS_S + p];
 #pragma unroll

@@ -206,7 +206,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_bwd_lds_kernel(const Bwd2dArgs 
     if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x);
     // ---- weight gradient: groups of 4 consecutive positions, every 4th group per wavefront
 #pragma unroll 2
-    for (int s = wave; s < TP / 4; s += 4) {
+    for (int it = 0; it < TP / 16; ++it) {  // (a constant trip count: `s = wave; s < TP / 4; s += 4` is refused by the unroller)
+      const int s = wave + 4 * it;
       const int p = 4 * s + lk;
       const int oy = p / TW, ox = p - oy * TW;
       const float av = CONV ? simg[(lm * SPH + oy + 1) * SPW + ox + 1] : simg[lm * LDS_S + p];

@@ -524,7 +524,8 @@ __global__ __launch_bounds__(256) void conv2d_wgrad_direct_kernel(const float* _
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
     // K loop: groups of 4 consecutive positions, every 4th group per wave
 #pragma unroll 4
-    for (int s = wave; s < TP / 4; s += 4) {
+    for (int it = 0; it < TP / 16; ++it) {  // (a constant trip count: `s = wave; s < TP / 4; s += 4` is refused by the unroller)
+      const int s = wave + 4 * it;
       const int p = 4 * s + lk;
       const int oy = p / TW, ox = p - oy * TW;
       float a[MT];
@@ -1118,7 +1119,8 @@ __global__ __launch_bounds__(256, 2) void tconv2d_bwd_fused_kernel(const float* 
     // ---- weight gradient: groups of 4 consecutive positions, every 4th group per wave (conv2d_wgrad_direct_kernel)
     const int ky = lm >> 2, kx = lm & 3;
 #pragma unroll 4
-    for (int s = wave; s < TP / 4; s += 4) {
+    for (int it = 0; it < TP / 16; ++it) {  // (a constant trip count: `s = wave; s < TP / 4; s += 4` is refused by the unroller)
+      const int s = wave + 4 * it;
       const int p = 4 * s + lk;
       const int oy = p / TW, ox = p - oy * TW;
       const float av = stile[lm * LDS_S + p];
@@ -1347,7 +1349,8 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_mid_kernel(const float* __re
     __syncthreads();
     if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
 #pragma unroll 4
-    for (int s = wave; s < TP / 4; s += 4) {
+    for (int it = 0; it < TP / 16; ++it) {  // (a constant trip count: `s = wave; s < TP / 4; s += 4` is refused by the unroller)
+      const int s = wave + 4 * it;
       const int p = 4 * s + lk;
       float a[MT];
 #pragma unroll

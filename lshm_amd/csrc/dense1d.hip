@@ -34,8 +34,7 @@ __device__ __forceinline__ f32x4 gemm_kfast(const float* __restrict__ As, const 
   const bool nok = lm < nvalid;
   const float* wrow = W + (long)(n0 + (nok ? lm : 0)) * ldw + 4 * lk;
   const float* arow = As + lm * AP + 4 * lk;
-#pragma unroll 4
-  for (int s = first; s < kblocks; s += step) {
+  for (int s = first; s < kblocks; s += step) {  // (run-time bounds: the unroller refuses a factor here)
     f32x4 b = *reinterpret_cast<const f32x4*>(wrow + 16 * s);
     if (!nok) b = (f32x4){0.f, 0.f, 0.f, 0.f};
     const f32x4 a = *reinterpret_cast<const f32x4*>(arow + 16 * s);
@@ -182,7 +181,8 @@ __global__ __launch_bounds__(NTH) void dense1d_bwd_kernel(const Dense1dBwdArgs a
     f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const float* w3 = a.fc3w[pr];
 #pragma unroll 4
-    for (int s = wave; s < 768 / 4; s += NWV) {
+    for (int it = 0; it < 768 / 4 / NWV; ++it) {
+      const int s = wave + NWV * it;
       const float av = ds[lm * DP + 4 * s + lk];
       const float* wr = w3 + (long)(4 * s + lk) * (LT + HD) + lm;  // W[k = out][n = in]
 #pragma unroll

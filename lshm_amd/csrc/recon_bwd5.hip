@@ -202,7 +202,8 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
     {
       const int co = lm >> 2, tt = lm & 3;
 #pragma unroll 4
-      for (int s4 = wave; s4 < T32 * 8 / 4; s4 += NT / 64) {
+      for (int it = 0; it < T32 * 8 / 4 / (NT / 64); ++it) {
+        const int s4 = wave + (NT / 64) * it;
         const int q = 4 * s4 + lk, r = q >> 3, p = q & 7;  // netT: (row r, position p); netF: (column r, position p)
         const float avT = lm < CA ? sT[lm * SP + q] : 0.f;
         accT = __builtin_amdgcn_mfma_f32_16x16x4f32(avT, g2[co * GP + r * (T32 + 1) + 4 * p + tt], accT, 0, 0, 0);
