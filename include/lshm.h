@@ -496,6 +496,7 @@ typedef struct lshm_step_config {
 #define LSHM_SCHED_NO_KHM_MFMA (1u << 20)     /* K-harmonic pass for 16 < K <= 64 on the row-split kernel instead of the matrix cores */
 #define LSHM_SCHED_NO_EARLY_LATENT (1u << 21) /* latent-space terms at the head of the backward instead of beside the paired forwards */
 #define LSHM_SCHED_NO_CONV0_BWD_TILE (1u << 23) /* backward of 1-D conv0 (netT, netF) and the combination into the 2-D autoencoder's output gradient as two launches (lshm_conv0_bwd_tile) */
+#define LSHM_SCHED_NO_SHARED_PACK (1u << 25)    /* paired forwards: each chain makes its own fragment-ordered copy of the deep weights */
 #define LSHM_SCHED_NO_RECON_BWD5 (1u << 24)     /* the reconstruction pass does not include the backward of netT / netF's last layer (lshm_recon_bwd5) */
 #define LSHM_SCHED_NO_RESID_CONV0_KEEP (1u << 22) /* closure forward: residual split + conv0 of netT / netF as two launches (lshm_resid_conv0_keep) */
 

@@ -45,7 +45,7 @@ SCHEDULE_BITS = {"no_deep2d": 1 << 0, "no_deep2d_bwd": 1 << 1, "no_wgrad_batch":
                  "no_bwd_lds_8_4": 1 << 12, "no_bwd_lds2d": 1 << 13, "no_bwd_fused2d": 1 << 14, "no_wgrad_mid": 1 << 15,
                  "no_stop_events": 1 << 16, "wgrad_inline": 1 << 17, "fork": 1 << 18, "phase_events": 1 << 19,
                  "no_khm_mfma": 1 << 20, "no_early_latent": 1 << 21, "no_resid_conv0_keep": 1 << 22,
-                 "no_conv0_bwd_tile": 1 << 23, "no_recon_bwd5": 1 << 24}
+                 "no_conv0_bwd_tile": 1 << 23, "no_recon_bwd5": 1 << 24, "no_shared_pack": 1 << 25}
 SCHED_NO_DEEP2D, SCHED_NO_DEEP2D_BWD = SCHEDULE_BITS["no_deep2d"], SCHEDULE_BITS["no_deep2d_bwd"]
 STEP_RECON_READY = 1
 NEXT_CONCURRENT_FORWARD = 1

@@ -112,6 +112,11 @@ struct lshm_engine {
   hipStream_t lstream = nullptr;  // latent-space terms (K-harmonic, similarity, augmentation, RICA): beside everything
   std::vector<hipEvent_t> events;
   mutable size_t next_event;
+  // paired forwards: the two chains run the same parameters, so the no-grad chain reads the closure chain's fragment-ordered
+  // copy of the deep weights instead of making its own at the head of the critical chain (two_forwards)
+  mutable const float* pack_override = nullptr;
+  mutable bool skip_pack = false;
+  mutable hipEvent_t pack_event = nullptr;
   mutable bool col_written = true;  // false: the last closure forward kept only the row image of the residual (conv0_bwd_tile reads nothing else)
   hipEvent_t latent_event;  // set while the latent-space terms of the current forward are in flight
   bool sim_started = false;  // cluster_similarity of the current forward already launched (side stream)
@@ -277,7 +282,13 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
       const AEPlan& a = A(0);
       const Deep2dWeights w{prm + a.cw[2], prm + a.cw[3], prm + a.cw[4], prm + a.cw[5], prm + a.fc1w, prm + a.fc2inw, prm + a.fc2outw,
                             prm + a.fc3w, prm + a.tw[0], prm + a.tw[1], prm + a.tw[2], prm + a.tw[3]};
-      return deep2d_pack(w, ws + e->o_pack2d, 0, e->deep_bf16, st);
+      if (e->skip_pack) return LSHM_OK;
+      const int rc = deep2d_pack(w, ws + e->o_pack2d, 0, e->deep_bf16, st);
+      if (rc == LSHM_OK && e->pack_event && hipEventRecord(e->pack_event, st) != hipSuccess) {
+        set_last_error("engine: event record failed");
+        return LSHM_ERR_ARG;
+      }
+      return rc;
     });
   }
   // 1-D autoencoders: conv2 .. tconv3 (twelve layers) as one launch (chain1d_full.hip)
@@ -320,7 +331,11 @@ static void ae_forward_steps(const lshm_engine* e, int G, const int* idx, const 
         io.a3 = ws + a.act[3]; io.a4 = ws + a.act[4]; io.cat1 = ws + a.cat1; io.z1 = ws + a.z1;
         io.mu = ws + e->o_Mu + a.mu_col; io.mu_ld = D; io.cat3 = ws + a.cat3; io.d0 = ws + a.d0;
         io.t0 = ws + a.dact[0]; io.t1 = ws + a.dact[1]; io.t2 = ws + a.dact[2]; io.t3 = ws + a.dact[3];
-        return deep2d_fwd(io, ws + e->o_pack2d, B, e->deep_variant + 4 * e->deep_bf16, st);
+        if (e->pack_override && e->pack_event && hipStreamWaitEvent(st, e->pack_event, 0) != hipSuccess) {
+          set_last_error("engine: stream join failed");
+          return LSHM_ERR_ARG;
+        }
+        return deep2d_fwd(io, e->pack_override ? e->pack_override : ws + e->o_pack2d, B, e->deep_variant + 4 * e->deep_bf16, st);
       });
       break;
     }
@@ -1033,8 +1048,21 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
       return (size_t)i == P.resid_mark ? P.resid_conv0_keep(ws_b, st_b) : LSHM_OK;
     return P.steps[i](ws_b, st_b);
   };
+  // one fragment-ordered copy of the deep weights for both chains: chain b (the closure forward) makes it, chain a reads it
+  // behind an event -- 8-30 us less at the head of the chain everything after the forwards waits for
+  struct PackShare {
+    const lshm_engine* e;
+    PackShare(const lshm_engine* en, const float* packed, bool on) : e(en) {
+      if (on) { e->pack_event = e->take_event(); share = packed; }
+    }
+    ~PackShare() { e->pack_override = nullptr; e->skip_pack = false; e->pack_event = nullptr; }
+    void chain_a(bool in) const { e->pack_override = in ? share : nullptr; e->skip_pack = in && share; }
+    const float* share = nullptr;
+  } pack_share(e, ws_b + e->o_pack2d, e->deep2d && !sched(LSHM_SCHED_NO_SHARED_PACK));
   for (int i = 0; i < n; ++i) {
     {
+      pack_share.chain_a(true);
+      struct Leave { const PackShare& p; ~Leave() { p.chain_a(false); } } leave{pack_share};
       if (fused_a && (size_t)i == P.resid_mark) {
         // (nothing: the residual is formed on the fly by the next step)
       } else if (skip_a_1d_output && (size_t)i == P.output1d_mark) {
