@@ -1032,8 +1032,10 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
   const lshm_engine::FwdPlan& P = forward_plan(e, prm, x, uv);
   const int n = (int)P.steps.size();
   int rc;
-  // two chains side by side: the deep sections take two patches per workgroup, so that each chain's launch fills half of
-  // the CUs and every weight fetched from L2 serves two patches (bit for bit the one-patch results)
+  // two chains side by side: the closure chain's deep section takes two patches per workgroup (half of the CUs, every weight
+  // fetched from L2 serves two patches; bit for bit the one-patch results), the no-grad chain's -- the one the reconstruction pass
+  // and the backward wait for -- one patch per workgroup on all CUs (100 us alone against 145): no-grad / closure = 2/2, 1/2, 2/1,
+  // 1/1 patches: 1.754 / 1.743 / 1.757 / 1.780 ms per iteration (profiles/r04/README.md)
   struct VariantScope {
     lshm_engine* e;
     explicit VariantScope(lshm_engine* en) : e(en) { e->deep_variant = 1; }
@@ -1062,7 +1064,8 @@ static int two_forwards(lshm_engine* e, const float* prm, const float* x, const 
   for (int i = 0; i < n; ++i) {
     {
       pack_share.chain_a(true);
-      struct Leave { const PackShare& p; ~Leave() { p.chain_a(false); } } leave{pack_share};
+      e->deep_variant = 0;  // (the no-grad chain: one patch per workgroup, see above)
+      struct Leave { const PackShare& p; lshm_engine* e; ~Leave() { p.chain_a(false); e->deep_variant = 1; } } leave{pack_share, e};
       if (fused_a && (size_t)i == P.resid_mark) {
         // (nothing: the residual is formed on the fly by the next step)
       } else if (skip_a_1d_output && (size_t)i == P.output1d_mark) {
