@@ -820,7 +820,8 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
   // the decoder's and the dense layers' closing sums go now (side stream, behind their producers): the
   // tail after the last weight gradient then only has the encoder's
   // (deepb: the dense batch joins the batched conv launch on the data-gradient stream, which has only conv1's kernel left;
-  //  the weight-gradient stream keeps the two direct kernels and the closing sums)
+  //  the weight-gradient stream keeps the two direct kernels and the closing sums; the dense batch on the latent-space stream
+  //  instead, beside conv1's kernel: +0.03 ms, profiles/r04/README.md)
   if (deepb && side && jobs.batch_conv) main_wgrads.insert(main_wgrads.begin(), [&jobs, st]() { return grad_jobs_launch_dense(jobs, st); });
   else pending.push_back([&]() { return grad_jobs_launch_dense(jobs, wst); });
   if ((rc = release(true))) return rc;
@@ -897,6 +898,24 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
       fused_tail = true;
       for (int g = 0; g < G; ++g) dz[g] = dx[g];
       continue;
+    }
+    if (i == 0 && G == 1 && a0.ndim == 2 && side && e->lstream && !dinput[0] && !e->in_capture) {
+      // the first layer's weight gradient -- the last kernel of the iteration's longer stream -- on the latent-space stream, idle by
+      // now: it runs beside the weight-gradient stream's closing sums instead of behind them; the last round of sums waits for it
+      if ((rc = release(true))) return rc;
+      hipEvent_t ev = e->take_event();
+      if (hipEventRecord(ev, st) != hipSuccess || hipStreamWaitEvent(e->lstream, ev, 0) != hipSuccess) {
+        set_last_error("engine: stream fork failed");
+        return LSHM_ERR_ARG;
+      }
+      if ((rc = conv_layer_wgrad(a0.enc[i], wg[0], nullptr, 0, 0, e->lstream, nullptr, &jobs))) return rc;
+      hipEvent_t ev2 = e->take_event();
+      if (hipEventRecord(ev2, e->lstream) != hipSuccess || hipStreamWaitEvent(wst, ev2, 0) != hipSuccess) {
+        set_last_error("engine: stream join failed");
+        return LSHM_ERR_ARG;
+      }
+      fused_tail = false;
+      break;
     }
     pending.push_back([&, i, w0 = wg[0], w1 = wg[1]]() {
       return conv_layer_wgrad(a0.enc[i], w0, nullptr, 0, 0, wst, G > 1 ? &w1 : nullptr, &jobs);
