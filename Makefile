@@ -29,6 +29,14 @@ oracle/_build/liblshm_oracle_c.so: oracle/lshm_oracle_c.c
 	@mkdir -p oracle/_build
 	gcc -O2 -fPIC -shared -fopenmp -o $@ $< -lm
 
+# the C restatement under AddressSanitizer + UndefinedBehaviorSanitizer (CPU only: the pool has no GPU sanitizer, the HIP library no CPU build)
+sanitize: oracle/_build/oracle_asan
+	ASAN_OPTIONS=detect_leaks=1:abort_on_error=0 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 ./oracle/_build/oracle_asan
+
+oracle/_build/oracle_asan: oracle/sanitize_main.c oracle/lshm_oracle_c.c
+	@mkdir -p oracle/_build
+	gcc -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -Wall -Wno-unknown-pragmas -o $@ oracle/sanitize_main.c -lm
+
 # test infrastructure: a host-shared-memory stand-in for RCCL (two ranks on one GPU, tests/test_gpu_dp.py)
 testlibs: tests/fake_rccl/libfake_rccl.so
 
@@ -38,4 +46,4 @@ tests/fake_rccl/libfake_rccl.so: tests/fake_rccl/fake_rccl.cpp
 clean:
 	rm -rf build lshm_amd/lib oracle/_build tests/fake_rccl/libfake_rccl.so
 
-.PHONY: all oracle testlibs clean
+.PHONY: all oracle testlibs clean sanitize

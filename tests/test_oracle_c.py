@@ -100,3 +100,14 @@ def test_fft_features(lib):
     lib.oc_fft2_features(fp(r), fp(re), fp(im), 2, 128, C.c_double(10.0))
     ref = O.fft_features(r)
     assert torch.allclose(re, ref[0, :2], atol=2e-5) and torch.allclose(im, ref[0, 2:], atol=2e-5)
+
+
+def test_c_oracle_is_clean_under_sanitizers():
+    """`make sanitize`: every function of the C restatement on exactly-sized heap buffers under AddressSanitizer +
+    UndefinedBehaviorSanitizer (oracle/sanitize_main.c).  CPU only -- the GPU pool offers no sanitizer and the HIP library
+    has no CPU build; the checker itself must at least be free of out-of-bounds reads."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-s", "sanitize"], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "sanitize_main: ok" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr
