@@ -350,10 +350,10 @@ def test_full_size_two_stream_schedule_equals_single_stream():
 
 @pytest.mark.parametrize("precision", ["fp32", "bf16s"], ids=["fp32", "bf16-storage"])
 def test_fused_backward_of_outer_1d_layer_matches_separate_kernels(precision):
-    """conv1d_bwd_fused_kernel (weight + bias + data gradient of netT / netF's last decoder layer from one pass,
-    src/lofar_models.py:141-142 backward) against the two kernels it replaces (LSHM_SCHED_NO_ONE_PASS_BWD), full size:
-    the weight and bias gradients of that layer come from the same MFMA sequence (bitwise equal); everything
-    upstream of its data gradient agrees to fp32 rounding (another summation order over the 16 taps x channels)."""
+    """The one-pass backward kernels of the outer layers (weight + bias + data gradient from one pass, src/lofar_models.py:115-117,
+    140-142 backward) against the separate kernels they replace (LSHM_SCHED_NO_ONE_PASS_BWD), full size: everything agrees to
+    fp32 rounding (other summation orders).  netT / netF's LAST layer is not part of the switch any more (round 4: its backward
+    runs on the tiles of the reconstruction pass in every schedule, lshm_tconv5_pair_bwd): its gradients are bitwise equal."""
     g = torch.Generator().manual_seed(23)
     x = torch.randn(256, 4, 128, 128, generator=g)
     uv = 1000.0 * torch.randn(256, 2, generator=g)
@@ -378,6 +378,39 @@ def test_fused_backward_of_outer_1d_layer_matches_separate_kernels(precision):
     tol = 2e-5 if precision == "fp32" else 1e-3
     for name in tr.layout:
         assert rel_err(tr.view(name, grads[0]), tr.view(name, grads[1])) < tol, name
+
+
+@pytest.mark.parametrize("off", [("no_recon_bwd5",), ("no_conv0_bwd_tile",), ("no_resid_conv0_keep",), ("no_shared_pack",),
+                                 ("no_recon_bwd5", "no_conv0_bwd_tile", "no_resid_conv0_keep", "no_resid_conv0", "no_shared_pack")],
+                         ids=["recon_bwd5", "conv0_bwd_tile", "resid_conv0_keep", "shared_pack", "all-image-tile-kernels"])
+def test_image_tile_kernels_of_the_1d_pair_in_the_step(off):
+    """Two full-size ADMM iterations (B = 256) with the round-4 image-tile kernels around the residual against the
+    same iterations with the launches they replace (schedule bits): parameters, multipliers and the logged terms.  The forward
+    forms are bitwise (so `no_resid_conv0_keep` and `no_shared_pack` give the same bits); the backward forms sum in another
+    order: fp32 rounding through two Adam steps."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(256, 4, 128, 128, generator=g)
+    uv = 1000.0 * torch.randn(256, 2, generator=g)
+    out = []
+    for sched in ((), off):
+        tr = _full_trainer(schedule_off=sched)
+        tr.new_minibatch(x.to(DEV), uv.to(DEV))
+        for _ in range(2):
+            tr.step()
+        torch.cuda.synchronize()
+        out.append((tr.params.clone(), [t.clone() for t in tr.y], tr.read_terms()))
+    (p0, y0, t0), (p1, y1, t1) = out
+    bitwise = set(off) <= {"no_resid_conv0_keep", "no_shared_pack"}
+    if bitwise:
+        assert torch.equal(p0, p1) and all(torch.equal(a, b) for a, b in zip(y0, y1))
+    else:
+        # Adam's first steps move every parameter by ~lr whatever the gradient's size: a last-bit difference of a tiny gradient can
+        # flip the sign of its update, so the parameters are compared in units of the step size
+        assert (p0 - p1).abs().max().item() <= 2.5 * 2 * tr.cfg.lr
+        assert rel_err(p0, p1) < 1e-4
+        for a, b in zip(y0, y1):
+            assert rel_err(a, b) < 1e-5
+    assert abs(t0["total"] - t1["total"]) <= 1e-5 * abs(t0["total"])
 
 
 @pytest.mark.parametrize("K,precision,tol", [(10, "fp32", 5e-5), (64, "fp32", 5e-5), (10, "bf16", 5e-5), (10, "bf16s", 5e-5)],
