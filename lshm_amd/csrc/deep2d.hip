@@ -191,16 +191,57 @@ constexpr int kPF = 8;                   // float4 registers of the cross-barrie
 
 // A weight slot is the four values a lane consumes in one step: a float4, or (bf16 operand precision, BASELINE configs[2]) four
 // bf16 in 8 bytes -- half the L2 stream; widened to fp32 registers on arrival (a shift), fp32 products and accumulation.
+// (round 4, second half: the bf16 slot stays bf16 in registers and goes into v_mfma_f32_16x16x16_bf16 / 4x4x4_bf16 as it is; the four
+// activations it meets are rounded to bf16 -- the operand precision of BASELINE configs[2], as in the implicit GEMMs' bf16 form --
+// one matrix instruction instead of four.  fp32 slots: the instruction sequence of before, bit for bit.)
+typedef short s16x4 __attribute__((ext_vector_type(4)));  // operand registers of the bf16 matrix instructions
 __device__ __forceinline__ f32x4 wload(const f32x4* __restrict__ p) { return *p; }
-__device__ __forceinline__ f32x4 wload(const bf16x4* __restrict__ p) { return __builtin_convertvector(*p, f32x4); }
+__device__ __forceinline__ bf16x4 wload(const bf16x4* __restrict__ p) { return *p; }
+__device__ __forceinline__ f32x4 wide(const f32x4& w) { return w; }
+__device__ __forceinline__ f32x4 wide(const bf16x4& w) { return __builtin_convertvector(w, f32x4); }
+__device__ __forceinline__ s16x4 op_bits(const bf16x4& v) { return __builtin_bit_cast(s16x4, v); }
+__device__ __forceinline__ s16x4 op_pack(float a0, float a1, float a2, float a3) {
+  return op_bits(__builtin_convertvector((f32x4){a0, a1, a2, a3}, bf16x4));
+}
+// four k-steps of one 16 x 16 accumulator tile: activations a0..a3 against the slot's four values
+__device__ __forceinline__ f32x4 mma16(float a0, float a1, float a2, float a3, const f32x4& w, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, w[2], acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a3, w[3], acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma16(float a0, float a1, float a2, float a3, const bf16x4& w, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(op_pack(a0, a1, a2, a3), op_bits(w), acc, 0, 0, 0);
+}
+// two k-steps: activations a0, a1 against values IA, IB of the slot (the transposed convolutions' column parities)
+template <int IA, int IB>
+__device__ __forceinline__ f32x4 mma16_2(float a0, float a1, const f32x4& w, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w[IA], acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w[IB], acc, 0, 0, 0);
+}
+template <int IA, int IB>
+__device__ __forceinline__ f32x4 mma16_2(float a0, float a1, const bf16x4& w, f32x4 acc) {
+  const bf16x4 wv = {w[IA], w[IB], (bf16)0.f, (bf16)0.f};
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(op_pack(a0, a1, 0.f, 0.f), op_bits(wv), acc, 0, 0, 0);
+}
+// four k-steps of the 16 independent 4 x 4 blocks
+__device__ __forceinline__ f32x4 mma4(float a0, float a1, float a2, float a3, const f32x4& w, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a0, w[0], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a1, w[1], acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a2, w[2], acc, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_4x4x1f32(a3, w[3], acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mma4(float a0, float a1, float a2, float a3, const bf16x4& w, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(op_pack(a0, a1, a2, a3), op_bits(w), acc, 0, 0, 0);
+}
 template <int NB, class W4>
-__device__ __forceinline__ void load_batch(f32x4 (&q)[NB], const W4* __restrict__ p, int s0, int nsteps) {
+__device__ __forceinline__ void load_batch(W4 (&q)[NB], const W4* __restrict__ p, int s0, int nsteps) {
 #pragma unroll
-  for (int k = 0; k < NB; ++k) q[k] = s0 + k < nsteps ? wload(p + (long)(s0 + k) * 64) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < NB; ++k) q[k] = s0 + k < nsteps ? wload(p + (long)(s0 + k) * 64) : W4{};
 }
 // the first NB steps of a wavefront's first unit of a stage, requested ahead of the barrier in front of the stage
 template <int NB, class W4>
-__device__ __forceinline__ void prefetch(f32x4 (&pf)[kPF], const W4* __restrict__ p, bool on) {
+__device__ __forceinline__ void prefetch(W4 (&pf)[kPF], const W4* __restrict__ p, bool on) {
   static_assert(NB <= kPF, "prefetch registers");
   if (on) {
 #pragma unroll
@@ -209,9 +250,9 @@ __device__ __forceinline__ void prefetch(f32x4 (&pf)[kPF], const W4* __restrict_
 }
 // NS steps of one unit: body(step, float4); `first`: the steps 0..NB-1 are already in pf
 template <int NS, int NB, class W4, class Body>
-__device__ __forceinline__ void stream_unit(const W4* __restrict__ wq, const f32x4 (&pf)[kPF], bool first, Body body) {
+__device__ __forceinline__ void stream_unit(const W4* __restrict__ wq, const W4 (&pf)[kPF], bool first, Body body) {
   static_assert(NS % NB == 0, "whole batches");
-  f32x4 cur[NB], nxt[NB];
+  W4 cur[NB], nxt[NB];
   if (first) {
 #pragma unroll
     for (int k = 0; k < NB; ++k) cur[k] = pf[k];
@@ -232,7 +273,7 @@ __device__ __forceinline__ void stream_unit(const W4* __restrict__ wq, const f32
 template <int G, int NW, int N, int NG, int SPK, int NB, class W4>
 __device__ __forceinline__ void dense_units(const float* __restrict__ xv /* RV + x offset, patch stride RV_F */,
                                             const W4* __restrict__ wp4, float* __restrict__ slab, const float* __restrict__ bias,
-                                            const f32x4 (&pf)[kPF]) {
+                                            const W4 (&pf)[kPF]) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   constexpr int NGP = NG * 64;
   for (int u = wave; u < NG * 4; u += NW) {
@@ -242,7 +283,8 @@ __device__ __forceinline__ void dense_units(const float* __restrict__ xv /* RV +
     const float bv = (bias && kg == 0 && n < N) ? bias[n] : 0.f;
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = bv;
-    stream_unit<SPK, NB>(wq, pf, u == wave, [&](int s, const f32x4& w4) {
+    stream_unit<SPK, NB>(wq, pf, u == wave, [&](int s, const W4& wraw) {
+      const f32x4 w4 = wide(wraw);  // (the dense stages multiply in fp32 in both forms)
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const f32x4 x = *reinterpret_cast<const f32x4*>(xv + g * RV_F + 4 * (kg * SPK + s));
@@ -292,7 +334,7 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
     if (BWD) return saved ? v * elu_grad_from_out(saved[idx]) : v;
     return elu(v);
   };
-  f32x4 pf[kPF];
+  W4 pf[kPF];
   stamp();
 
   // first units of the stages, by wavefront (for the cross-barrier prefetch)
@@ -338,7 +380,7 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
     const f32x4 b4v = splat((!BWD && kg == 0) ? a.b3[16 * nt + lm] : 0.f);
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g][0] = acc[g][1] = b4v;
-    stream_unit<12, 4>(wq_conv3(u), pf, u == wave, [&](int s, const f32x4& w4) {
+    stream_unit<12, 4>(wq_conv3(u), pf, u == wave, [&](int s, const W4& w4) {
       const int ci = 12 * kg + s;
 #pragma unroll
       for (int g = 0; g < G; ++g)
@@ -347,10 +389,7 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
           const int oy = 2 * (2 * mh + mi) + (lm >> 3), ox = lm & 7;
           const float* ap = RA + g * RA_F + ci * X2_CP + (2 * oy + lk) * X2_RP + 2 * ox;
           const float2 a01 = *reinterpret_cast<const float2*>(ap), a23 = *reinterpret_cast<const float2*>(ap + 2);
-          acc[g][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a01.x, w4[0], acc[g][mi], 0, 0, 0);
-          acc[g][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a01.y, w4[1], acc[g][mi], 0, 0, 0);
-          acc[g][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a23.x, w4[2], acc[g][mi], 0, 0, 0);
-          acc[g][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a23.y, w4[3], acc[g][mi], 0, 0, 0);
+          acc[g][mi] = mma16(a01.x, a01.y, a23.x, a23.y, w4, acc[g][mi]);
         }
     });
 #pragma unroll
@@ -382,17 +421,14 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
     const f32x4 b4v = splat((!BWD && kg == 0) ? a.b4[16 * nt + lm] : 0.f);
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = b4v;
-    stream_unit<24, 8>(wq_conv4(u), pf, u == wave, [&](int s, const f32x4& w4) {
+    stream_unit<24, 8>(wq_conv4(u), pf, u == wave, [&](int s, const W4& w4) {
       const int ci = 24 * kg + s;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int oy = lm >> 2, ox = lm & 3;
         const float* ap = RX + g * RX_F + ci * X3_CP + (2 * oy + lk) * X3_RP + 2 * ox;
         const float2 a01 = *reinterpret_cast<const float2*>(ap), a23 = *reinterpret_cast<const float2*>(ap + 2);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a01.x, w4[0], acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a01.y, w4[1], acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a23.x, w4[2], acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a23.y, w4[3], acc[g], 0, 0, 0);
+        acc[g] = mma16(a01.x, a01.y, a23.x, a23.y, w4, acc[g]);
       }
     });
 #pragma unroll
@@ -432,13 +468,12 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = b4v;
     const int oy = (lane >> 1) & 1, ox = lane & 1;
-    stream_unit<96, 8>(wq_conv5(u), pf, u == wave, [&](int s, const f32x4& w4) {
+    stream_unit<96, 8>(wq_conv5(u), pf, u == wave, [&](int s, const W4& w4) {
       const int ci = 24 * kg + (s >> 2), ky = s & 3;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(RS + g * RS_F + ci * X4_CP + (2 * oy + ky) * 8 + 4 * ox);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[e], w4[e], acc[g], 0, 0, 0);
+        acc[g] = mma4(av[0], av[1], av[2], av[3], w4, acc[g]);
       }
     });
 #pragma unroll
@@ -551,16 +586,13 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = b4v;
     const int aoff = (iy + py) * 8 + 2 * (ix + px);  // rows iy + py - 1 + j, column pair (ix + px - 1, ix + px), padded by one
-    stream_unit<96, 8>(wq_tconv0(u), pf, u == wave, [&](int s, const f32x4& w4) {
+    stream_unit<96, 8>(wq_tconv0(u), pf, u == wave, [&](int s, const W4& w4) {
       const int ci = 96 * kg + s;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float* ap = RS + g * RS_F + ci * D0_CP + aoff;
         const float2 r0 = *reinterpret_cast<const float2*>(ap), r1 = *reinterpret_cast<const float2*>(ap + 8);
-        acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.x, w4[0], acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(r0.y, w4[1], acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.x, w4[2], acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(r1.y, w4[3], acc[g], 0, 0, 0);
+        acc[g] = mma4(r0.x, r0.y, r1.x, r1.y, w4, acc[g]);
       }
     });
 #pragma unroll
@@ -599,17 +631,15 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
     const f32x4 b4v = splat((!BWD && kg == 0) ? a.bt1[co] : 0.f);
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g][0] = acc[g][1] = b4v;
-    stream_unit<24, 8>(wq_tconv1(u), pf, u == wave, [&](int s, const f32x4& w4) {
+    stream_unit<24, 8>(wq_tconv1(u), pf, u == wave, [&](int s, const W4& w4) {
       const int ci = 4 * (12 * kg + (s >> 1)) + lk, jy = s & 1;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const float* ap = RS + g * RS_F + ci * T0_CP + (iy + py + jy) * T0_RP + ix;  // padded columns ix, ix + 1, ix + 2
         const float am = ap[0], a0 = ap[1], a1 = ap[2];
         // column parity 0: columns ix - 1, ix through kernel columns 3, 1; parity 1: columns ix, ix + 1 through 2, 0
-        acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, w4[3], acc[g][0], 0, 0, 0);
-        acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w4[1], acc[g][0], 0, 0, 0);
-        acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w4[2], acc[g][1], 0, 0, 0);
-        acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w4[0], acc[g][1], 0, 0, 0);
+        acc[g][0] = mma16_2<3, 1>(am, a0, w4, acc[g][0]);
+        acc[g][1] = mma16_2<2, 0>(a0, a1, w4, acc[g][1]);
       }
     });
 #pragma unroll
@@ -651,7 +681,7 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
     const f32x4 b4v = splat((!BWD && co < 24) ? a.bt2[co] : 0.f);
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g][0] = acc[g][1] = b4v;
-    stream_unit<12, 4>(wq_tconv2(u), pf, u == wave, [&](int s, const f32x4& w4) {
+    stream_unit<12, 4>(wq_tconv2(u), pf, u == wave, [&](int s, const W4& w4) {
       const int ci = 4 * s + lk;
 #pragma unroll
       for (int g = 0; g < G; ++g)
@@ -659,10 +689,7 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
         for (int mi = 0; mi < 2; ++mi) {
           const int iy = 2 * (2 * mh + mi) + (lm >> 3), ix = lm & 7;
           const float* ap = RX + g * RX_F + ci * T1_CP + (iy + py) * T1_RP + ix + px;  // rows iy + py - 1 + j, columns ix + px - 1 + j
-          acc[g][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[0], w4[0], acc[g][mi], 0, 0, 0);
-          acc[g][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[1], w4[1], acc[g][mi], 0, 0, 0);
-          acc[g][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[T1_RP], w4[2], acc[g][mi], 0, 0, 0);
-          acc[g][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[T1_RP + 1], w4[3], acc[g][mi], 0, 0, 0);
+          acc[g][mi] = mma16(ap[0], ap[1], ap[T1_RP], ap[T1_RP + 1], w4, acc[g][mi]);
         }
     });
     if (co < 24) {
@@ -708,7 +735,7 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
     const f32x4 b4v = splat((!BWD && lm < 12) ? a.bt3[lm] : 0.f);
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g][0][0] = acc[g][0][1] = acc[g][1][0] = acc[g][1][1] = b4v;
-    stream_unit<12, 4>(wq_tconv3(u), pf, u == wave, [&](int s, const f32x4& w4) {
+    stream_unit<12, 4>(wq_tconv3(u), pf, u == wave, [&](int s, const W4& w4) {
       const int ci = 4 * (s >> 1) + lk, jy = s & 1;
 #pragma unroll
       for (int g = 0; g < G; ++g)
@@ -717,10 +744,8 @@ __global__ __launch_bounds__(THREADS) void deep2d_kernel(const Deep2dArgs a) {
           const int iy = 2 * mq + mi;
           const float* ap = RA + g * RA_F + ci * X2_CP + (iy + py + jy) * X2_RP + lm;  // padded columns ix, ix + 1, ix + 2 (ix = lm)
           const float am = ap[0], a0 = ap[1], a1 = ap[2];
-          acc[g][mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(am, w4[3], acc[g][mi][0], 0, 0, 0);
-          acc[g][mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w4[1], acc[g][mi][0], 0, 0, 0);
-          acc[g][mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, w4[2], acc[g][mi][1], 0, 0, 0);
-          acc[g][mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, w4[0], acc[g][mi][1], 0, 0, 0);
+          acc[g][mi][0] = mma16_2<3, 1>(am, a0, w4, acc[g][mi][0]);
+          acc[g][mi][1] = mma16_2<2, 0>(a0, a1, w4, acc[g][mi][1]);
         }
     });
     f32x4 sv[G][2][2];  // backward: the saved activation at the lane's eight outputs per row, (requested after the matrix work: ahead of it the registers spill)

@@ -654,21 +654,24 @@ def _deep2d_problem(nb, seed):
     return w, b, x2, uv1, uv3
 
 
-def _deep2d_reference(w, b, x2, uv1, uv3, dt):
+def _deep2d_reference(w, b, x2, uv1, uv3, dt, bf16_operands=False):
+    """bf16_operands: the convolution stages multiply on the bf16 matrix cores -- their input activations are rounded to bf16
+    (the dense stages multiply in fp32)."""
     c = lambda t: t.to(dt)
-    a3 = TF.elu(TF.conv2d(c(x2), c(w[0]), c(b[0]), stride=2, padding=1))
-    a4 = TF.elu(TF.conv2d(a3, c(w[1]), c(b[1]), stride=2, padding=1))
-    a5 = TF.elu(TF.conv2d(a4, c(w[2]), c(b[2]), stride=2, padding=1))
+    q = (lambda t: t.to(torch.bfloat16).to(dt)) if bf16_operands else (lambda t: t)
+    a3 = TF.elu(TF.conv2d(q(c(x2)), c(w[0]), c(b[0]), stride=2, padding=1))
+    a4 = TF.elu(TF.conv2d(q(a3), c(w[1]), c(b[1]), stride=2, padding=1))
+    a5 = TF.elu(TF.conv2d(q(a4), c(w[2]), c(b[2]), stride=2, padding=1))
     cat1 = torch.cat([a5.flatten(1), c(uv1)], 1)
     z1 = TF.elu(TF.linear(cat1, c(w[3]), c(b[3])))
     mu = TF.elu(TF.linear(z1, c(w[4]), c(b[4])))
     h = TF.elu(TF.linear(mu, c(w[5]), c(b[5])))
     cat3 = torch.cat([h, c(uv3)], 1)
     d0 = TF.linear(cat3, c(w[6]), c(b[6]))
-    t0 = TF.elu(TF.conv_transpose2d(d0.view(-1, 192, 2, 2), c(w[7]), c(b[7]), stride=2, padding=1))
-    t1 = TF.elu(TF.conv_transpose2d(t0, c(w[8]), c(b[8]), stride=2, padding=1))
-    t2 = TF.elu(TF.conv_transpose2d(t1, c(w[9]), c(b[9]), stride=2, padding=1))
-    t3 = TF.elu(TF.conv_transpose2d(t2, c(w[10]), c(b[10]), stride=2, padding=1))
+    t0 = TF.elu(TF.conv_transpose2d(q(d0).view(-1, 192, 2, 2), c(w[7]), c(b[7]), stride=2, padding=1))
+    t1 = TF.elu(TF.conv_transpose2d(q(t0), c(w[8]), c(b[8]), stride=2, padding=1))
+    t2 = TF.elu(TF.conv_transpose2d(q(t1), c(w[9]), c(b[9]), stride=2, padding=1))
+    t3 = TF.elu(TF.conv_transpose2d(q(t2), c(w[10]), c(b[10]), stride=2, padding=1))
     return [a3, a4, cat1, z1, mu, cat3, d0, t0, t1, t2, t3]
 
 
@@ -702,11 +705,14 @@ def test_deep_section_of_the_2d_autoencoder_as_one_launch(variant, nb):
         assert torch.isfinite(o).all(), k
     # fp64 on whole samples (first / last patch, both patches of a two-patch workgroup)
     idx = [i for i in SAMPLES if i < nb] if nb > 5 else list(range(nb))
-    # variants 4, 5 stream bf16 copies of the weights (fp32 activations, products and sums): fp64 on the rounded weights
+    # variants 4, 5 stream bf16 copies of the weights into the bf16 matrix instructions (v_mfma_f32_16x16x16_bf16 / 4x4x4_bf16: the
+    # activations a convolution stage multiplies are rounded to bf16 too; fp32 sums, fp32 dense stages): fp64 with the same roundings.
+    # An activation within fp32 rounding of a bf16 rounding boundary rounds the other way in fp64 (4e-3 of that element), and every
+    # stage inherits the flips of the stages before it: 1e-5 at the first stage, 6e-4 at the ninth (a wrong index would give O(1))
     wref = [t.bfloat16().float() for t in w] if variant & 4 else w
-    ref = _deep2d_reference(wref, b, x2[idx], uv1[idx], uv3[idx], torch.float64)
+    ref = _deep2d_reference(wref, b, x2[idx], uv1[idx], uv3[idx], torch.float64, bf16_operands=bool(variant & 4))
     for k, (o, r) in enumerate(zip(got, ref)):
-        assert rel_err(o[idx].cpu().double().reshape(r.shape), r) < 2e-5, (variant, k)
+        assert rel_err(o[idx].cpu().double().reshape(r.shape), r) < (2e-3 if variant & 4 else 2e-5), (variant, k)
     if variant & 4:
         return
     # the separate launches of the library (implicit GEMMs with their own summation order)
@@ -781,15 +787,17 @@ def _eg(y):
     return torch.where(y > 0, torch.ones_like(y), y + 1.0)
 
 
-def _deep2d_bwd_reference(w, saved, g_t2, gmu, dt):
+def _deep2d_bwd_reference(w, saved, g_t2, gmu, dt, bf16_operands=False):
     """The data-gradient pass through tconv2 .. conv2 of AutoEncoderCNN2 written out: the data gradient of a k4 s2 p1
-    transposed conv is the conv with the same tensor and vice versa (autograd of src/lofar_models.py:73-98)."""
+    transposed conv is the conv with the same tensor and vice versa (autograd of src/lofar_models.py:73-98).
+    bf16_operands: the convolution stages' input gradients are rounded to bf16 (bf16 matrix instructions)."""
     c = lambda t: t.to(dt)
+    q = (lambda t: t.to(torch.bfloat16).to(dt)) if bf16_operands else (lambda t: t)
     c2, c3, c4, c5, fc1, fc2in, fc2out, fc3, t0, t1, t2, _t3 = [c(t) for t in w]
     s_t1, s_t0, s_cat3, s_mu, s_z1, s_cat1, s_c4, s_c3, s_c2, s_c1 = [c(t) for t in saved]
-    g_t1 = TF.conv2d(c(g_t2), t2, None, stride=2, padding=1) * _eg(s_t1)
-    g_t0 = TF.conv2d(g_t1, t1, None, stride=2, padding=1) * _eg(s_t0)
-    g_d0 = TF.conv2d(g_t0, t0, None, stride=2, padding=1).flatten(1)
+    g_t1 = TF.conv2d(q(c(g_t2)), t2, None, stride=2, padding=1) * _eg(s_t1)
+    g_t0 = TF.conv2d(q(g_t1), t1, None, stride=2, padding=1) * _eg(s_t0)
+    g_d0 = TF.conv2d(q(g_t0), t0, None, stride=2, padding=1).flatten(1)
     g_cat3 = (g_d0 @ fc3) * _eg(s_cat3)
     g_mu = g_cat3[:, :224] @ fc2out
     if gmu is not None:
@@ -797,10 +805,10 @@ def _deep2d_bwd_reference(w, saved, g_t2, gmu, dt):
     g_mu = g_mu * _eg(s_mu)
     g_z1 = (g_mu @ fc2in) * _eg(s_z1)
     g_cat1 = (g_z1 @ fc1) * _eg(s_cat1)
-    g_c4 = TF.conv_transpose2d(g_cat1[:, :768].reshape(-1, 192, 2, 2), c5, None, stride=2, padding=1) * _eg(s_c4)
-    g_c3 = TF.conv_transpose2d(g_c4, c4, None, stride=2, padding=1) * _eg(s_c3)
-    g_c2 = TF.conv_transpose2d(g_c3, c3, None, stride=2, padding=1) * _eg(s_c2)
-    g_c1 = TF.conv_transpose2d(g_c2, c2, None, stride=2, padding=1) * _eg(s_c1)
+    g_c4 = TF.conv_transpose2d(q(g_cat1[:, :768]).reshape(-1, 192, 2, 2), c5, None, stride=2, padding=1) * _eg(s_c4)
+    g_c3 = TF.conv_transpose2d(q(g_c4), c4, None, stride=2, padding=1) * _eg(s_c3)
+    g_c2 = TF.conv_transpose2d(q(g_c3), c3, None, stride=2, padding=1) * _eg(s_c2)
+    g_c1 = TF.conv_transpose2d(q(g_c2), c2, None, stride=2, padding=1) * _eg(s_c1)
     return [g_t1, g_t0, g_d0, g_cat3, g_mu, g_z1, g_cat1, g_c4, g_c3, g_c2, g_c1]
 
 
@@ -856,9 +864,9 @@ def test_deep_section_backward_as_one_launch(variant, nb):
         assert torch.isfinite(o).all(), k
     idx = [i for i in SAMPLES if i < nb] if nb > 5 else list(range(nb))
     wref = [t.bfloat16().float() for t in w] if variant & 4 else w  # (variant 4: bf16 copies of the weights are streamed)
-    ref = _deep2d_bwd_reference(wref, [t[idx] for t in saved], g_t2[idx], gmu[idx], torch.float64)
+    ref = _deep2d_bwd_reference(wref, [t[idx] for t in saved], g_t2[idx], gmu[idx], torch.float64, bf16_operands=bool(variant & 4))
     for k, (o, r) in enumerate(zip(got, ref)):
-        assert rel_err(o[idx].cpu().double().reshape(r.shape), r) < 3e-5, (variant, k)
+        assert rel_err(o[idx].cpu().double().reshape(r.shape), r) < (2e-3 if variant & 4 else 3e-5), (variant, k)
     if variant & 4:
         return
     # the separate launches of the library (no latent-term gradient: the C entry of the dense data gradient has no addend)
