@@ -225,7 +225,9 @@ __global__ __launch_bounds__(NT, 4) void conv0_bwd_tile_kernel(const Conv0BwdTil
 }
 
 bool conv0_bwd_tile_supported(int C, int Pp, int Cin, int Cout, int L1d, long in_bs) {
-  return !sched(LSHM_SCHED_NO_CONV0_BWD_TILE) && C == CI && Pp == P && Cin == CI && Cout == CO && L1d == L && in_bs == (long)CI * L;
+  // (the schedule is decided where the plan is built: a device whose workgroups cannot hold the tile takes the separate launches)
+  return !sched(LSHM_SCHED_NO_CONV0_BWD_TILE) && C == CI && Pp == P && Cin == CI && Cout == CO && L1d == L && in_bs == (long)CI * L &&
+         device_lds_fits(sizeof(float) * (CI * RCH + CO * ZTP + CO * ZFP + NW));
 }
 size_t conv0_bwd_tile_workspace_floats() { return (size_t)MAX_GRID * SLAB; }
 

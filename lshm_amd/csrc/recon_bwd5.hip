@@ -242,7 +242,8 @@ __global__ __launch_bounds__(NT, 4) void recon_bwd5_kernel(const ReconBwd5Args a
 }
 
 bool recon_bwd5_supported(int Cc, int Pp, int Cin, int Cout, int Ls) {
-  return !sched(LSHM_SCHED_NO_RECON_BWD5) && Cc == C && Pp == P && Cin == CA && Cout == C && Ls == LA;
+  return !sched(LSHM_SCHED_NO_RECON_BWD5) && Cc == C && Pp == P && Cin == CA && Cout == C && Ls == LA &&
+         device_lds_fits(sizeof(float) * (2 * C * GP + 2 * CA * SP + (NT / 64) * 9));
 }
 size_t recon_bwd5_workspace_floats() { return (size_t)MAX_GRID * SLAB; }
 

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(NT) void resid_conv0_kernel(const ResidConv0Args a)
 }
 
 bool resid_conv0_supported(int C, int Pp, int Cin, int Cout, int L1d) {
-  return !sched(LSHM_SCHED_NO_RESID_CONV0) && C == CI && Pp == P && Cin == CI && Cout == CO && L1d == L;
+  return !sched(LSHM_SCHED_NO_RESID_CONV0) && C == CI && Pp == P && Cin == CI && Cout == CO && L1d == L &&
+         device_lds_fits(sizeof(float) * (CI * TS * PITCH + 2 * CI * TS));
 }
 
 template <class T, int KEEP>
