@@ -752,7 +752,10 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     // ... between the two streams: the data-gradient stream has only conv1's one-pass backward left, so a share of the
     // weight gradients follows that kernel there (bit k of the placement word: item k on the data-gradient stream)
     const bool batch_conv = !(c.schedule & LSHM_SCHED_NO_WGRAD_BATCH);
-    const unsigned on_main = (side && !batch_conv) ? e->wgrad_on_main : 0u;
+    // (batched: the batch goes to the weight-gradient stream right behind the chain, beside conv1's kernel; conv2's direct kernel
+    //  -- item 6 -- follows conv1's kernel and the dense batch on the data-gradient stream instead: 1.727 -> 1.715 ms per iteration
+    //  against the other way round, profiles/r04/README.md)
+    const unsigned on_main = (side && !batch_conv) ? e->wgrad_on_main : (side && batch_conv) ? (1u << 6) : 0u;
     int item = 0;
     auto conv_w = [&](const ConvLayer& Lr, const float* xin, const float* dzp, long wo, long bo) {
       const ConvWgradIO w0{xin, dzp, grd + wo, grd + bo};
@@ -768,10 +771,10 @@ static int ae_backward(const lshm_engine* e, int G, const int* idx, const float*
     conv_w(a0.enc[2], ws + a.act[1], ws + la.o_genc[3], a.cw[2], a.cb[2]);
     // the six implicit-GEMM ones park their problems; one launch runs them all
     jobs.batch_conv = batch_conv;
-    // ... on the DATA-gradient stream, behind conv1's one-pass backward (the only kernel that stream has left): the
-    // weight-gradient stream meanwhile runs conv2's and conv0's direct kernels and the dense batch, and one round of closing
-    // sums ends the pass (the two streams finish ~100 us after the chain instead of ~250)
-    if (jobs.batch_conv) main_wgrads.push_back([&jobs, st, wst, side]() { return grad_jobs_launch_conv(jobs, side ? st : wst); });
+    // ... on the weight-gradient stream right behind the chain (its closing sums join the mid-way round); the data-gradient stream,
+    // which has only conv1's one-pass backward left, then takes the dense batch and conv2's direct kernel, the latent-space stream
+    // conv0's (below): the three streams finish ~120 us after the chain instead of ~250
+    if (jobs.batch_conv) pending.push_back([&jobs, wst]() { return grad_jobs_launch_conv(jobs, wst); });
     enc_from = 1;
   }
   if (dense_chain && !deepb) {
