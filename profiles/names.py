@@ -27,4 +27,5 @@ def short(name: str) -> str:
                 else:
                     return ident + "<?>"
         return ident + ("<" + ", ".join(args) + ">" if args else "")
-    return n.replace("(anonymous namespace)::", "").replace("lshm::", "").replace("void ", "").split("(")[0]
+    # (rocprofv3's own demangler renders the vendor type DF16b of some instantiations as "bool _Accum")
+    return n.replace("(anonymous namespace)::", "").replace("lshm::", "").replace("void ", "").replace("bool _Accum", "__bf16").split("(")[0]
