@@ -790,6 +790,16 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
 }
 
 // ----------------------------------------------------------------------------------------------
+// bf16 storage (BASELINE configs[2]): the four taps of a kernel row meet the four values of a weight quad in ONE
+// v_mfma_f32_4x4x4_16B_bf16 (a lane's operand = its four k) instead of four v_mfma_f32_4x4x1_f32; the activations come from bf16
+// tensors (exact), or are rounded to bf16 on the way (the fp32 minibatch under conv0: the operand precision of that configuration),
+// the weights are rounded once per launch.  fp32 storage: the instruction sequence of before.
+typedef short q4_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ q4_s16x4 q4_bits(const bf16x4& v) { return __builtin_bit_cast(q4_s16x4, v); }
+__device__ __forceinline__ f32x4 q4_mma(float a0, float a1, float a2, float a3, const bf16x4& w, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(q4_bits(__builtin_convertvector((f32x4){a0, a1, a2, a3}, bf16x4)), q4_bits(w), acc, 0, 0, 0);
+}
+
 // Same op on v_mfma_f32_4x4x1_16b_f32 for conv0 (4 -> 8 channels; as a data gradient: tconv5).  The
 // 4x4x1 form runs 16 independent 4x4 outer products per instruction, D[lane l][r] += A[lane 4*(l/4)+r]
 // * B[lane l], at the same FLOP/clk as 16x16x4 - so 8 output channels are two full instructions instead
@@ -825,6 +835,12 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
 #pragma unroll
     for (int h = 0; h < NH; ++h)
       bw[ky][h] = *reinterpret_cast<const f32x4*>(w + (((long)(4 * h + q) * CIN + wave) * 4 + ky) * 4);
+  constexpr bool BF16_MMA = sizeof(TO) == 2;  // bf16 storage of the output: the bf16 configuration
+  bf16x4 bwh[4][NH];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) bwh[ky][h] = __builtin_convertvector(bw[ky][h], bf16x4);
   float bv[NH];
 #pragma unroll
   for (int h = 0; h < NH; ++h) bv[h] = bias ? bias[4 * h + q] : 0.f;
@@ -900,6 +916,12 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
         a01[r] = *reinterpret_cast<const float2*>(pr);
         a23[r] = *reinterpret_cast<const float2*>(pr + 2);
       }
+      if constexpr (BF16_MMA) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r)
+#pragma unroll
+          for (int h = 0; h < NH; ++h) acc[r][h] = q4_mma(a01[r].x, a01[r].y, a23[r].x, a23[r].y, bwh[ky][h], acc[r][h]);
+      } else {
 #pragma unroll
       for (int r = 0; r < TH; ++r)
 #pragma unroll
@@ -916,6 +938,7 @@ __global__ __launch_bounds__(256, 3) void conv2d_q4_kernel(const float* __restri
       for (int r = 0; r < TH; ++r)
 #pragma unroll
         for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a23[r].y, bw[ky][h][3], acc[r][h], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < TH; ++r)
@@ -987,6 +1010,12 @@ __global__ __launch_bounds__(256, 2) void tconv2d_bwd_fused_kernel(const float* 
 #pragma unroll
     for (int h = 0; h < NH; ++h)
       bw[ky][h] = *reinterpret_cast<const f32x4*>(w + (((long)(4 * h + q) * CB + wave) * 4 + ky) * 4);
+  constexpr bool BF16_MMA = sizeof(TB) == 2;  // the gradient image is a bf16 tensor: the bf16 configuration
+  bf16x4 bwh[4][NH];
+#pragma unroll
+  for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+    for (int h = 0; h < NH; ++h) bwh[ky][h] = __builtin_convertvector(bw[ky][h], bf16x4);
   f32x4 wacc[CB];
 #pragma unroll
   for (int j = 0; j < CB; ++j) wacc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1074,6 +1103,12 @@ __global__ __launch_bounds__(256, 2) void tconv2d_bwd_fused_kernel(const float* 
         a01[r] = *reinterpret_cast<const float2*>(pr);
         a23[r] = *reinterpret_cast<const float2*>(pr + 2);
       }
+      if constexpr (BF16_MMA) {
+#pragma unroll
+        for (int r = 0; r < TH; ++r)
+#pragma unroll
+          for (int h = 0; h < NH; ++h) acc[r][h] = q4_mma(a01[r].x, a01[r].y, a23[r].x, a23[r].y, bwh[ky][h], acc[r][h]);
+      } else {
 #pragma unroll
       for (int r = 0; r < TH; ++r)
 #pragma unroll
@@ -1090,6 +1125,7 @@ __global__ __launch_bounds__(256, 2) void tconv2d_bwd_fused_kernel(const float* 
       for (int r = 0; r < TH; ++r)
 #pragma unroll
         for (int h = 0; h < NH; ++h) acc[r][h] = __builtin_amdgcn_mfma_f32_4x4x1f32(a23[r].y, bw[ky][h][3], acc[r][h], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int r = 0; r < TH; ++r)
