@@ -186,6 +186,16 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
 // Wavefront (rp, ch) takes small rows {2rp, 2rp+1} and input channels 4ch..4ch+3 (64 weight
 // registers, resident); the two channel halves of a row meet in LDS and are added half 0 + half 1.
 // ----------------------------------------------------------------------------------------------
+// bf16 storage (BASELINE configs[2]): the four taps of a kernel row meet the four values of a weight quad in ONE
+// v_mfma_f32_4x4x4_16B_bf16 (a lane's operand = its four k) instead of four v_mfma_f32_4x4x1_f32; the activations come from bf16
+// tensors (exact), or are rounded to bf16 on the way (the fp32 minibatch under conv0: the operand precision of that configuration),
+// the weights are rounded once per launch.  fp32 storage: the instruction sequence of before.
+typedef short q4_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ q4_s16x4 q4_bits(const bf16x4& v) { return __builtin_bit_cast(q4_s16x4, v); }
+__device__ __forceinline__ f32x4 q4_mma(float a0, float a1, float a2, float a3, const bf16x4& w, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(q4_bits(__builtin_convertvector((f32x4){a0, a1, a2, a3}, bf16x4)), q4_bits(w), acc, 0, 0, 0);
+}
+
 template <int TH, class TO = float, class TS = float>  // TO: element type of `big` and `dact`, TS: of `small` (bf16 storage, common.h)
 __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restrict__ small_, long s_bs,
                                                             const float* __restrict__ w,
@@ -210,6 +220,26 @@ __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restr
 #pragma unroll
     for (int ky = 0; ky < 4; ++ky)
       bw[c][ky] = *reinterpret_cast<const f32x4*>(w + (((long)(4 * ch + c) * CB + q) * 4 + ky) * 4);
+  // bf16 storage of the output: the four taps of an output parity in one v_mfma_f32_4x4x4_16B_bf16 (bwp[c][py][px] = the quad
+  // the loop below meets in its (dyi, dxi) order)
+  constexpr bool BF16_MMA = sizeof(TO) == 2;
+  bf16x4 bwp[4][2][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        f32x4 v;
+#pragma unroll
+        for (int dyi = 0; dyi < 2; ++dyi)
+#pragma unroll
+          for (int dxi = 0; dxi < 2; ++dxi) {
+            const int dy = py - 1 + dyi, dx = px - 1 + dxi;
+            v[2 * dyi + dxi] = bw[c][py - 2 * dy + 1][px - 2 * dx + 1];
+          }
+        bwp[c][py][px] = __builtin_convertvector(v, bf16x4);
+      }
   const float bv = bias ? bias[q] : 0.f;
 
   const int tiles_x = Ws / TW, tiles_y = Hs / TH;
@@ -287,16 +317,22 @@ __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restr
 #pragma unroll
         for (int py = 0; py < 2; ++py)
 #pragma unroll
-          for (int px = 0; px < 2; ++px)
+          for (int px = 0; px < 2; ++px) {
+            if constexpr (BF16_MMA) {  // (dy, dx) = (py - 1, px - 1), (py - 1, px), (py, px - 1), (py, px)
+              acc[rr][py][px] = q4_mma(a[rr + py][px], a[rr + py][px + 1], a[rr + py + 1][px], a[rr + py + 1][px + 1], bwp[c][py][px],
+                                       acc[rr][py][px]);
+            } else {
 #pragma unroll
-            for (int dyi = 0; dyi < 2; ++dyi)
+              for (int dyi = 0; dyi < 2; ++dyi)
 #pragma unroll
-              for (int dxi = 0; dxi < 2; ++dxi) {
-                const int dy = py - 1 + dyi, dx = px - 1 + dxi;  // dy in {py-1, py}, dx in {px-1, px}
-                const int ky = py - 2 * dy + 1, kx = px - 2 * dx + 1;
-                acc[rr][py][px] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rr + dy + 1][dx + 1], bw[c][ky][kx],
-                                                                    acc[rr][py][px], 0, 0, 0);
-              }
+                for (int dxi = 0; dxi < 2; ++dxi) {
+                  const int dy = py - 1 + dyi, dx = px - 1 + dxi;  // dy in {py-1, py}, dx in {px-1, px}
+                  const int ky = py - 2 * dy + 1, kx = px - 2 * dx + 1;
+                  acc[rr][py][px] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rr + dy + 1][dx + 1], bw[c][ky][kx],
+                                                                      acc[rr][py][px], 0, 0, 0);
+                }
+            }
+          }
     }
     // ---- exchange: this wavefront finishes small row 2rp + ch, its partner (other ch) the other one
 #pragma unroll
@@ -790,16 +826,6 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
 }
 
 // ----------------------------------------------------------------------------------------------
-// bf16 storage (BASELINE configs[2]): the four taps of a kernel row meet the four values of a weight quad in ONE
-// v_mfma_f32_4x4x4_16B_bf16 (a lane's operand = its four k) instead of four v_mfma_f32_4x4x1_f32; the activations come from bf16
-// tensors (exact), or are rounded to bf16 on the way (the fp32 minibatch under conv0: the operand precision of that configuration),
-// the weights are rounded once per launch.  fp32 storage: the instruction sequence of before.
-typedef short q4_s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ q4_s16x4 q4_bits(const bf16x4& v) { return __builtin_bit_cast(q4_s16x4, v); }
-__device__ __forceinline__ f32x4 q4_mma(float a0, float a1, float a2, float a3, const bf16x4& w, f32x4 acc) {
-  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(q4_bits(__builtin_convertvector((f32x4){a0, a1, a2, a3}, bf16x4)), q4_bits(w), acc, 0, 0, 0);
-}
-
 // Same op on v_mfma_f32_4x4x1_16b_f32 for conv0 (4 -> 8 channels; as a data gradient: tconv5).  The
 // 4x4x1 form runs 16 independent 4x4 outer products per instruction, D[lane l][r] += A[lane 4*(l/4)+r]
 // * B[lane l], at the same FLOP/clk as 16x16x4 - so 8 output channels are two full instructions instead
