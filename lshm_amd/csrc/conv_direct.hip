@@ -26,6 +26,19 @@ namespace lshm {
 // into N = 32 over the whole 3 x 3 neighbourhood, K = 9 CS with 4/9 useful -- 3/2 of the matrix instructions and of the
 // weight-fragment registers).  Tile: TH small rows x TW small columns; 4 wavefronts, each (TH*TW/16)/4 m-tiles.
 // ----------------------------------------------------------------------------------------------
+// bf16 storage (BASELINE configs[2]): the four taps of a kernel row meet the four values of a weight quad in ONE
+// v_mfma_f32_4x4x4_16B_bf16 (a lane's operand = its four k) instead of four v_mfma_f32_4x4x1_f32; the activations come from bf16
+// tensors (exact), or are rounded to bf16 on the way (the fp32 minibatch under conv0: the operand precision of that configuration),
+// the weights are rounded once per launch.  fp32 storage: the instruction sequence of before.
+typedef short q4_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ q4_s16x4 q4_bits(const bf16x4& v) { return __builtin_bit_cast(q4_s16x4, v); }
+__device__ __forceinline__ f32x4 q4_mma(float a0, float a1, float a2, float a3, const bf16x4& w, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(q4_bits(__builtin_convertvector((f32x4){a0, a1, a2, a3}, bf16x4)), q4_bits(w), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 q16_mma(float a0, float a1, float a2, float a3, const bf16x4& w, f32x4 acc) {  // ... and v_mfma_f32_16x16x16_bf16 for four k-steps of a 16 x 16 tile
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(q4_bits(__builtin_convertvector((f32x4){a0, a1, a2, a3}, bf16x4)), q4_bits(w), acc, 0, 0, 0);
+}
+
 template <int CS, int CB, int TH, int TW, class TO = float>  // TO: element type of `big` and of `dact` (bf16 storage, common.h)
 __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __restrict__ small, long s_bs,
                                                              const float* __restrict__ w,
@@ -59,6 +72,19 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
 #pragma unroll
     for (int py = 0; py < 2; ++py) bf[s][py] = (kx >= 0 && kx <= 3) ? w[(((long)cs * CB + co) * 4 + 3 - py - 2 * dyi) * 4 + kx] : 0.f;
   }
+  // bf16 storage of the output: four k-steps per v_mfma_f32_16x16x16_bf16 (the last group padded with zeros)
+  constexpr bool BF16_MMA = sizeof(TO) == 2;
+  constexpr int KG = (KS + 3) / 4;
+  bf16x4 bfp[KG][2];
+#pragma unroll
+  for (int g = 0; g < KG; ++g)
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = 4 * g + e < KS ? bf[4 * g + e < KS ? 4 * g + e : 0][py] : 0.f;
+      bfp[g][py] = __builtin_convertvector(v, bf16x4);
+    }
   const float bv = bias ? bias[co] : 0.f;
   // persistent over tiles: the weight fragments above are loaded once per workgroup; the next
   // tile's patch is fetched into registers while the current tile computes (software pipeline)
@@ -123,6 +149,28 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
 
   // m-tile index -> (row in tile, first column in tile)
   constexpr int TPR = TW / 16;  // m-tiles per tile row
+  if constexpr (BF16_MMA) {
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      int koff[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = 4 * (4 * g + e < KS ? 4 * g + e : KS - 1) + lk;
+        const int cs = k / 6, r = k - cs * 6;
+        const int dyi = r / 3, dxp = r - dyi * 3;
+        koff[e] = (cs * PH + dyi) * PW + dxp;
+      }
+#pragma unroll
+      for (int i = 0; i < MW; ++i) {
+        const int mt = wave * MW + i;
+        const int row = mt / TPR, col = (mt - row * TPR) * 16;
+        const float* ap = &patch[row * PW + col + lm];
+#pragma unroll
+        for (int py = 0; py < 2; ++py)  // (a step past the last one meets a zero weight)
+          acc[i][py] = q16_mma(ap[koff[0] + py * PW], ap[koff[1] + py * PW], ap[koff[2] + py * PW], ap[koff[3] + py * PW], bfp[g][py], acc[i][py]);
+      }
+    }
+  } else {
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int k = 4 * s + lk;
@@ -138,6 +186,7 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
       for (int py = 0; py < 2; ++py)
         acc[i][py] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[py * PW], bf[s][py], acc[i][py], 0, 0, 0);
     }
+  }
   }
   // ---- accumulators -> LDS output tile [co][2*TH][2*TW] (bias + activation applied here)
 #pragma unroll
@@ -186,16 +235,6 @@ __global__ __launch_bounds__(256) void tconv2d_direct_kernel(const float* __rest
 // Wavefront (rp, ch) takes small rows {2rp, 2rp+1} and input channels 4ch..4ch+3 (64 weight
 // registers, resident); the two channel halves of a row meet in LDS and are added half 0 + half 1.
 // ----------------------------------------------------------------------------------------------
-// bf16 storage (BASELINE configs[2]): the four taps of a kernel row meet the four values of a weight quad in ONE
-// v_mfma_f32_4x4x4_16B_bf16 (a lane's operand = its four k) instead of four v_mfma_f32_4x4x1_f32; the activations come from bf16
-// tensors (exact), or are rounded to bf16 on the way (the fp32 minibatch under conv0: the operand precision of that configuration),
-// the weights are rounded once per launch.  fp32 storage: the instruction sequence of before.
-typedef short q4_s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ q4_s16x4 q4_bits(const bf16x4& v) { return __builtin_bit_cast(q4_s16x4, v); }
-__device__ __forceinline__ f32x4 q4_mma(float a0, float a1, float a2, float a3, const bf16x4& w, f32x4 acc) {
-  return __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(q4_bits(__builtin_convertvector((f32x4){a0, a1, a2, a3}, bf16x4)), q4_bits(w), acc, 0, 0, 0);
-}
-
 template <int TH, class TO = float, class TS = float>  // TO: element type of `big` and `dact`, TS: of `small` (bf16 storage, common.h)
 __global__ __launch_bounds__(256, 3) void tconv2d_q4_kernel(const float* __restrict__ small_, long s_bs,
                                                             const float* __restrict__ w,
@@ -736,6 +775,11 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
   float bf[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) bf[s] = lm < COUT ? w[((long)lm * CIN * 4 + s) * 4 + lk] : 0.f;
+  // bf16 storage of the input: the four kernel rows of an input channel in one v_mfma_f32_16x16x16_bf16
+  constexpr bool BF16_MMA = sizeof(TI) == 2;
+  bf16x4 bfp[CIN];
+#pragma unroll
+  for (int ci = 0; ci < CIN; ++ci) bfp[ci] = __builtin_convertvector((f32x4){bf[4 * ci], bf[4 * ci + 1], bf[4 * ci + 2], bf[4 * ci + 3]}, bf16x4);
   const float bv = (bias && lm < COUT) ? bias[lm] : 0.f;
   const int tiles_x = Wo / TW, tiles_y = Ho / TH;
   const int H = 2 * Ho, W = 2 * Wo;
@@ -791,6 +835,17 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
     f32x4 acc[MW];
 #pragma unroll
     for (int i = 0; i < MW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF16_MMA) {
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int i = 0; i < MW; ++i) {
+          const int mt = wave * MW + i;
+          const int row = mt / TPR, col = (mt - row * TPR) * 16;
+          const float* ap = &patch[(ci * PH + 2 * row) * PW + 2 * (col + lm) + lk];
+          acc[i] = q16_mma(ap[0], ap[PW], ap[2 * PW], ap[3 * PW], bfp[ci], acc[i]);
+        }
+    } else {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const int ci = s >> 2, ky = s & 3;
@@ -801,6 +856,7 @@ __global__ __launch_bounds__(256, 4) void conv2d_direct_kernel(const float* __re
         const float a = patch[(ci * PH + 2 * row + ky) * PW + 2 * (col + lm) + lk];
         acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bf[s], acc[i], 0, 0, 0);
       }
+    }
     }
     if (lm < COUT) {
 #pragma unroll

@@ -372,10 +372,13 @@ def test_fused_backward_of_outer_1d_layer_matches_separate_kernels(precision):
             name = f"{net}.{leaf}"
             assert torch.equal(tr.view(name, grads[0]), tr.view(name, grads[1])), name
     assert not torch.equal(grads[0], grads[1])  # the switch did select another kernel
-    assert rel_err(grads[0], grads[1]) < 2e-6
+    # (bf16 storage: the separate data-gradient kernels of the 2-D 12 / 8 layers multiply on the bf16 matrix instructions, weights
+    #  rounded to bf16; the one-pass kernels keep fp32 weights: 3e-5 of the gradient vector)
+    assert rel_err(grads[0], grads[1]) < (2e-6 if precision == "fp32" else 1e-4)
     # with bf16 storage a last-bit fp32 difference upstream can flip the rounding of a bf16 gradient image element
     # (4e-3 of that element); tensors whose gradient is a cancelling sum (fcuv3.weight, 1e-8) moved by 1.7e-4
-    tol = 2e-5 if precision == "fp32" else 1e-3
+    # (... and, since the separate data-gradient kernels round their weights to bf16 for the matrix instructions, 3e-3 on net.conv0.weight)
+    tol = 2e-5 if precision == "fp32" else 1e-2
     for name in tr.layout:
         assert rel_err(tr.view(name, grads[0]), tr.view(name, grads[1])) < tol, name
 
